@@ -1,0 +1,135 @@
+"""ctypes binding of ``libdxmat.so`` (C ABI declared in ``include/dxmat.h``).
+
+There is no fallback: if the shared library is missing or no HIP device is usable the
+constructors raise.  ``build()`` compiles the library in-tree with ``hipcc --offload-arch=gfx950``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdxmat.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+DXM_MAX_STATE_FIELDS = 4
+LAW_ELASTIC_ISO, LAW_J2_LINEAR, LAW_J2_VOCE, LAW_FEFP_J2_VOCE = 0, 1, 2, 3
+S0, S1 = 0, 1
+
+
+class DxmError(RuntimeError):
+    """Hard error reported by libdxmat (negative return code)."""
+
+
+class LawInfo(C.Structure):
+    _fields_ = [
+        ("n_grad", C.c_int32),
+        ("n_flux", C.c_int32),
+        ("n_params", C.c_int32),
+        ("n_isv_fields", C.c_int32),
+        ("isv_dim", C.c_int32 * DXM_MAX_STATE_FIELDS),
+        ("isv_name", C.c_char_p * DXM_MAX_STATE_FIELDS),
+        ("n_isv_total", C.c_int32),
+        ("algorithmic_bytes_per_point", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_points", C.c_int64),
+        ("n_plastic", C.c_int64),
+        ("n_not_converged", C.c_int64),
+        ("n_nan", C.c_int64),
+        ("max_local_iters", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_dp = C.POINTER(C.c_double)
+_h = C.c_void_p
+
+#: every symbol include/dxmat.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "dxm_abi_version": (C.c_int, []),
+    "dxm_last_error": (C.c_char_p, []),
+    "dxm_device_count": (C.c_int, []),
+    "dxm_law_info_get": (C.c_int, [C.c_int, C.POINTER(LawInfo)]),
+    "dxm_create": (_h, [C.c_int, _dp, C.c_int, C.c_int64, C.c_int]),
+    "dxm_destroy": (C.c_int, [_h]),
+    "dxm_npoints": (C.c_int64, [_h]),
+    "dxm_law": (C.c_int, [_h]),
+    "dxm_set_params": (C.c_int, [_h, _dp, C.c_int]),
+    "dxm_set_newton": (C.c_int, [_h, C.c_int, C.c_double]),
+    "dxm_set_state": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    "dxm_get_state": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    "dxm_advance": (C.c_int, [_h]),
+    "dxm_revert": (C.c_int, [_h]),
+    "dxm_integrate": (
+        C.c_int,
+        [_h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],
+    ),
+    "dxm_integrate_device": (
+        C.c_int,
+        [_h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "dxm_get_stats": (C.c_int, [_h, C.POINTER(Stats)]),
+    "dxm_isv_device": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_void_p]),
+    "dxm_state_ptr": (C.c_void_p, [_h, C.c_int, C.c_int, C.c_int]),
+    "dxm_kernel_name": (C.c_char_p, [_h]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile ``libdxmat.so`` for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["make", "-C", CSRC_DIR], check=True)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every ABI symbol; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DxmError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` or `make -C dolfinx_materials_amd/csrc`). "
+            "dolfinx_materials_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().dxm_last_error() or b"").decode()
+
+
+def check(rc: int) -> int:
+    """Raise on hard errors (<0); pass soft codes (>=0) through."""
+    if rc < 0:
+        raise DxmError(f"libdxmat error {rc}: {last_error()}")
+    return rc
+
+
+def device_count() -> int:
+    n = load().dxm_device_count()
+    return max(n, 0)
+
+
+def law_info(law: int) -> LawInfo:
+    info = LawInfo()
+    check(load().dxm_law_info_get(law, C.byref(info)))
+    return info

@@ -1,0 +1,89 @@
+// Shared device-side definitions for the gfx950 constitutive-update kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dxm {
+
+constexpr int WAVE = 64;            // gfx950 wavefront
+constexpr int BLOCK = 256;          // 4 waves per workgroup
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+
+// Material parameters as the kernels consume them (built on the host from E, nu, ...).
+struct LawParams {
+  double lambda;   // first Lame coefficient          python_materials/elasticity.py:12-13
+  double mu;       // shear modulus
+  double kappa;    // bulk modulus (finite strain)
+  double sig0;     // initial yield stress
+  double h1;       // linear: H           | Voce: sigu
+  double h2;       // linear: unused      | Voce: b
+  double tol;      // absolute residual tolerance of the local Newton (= rtol * sig0)
+  int32_t maxit;   // local Newton iteration cap
+  int32_t pad;
+};
+
+// One record per workgroup, summed on the host on demand (no atomics on the hot path: a
+// same-address atomic fan-in of a few thousand workgroups costs ~10 ns each at kernel end).
+struct BlockStats {
+  unsigned long long n_plastic;
+  unsigned long long n_not_converged;
+  unsigned long long n_nan;
+  unsigned long long max_iters;
+};
+
+// LDS traffic between lanes of ONE wave: DS operations of a wave execute in issue order, so no
+// s_barrier is needed; the fences only stop the compiler from moving LDS accesses across.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_down(v, off, WAVE);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// Reduce per-thread counters over the workgroup and let thread 0 store the block record.
+__device__ __forceinline__ void store_block_stats(BlockStats* out, unsigned long long n_plastic,
+                                                  unsigned long long n_notconv,
+                                                  unsigned long long n_nan,
+                                                  unsigned long long max_it,
+                                                  unsigned long long* red /* LDS, 4*WAVES_PER_BLOCK */) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x >> 6;
+  n_plastic = wave_sum(n_plastic);
+  n_notconv = wave_sum(n_notconv);
+  n_nan = wave_sum(n_nan);
+  max_it = wave_max(max_it);
+  if (lane == 0) {
+    red[wid * 4 + 0] = n_plastic;
+    red[wid * 4 + 1] = n_notconv;
+    red[wid * 4 + 2] = n_nan;
+    red[wid * 4 + 3] = max_it;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BlockStats s = {0, 0, 0, 0};
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+      s.n_plastic += red[w * 4 + 0];
+      s.n_not_converged += red[w * 4 + 1];
+      s.n_nan += red[w * 4 + 2];
+      s.max_iters = red[w * 4 + 3] > s.max_iters ? red[w * 4 + 3] : s.max_iters;
+    }
+    out[blockIdx.x] = s;
+  }
+}
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+}  // namespace dxm

@@ -1,0 +1,525 @@
+// libdxmat.so -- C ABI (include/dxmat.h) over the gfx950 constitutive-update kernels.
+//
+// Host side of the batch dispatch that the reference performs in
+//   JAXMaterial.integrate / DataManager           dolfinx_materials/jaxmat.py:30-43, :208-234
+//   Material.integrate / MaterialStateManager     dolfinx_materials/generic.py:176-295
+// with the state kept device-resident in SoA form instead of dicts of (N, dim) arrays.
+// There is deliberately no CPU implementation behind this ABI.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dxmat.h"
+#include "dxm_common.hpp"
+#include "fefp.hpp"
+#include "small_strain.hpp"
+
+using namespace dxm;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// law descriptors
+// ------------------------------------------------------------------------------------------
+struct LawDesc {
+  int n_grad, n_flux, n_params;
+  int n_isv_fields;                       // user-visible
+  int isv_dim[DXM_MAX_STATE_FIELDS];
+  const char* isv_name[DXM_MAX_STATE_FIELDS];
+  int isv_slot[DXM_MAX_STATE_FIELDS];     // first SoA slot of the field
+  int n_slots;                            // SoA slots incl. hidden ones
+  int alg_bytes;
+  const char* kernel;
+};
+
+static const LawDesc kLaws[DXM_LAW_COUNT] = {
+    {6, 6, 2, 0, {0, 0, 0, 0}, {nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, 0, 384,
+     "small_strain_kernel<0"},
+    {6, 6, 4, 2, {1, 6, 0, 0}, {"p", "epsp", nullptr, nullptr}, {0, 1, 0, 0}, SS_NSLOTS, 496,
+     "small_strain_kernel<1"},
+    {6, 6, 5, 2, {1, 6, 0, 0}, {"p", "epsp", nullptr, nullptr}, {0, 1, 0, 0}, SS_NSLOTS, 496,
+     "small_strain_kernel<2"},
+    {9, 9, 5, 2, {1, 6, 0, 0}, {"p", "be_bar", nullptr, nullptr}, {0, 1, 0, 0}, FEFP_NSLOTS, 976,
+     "fefp_kernel"},
+};
+
+static int isv_total(const LawDesc& d) {
+  int t = 0;
+  for (int f = 0; f < d.n_isv_fields; ++f) t += d.isv_dim[f];
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct dxm_material {
+  int law = 0;
+  int device = 0;
+  int64_t n = 0;
+  int64_t ld = 0;  // SoA leading dimension (n rounded up to 256)
+  LawParams prm{};
+  std::vector<double> raw_params;
+  int maxit = 25;
+  double rtol = 1e-14;
+  double* state[2] = {nullptr, nullptr};  // [n_slots][ld] each
+  bool s1_alias = false;  // after advance()/revert() s1 == s0 until the next integrate: no copy is made
+  BlockStats* d_stats = nullptr;
+  int stats_capacity = 0;
+  int last_grid = 0;
+  hipStream_t last_stream = nullptr;
+  bool launched = false;
+  hipStream_t own_stream = nullptr;
+  int num_cu = 256;
+  int blocks_per_cu = 5;
+  bool nt_store = false;
+  // host-path staging (device side), allocated on first dxm_integrate
+  double* d_grad = nullptr;
+  double* d_flux = nullptr;
+  double* d_isv = nullptr;
+  double* d_ct = nullptr;
+};
+
+static int build_params(dxm_material* m, const double* p, int np) {
+  const LawDesc& d = kLaws[m->law];
+  if (np != d.n_params) return fail(-1, "law %d expects %d parameters, got %d", m->law, d.n_params, np);
+  const double E = p[0], nu = p[1];
+  if (!(E > 0.0) || !(nu > -1.0 && nu < 0.5)) return fail(-1, "invalid elastic constants E=%g nu=%g", E, nu);
+  LawParams q{};
+  q.lambda = E * nu / (1 + nu) / (1 - 2 * nu);  // python_materials/elasticity.py:12-13
+  q.mu = E / 2 / (1 + nu);
+  q.kappa = q.lambda + 2.0 * q.mu / 3.0;
+  q.sig0 = 1.0;
+  switch (m->law) {
+    case DXM_LAW_ELASTIC_ISO: break;
+    case DXM_LAW_J2_LINEAR: q.sig0 = p[2]; q.h1 = p[3]; break;
+    case DXM_LAW_J2_VOCE:
+    case DXM_LAW_FEFP_J2_VOCE: q.sig0 = p[2]; q.h1 = p[3]; q.h2 = p[4]; break;
+  }
+  q.maxit = m->maxit;
+  q.tol = m->rtol * fabs(q.sig0);
+  m->prm = q;
+  m->raw_params.assign(p, p + np);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// small helper kernels (not on the hot path)
+// ------------------------------------------------------------------------------------------
+__global__ void fill_slot_kernel(double* dst, int64_t count, double value) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = value;
+}
+
+struct PackMap { int n; int slot[16]; };
+
+// SoA state -> AoS (n, total) internal-state-variable array (jaxmat.py:46-58 `_hcat_mixed`).
+__global__ void pack_isv_kernel(const double* __restrict__ soa, int64_t ld, int64_t n,
+                                double* __restrict__ aos, PackMap map) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = n * map.n;
+  if (t >= total) return;
+  const int64_t i = t / map.n;
+  const int k = (int)(t - i * map.n);
+  aos[t] = soa[(int64_t)map.slot[k] * ld + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int dxm_abi_version(void) { return DXM_ABI_VERSION; }
+
+const char* dxm_last_error(void) { return g_last_error.c_str(); }
+
+int dxm_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(-2, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int dxm_law_info_get(int law, dxm_law_info* out) {
+  if (law < 0 || law >= DXM_LAW_COUNT || !out) return fail(-1, "unknown law id %d", law);
+  const LawDesc& d = kLaws[law];
+  memset(out, 0, sizeof(*out));
+  out->n_grad = d.n_grad;
+  out->n_flux = d.n_flux;
+  out->n_params = d.n_params;
+  out->n_isv_fields = d.n_isv_fields;
+  for (int f = 0; f < DXM_MAX_STATE_FIELDS; ++f) {
+    out->isv_dim[f] = d.isv_dim[f];
+    out->isv_name[f] = d.isv_name[f];
+  }
+  out->n_isv_total = isv_total(d);
+  out->algorithmic_bytes_per_point = d.alg_bytes;
+  return 0;
+}
+
+static int init_state(dxm_material* m) {
+  const LawDesc& d = kLaws[m->law];
+  if (d.n_slots == 0) return 0;
+  const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
+  for (int w = 0; w < 2; ++w) {
+    HIP_TRY(hipMemsetAsync(m->state[w], 0, bytes, m->own_stream));
+    if (m->law == DXM_LAW_FEFP_J2_VOCE) {
+      // be_bar = Cp^-1 = identity: unstressed natural configuration
+      // (demos/jax/finite_strain_elastoplasticity/finite_strain_elastoplasticity.py:181)
+      const int ones[6] = {FEFP_SLOT_BE + 0, FEFP_SLOT_BE + 1, FEFP_SLOT_BE + 2,
+                           FEFP_SLOT_CPI + 0, FEFP_SLOT_CPI + 1, FEFP_SLOT_CPI + 2};
+      for (int s : ones) {
+        const int blocks = (int)((m->ld + 255) / 256);
+        hipLaunchKernelGGL(fill_slot_kernel, dim3(blocks), dim3(256), 0, m->own_stream,
+                           m->state[w] + (size_t)s * m->ld, m->ld, 1.0);
+      }
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(m->own_stream));
+  return 0;
+}
+
+dxm_material* dxm_create(int law, const double* params, int n_params, int64_t npoints, int device) {
+  if (law < 0 || law >= DXM_LAW_COUNT) { fail(-1, "unknown law id %d", law); return nullptr; }
+  if (npoints < 0) { fail(-1, "negative point count"); return nullptr; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    fail(-2, "no usable HIP device (hipGetDeviceCount: %s, count %d); libdxmat has no CPU fallback",
+         hipGetErrorString(e), ndev);
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev) { fail(-1, "device %d out of range [0,%d)", device, ndev); return nullptr; }
+  dxm_material* m = new dxm_material();
+  m->law = law;
+  m->device = device;
+  m->n = npoints;
+  m->ld = ((npoints + 255) / 256) * 256;
+  if (m->ld == 0) m->ld = 256;
+  if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : 5;
+  if (const char* s = getenv("DXM_NT_STORE")) m->nt_store = atoi(s) != 0;
+  auto bail = [&](void) -> dxm_material* { dxm_destroy(m); return nullptr; };
+  if (build_params(m, params, n_params) != 0) return bail();
+  if (hipSetDevice(device) != hipSuccess) { fail(-2, "hipSetDevice(%d) failed", device); return bail(); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->num_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(-2, "hipStreamCreate failed"); return bail();
+  }
+  const LawDesc& d = kLaws[law];
+  if (d.n_slots > 0) {
+    const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
+    for (int w = 0; w < 2; ++w) {
+      if (hipMalloc(&m->state[w], bytes) != hipSuccess) {
+        fail(-3, "hipMalloc of %zu state bytes failed", bytes); return bail();
+      }
+    }
+  }
+  m->stats_capacity = m->num_cu * 16;
+  if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {
+    fail(-3, "hipMalloc of stats failed"); return bail();
+  }
+  if (init_state(m) != 0) return bail();
+  g_last_error.clear();
+  return m;
+}
+
+int dxm_destroy(dxm_material* m) {
+  if (!m) return 0;
+  (void)hipSetDevice(m->device);
+  if (m->launched && m->last_stream) (void)hipStreamSynchronize(m->last_stream);
+  for (int w = 0; w < 2; ++w) if (m->state[w]) (void)hipFree(m->state[w]);
+  if (m->d_stats) (void)hipFree(m->d_stats);
+  if (m->d_grad) (void)hipFree(m->d_grad);
+  if (m->d_flux) (void)hipFree(m->d_flux);
+  if (m->d_isv) (void)hipFree(m->d_isv);
+  if (m->d_ct) (void)hipFree(m->d_ct);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  delete m;
+  return 0;
+}
+
+int64_t dxm_npoints(const dxm_material* m) { return m ? m->n : -1; }
+int dxm_law(const dxm_material* m) { return m ? m->law : -1; }
+
+int dxm_set_params(dxm_material* m, const double* params, int n_params) {
+  if (!m || !params) return fail(-1, "null argument");
+  return build_params(m, params, n_params);
+}
+
+int dxm_set_newton(dxm_material* m, int maxit, double rtol) {
+  if (!m) return fail(-1, "null handle");
+  if (maxit < 1 || !(rtol > 0.0)) return fail(-1, "invalid Newton controls maxit=%d rtol=%g", maxit, rtol);
+  m->maxit = maxit;
+  m->rtol = rtol;
+  return build_params(m, m->raw_params.data(), (int)m->raw_params.size());
+}
+
+static int check_field(const dxm_material* m, int which, int field) {
+  if (!m) return fail(-1, "null handle");
+  if (which != DXM_S0 && which != DXM_S1) return fail(-1, "state selector must be DXM_S0 or DXM_S1");
+  const LawDesc& d = kLaws[m->law];
+  if (field < 0 || field >= d.n_isv_fields) return fail(-1, "law %d has no state field %d", m->law, field);
+  return 0;
+}
+
+static int sync_last(dxm_material* m) {
+  if (m->launched) {
+    HIP_TRY(hipStreamSynchronize(m->last_stream));
+  }
+  return 0;
+}
+
+static double* state_of(const dxm_material* m, int which) {
+  return m->state[(which == DXM_S1 && !m->s1_alias) ? 1 : 0];
+}
+
+// A write to s1 while it is served from s0 needs its own storage first.
+static int materialize_s1(dxm_material* m) {
+  if (!m->s1_alias) return 0;
+  const LawDesc& d = kLaws[m->law];
+  if (d.n_slots > 0)
+    HIP_TRY(hipMemcpy(m->state[1], m->state[0], (size_t)d.n_slots * m->ld * sizeof(double),
+                      hipMemcpyDeviceToDevice));
+  m->s1_alias = false;
+  return 0;
+}
+
+// forward
+static int refresh_hidden_state(dxm_material* m, int which);
+
+int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos) {
+  if (int rc = check_field(m, which, field)) return rc;
+  if (!host_aos) return fail(-1, "null host pointer");
+  HIP_TRY(hipSetDevice(m->device));
+  if (int rc = sync_last(m)) return rc;
+  const LawDesc& d = kLaws[m->law];
+  const int dim = d.isv_dim[field];
+  const int64_t n = m->n;
+  if (n == 0) return 0;
+  std::vector<double> tmp((size_t)dim * n);
+  for (int64_t i = 0; i < n; ++i)
+    for (int c = 0; c < dim; ++c) tmp[(size_t)c * n + i] = host_aos[i * dim + c];
+  if (which == DXM_S1) if (int rc = materialize_s1(m)) return rc;
+  double* dst = state_of(m, which) + (size_t)d.isv_slot[field] * m->ld;
+  HIP_TRY(hipMemcpy2D(dst, m->ld * sizeof(double), tmp.data(), n * sizeof(double),
+                      n * sizeof(double), dim, hipMemcpyHostToDevice));
+  return refresh_hidden_state(m, which);
+}
+
+int dxm_get_state(dxm_material* m, int which, int field, double* host_aos) {
+  if (int rc = check_field(m, which, field)) return rc;
+  if (!host_aos) return fail(-1, "null host pointer");
+  HIP_TRY(hipSetDevice(m->device));
+  if (int rc = sync_last(m)) return rc;
+  const LawDesc& d = kLaws[m->law];
+  const int dim = d.isv_dim[field];
+  const int64_t n = m->n;
+  if (n == 0) return 0;
+  std::vector<double> tmp((size_t)dim * n);
+  const double* src = state_of(m, which) + (size_t)d.isv_slot[field] * m->ld;
+  HIP_TRY(hipMemcpy2D(tmp.data(), n * sizeof(double), src, m->ld * sizeof(double),
+                      n * sizeof(double), dim, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i)
+    for (int c = 0; c < dim; ++c) host_aos[i * dim + c] = tmp[(size_t)c * n + i];
+  return 0;
+}
+
+int dxm_advance(dxm_material* m) {
+  if (!m) return fail(-1, "null handle");
+  // s0 <- s1 (generic.py:212-213 copies, jaxmat.py:39-40 aliases).  Done by swapping the two
+  // device buffers; until the next integrate rewrites s1 in full, s1 reads are served from s0
+  // (QuadratureMap.advance reads the final state right after update(): quadrature_map.py:355-356).
+  if (!m->s1_alias) {
+    double* t = m->state[0];
+    m->state[0] = m->state[1];
+    m->state[1] = t;
+    m->s1_alias = true;
+  }
+  return 0;
+}
+
+int dxm_revert(dxm_material* m) {
+  if (!m) return fail(-1, "null handle");
+  m->s1_alias = true;  // s1 <- s0 (generic.py:215-216, jaxmat.py:42-43)
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- launch -------------------------------------------------------------------------------
+template <int LAW>
+static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, const double* grad,
+                                double* flux, double* ct) {
+  if (m->nt_store)
+    hipLaunchKernelGGL((small_strain_kernel<LAW, true>), dim3(grid), dim3(BLOCK), 0, st, m->prm,
+                       m->n, grad, m->state[0], m->state[1], m->ld, flux, ct, m->d_stats);
+  else
+    hipLaunchKernelGGL((small_strain_kernel<LAW, false>), dim3(grid), dim3(BLOCK), 0, st, m->prm,
+                       m->n, grad, m->state[0], m->state[1], m->ld, flux, ct, m->d_stats);
+}
+
+static int launch(dxm_material* m, const double* grad, double* flux, double* ct, hipStream_t st) {
+  if (m->n == 0) { m->last_grid = 0; return 0; }
+  if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
+    return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
+  const int64_t ntiles = (m->n + WAVE - 1) / WAVE;
+  int64_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int64_t cap = (int64_t)m->num_cu * m->blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks > m->stats_capacity) blocks = m->stats_capacity;
+  const int grid = (int)blocks;
+  switch (m->law) {
+    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, grad, flux, ct); break;
+    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, grad, flux, ct); break;
+    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, grad, flux, ct); break;
+    case DXM_LAW_FEFP_J2_VOCE:
+      hipLaunchKernelGGL(fefp_kernel, dim3(grid), dim3(BLOCK), 0, st, m->prm, m->n, grad,
+                         m->state[0], m->state[1], m->ld, flux, ct, m->d_stats);
+      break;
+    default: return fail(-1, "law %d not launchable", m->law);
+  }
+  HIP_TRY(hipGetLastError());
+  m->last_grid = grid;
+  m->last_stream = st;
+  m->launched = true;
+  m->s1_alias = false;  // the kernel rewrites every slot of s1
+  return 0;
+}
+
+extern "C" {
+
+int dxm_integrate_device(dxm_material* m, const double* grad_dev, double dt, double* flux_dev,
+                         double* ct_dev, void* hip_stream) {
+  (void)dt;  // rate-independent laws; QuadratureMap never forwards dt (quadrature_map.py:321)
+  if (!m) return fail(-1, "null handle");
+  if (m->n > 0 && (!grad_dev || !flux_dev || !ct_dev)) return fail(-1, "null device pointer");
+  HIP_TRY(hipSetDevice(m->device));
+  return launch(m, grad_dev, flux_dev, ct_dev, (hipStream_t)hip_stream);
+}
+
+int dxm_get_stats(dxm_material* m, dxm_stats* stats) {
+  if (!m) return fail(-1, "null handle");
+  dxm_stats s{};
+  s.n_points = m->n;
+  if (m->launched && m->last_grid > 0) {
+    HIP_TRY(hipSetDevice(m->device));
+    std::vector<BlockStats> h(m->last_grid);
+    HIP_TRY(hipMemcpyAsync(h.data(), m->d_stats, sizeof(BlockStats) * m->last_grid,
+                           hipMemcpyDeviceToHost, m->last_stream));
+    HIP_TRY(hipStreamSynchronize(m->last_stream));
+    for (const BlockStats& b : h) {
+      s.n_plastic += (int64_t)b.n_plastic;
+      s.n_not_converged += (int64_t)b.n_not_converged;
+      s.n_nan += (int64_t)b.n_nan;
+      if ((int32_t)b.max_iters > s.max_local_iters) s.max_local_iters = (int32_t)b.max_iters;
+    }
+  }
+  if (stats) *stats = s;
+  if (s.n_not_converged > 0)
+    return (int)(s.n_not_converged > 0x7fffffff ? 0x7fffffff : s.n_not_converged);
+  return 0;
+}
+
+int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_stream) {
+  if (!m) return fail(-1, "null handle");
+  if (which != DXM_S0 && which != DXM_S1) return fail(-1, "state selector must be DXM_S0 or DXM_S1");
+  const LawDesc& d = kLaws[m->law];
+  const int total = isv_total(d);
+  if (total == 0 || m->n == 0) return 0;
+  if (!isv_aos_dev) return fail(-1, "null device pointer");
+  HIP_TRY(hipSetDevice(m->device));
+  PackMap map{};
+  map.n = total;
+  int k = 0;
+  for (int f = 0; f < d.n_isv_fields; ++f)
+    for (int c = 0; c < d.isv_dim[f]; ++c) map.slot[k++] = d.isv_slot[f] + c;
+  const int64_t work = m->n * total;
+  const int blocks = (int)((work + 255) / 256);
+  hipLaunchKernelGGL(pack_isv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
+                     state_of(m, which), m->ld, m->n, isv_aos_dev, map);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
+                  double* isv_aos, double* ct_aos, dxm_stats* stats) {
+  if (!m) return fail(-1, "null handle");
+  const LawDesc& d = kLaws[m->law];
+  const int64_t n = m->n;
+  if (n == 0) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    return 0;
+  }
+  if (!grad_aos) return fail(-1, "null gradient pointer");
+  HIP_TRY(hipSetDevice(m->device));
+  const int total = isv_total(d);
+  if (!m->d_grad) {
+    HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * n * d.n_grad));
+    HIP_TRY(hipMalloc(&m->d_flux, sizeof(double) * n * d.n_flux));
+    HIP_TRY(hipMalloc(&m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad));
+    if (total > 0) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * n * total));
+  }
+  hipStream_t st = m->own_stream;
+  if (m->launched && m->last_stream != st) HIP_TRY(hipStreamSynchronize(m->last_stream));
+  HIP_TRY(hipMemcpyAsync(m->d_grad, grad_aos, sizeof(double) * n * d.n_grad, hipMemcpyHostToDevice, st));
+  if (int rc = launch(m, m->d_grad, m->d_flux, m->d_ct, st)) return rc;
+  (void)dt;
+  if (flux_aos)
+    HIP_TRY(hipMemcpyAsync(flux_aos, m->d_flux, sizeof(double) * n * d.n_flux, hipMemcpyDeviceToHost, st));
+  if (isv_aos && total > 0) {
+    if (int rc = dxm_isv_device(m, DXM_S1, m->d_isv, st)) return rc;
+    HIP_TRY(hipMemcpyAsync(isv_aos, m->d_isv, sizeof(double) * n * total, hipMemcpyDeviceToHost, st));
+  }
+  if (ct_aos)
+    HIP_TRY(hipMemcpyAsync(ct_aos, m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad,
+                           hipMemcpyDeviceToHost, st));
+  return dxm_get_stats(m, stats);  // synchronises st
+}
+
+const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp) {
+  if (check_field(m, which, field)) return nullptr;
+  const LawDesc& d = kLaws[m->law];
+  if (comp < 0 || comp >= d.isv_dim[field]) { fail(-1, "component out of range"); return nullptr; }
+  return state_of(m, which) + (size_t)(d.isv_slot[field] + comp) * m->ld;
+}
+
+const char* dxm_kernel_name(const dxm_material* m) { return m ? kLaws[m->law].kernel : ""; }
+
+}  // extern "C"
+
+// FeFp keeps a hidden state field (isochoric Cp^-1) next to the user-visible be_bar; when the
+// user overwrites be_bar through set_initial_state_dict, rebuild it assuming F_n = I
+// (be_bar = Cp^-1 in that configuration).
+static int refresh_hidden_state(dxm_material* m, int which) {
+  if (m->law != DXM_LAW_FEFP_J2_VOCE || m->n == 0) return 0;
+  HIP_TRY(hipMemcpy2D(state_of(m, which) + (size_t)FEFP_SLOT_CPI * m->ld, m->ld * sizeof(double),
+                      state_of(m, which) + (size_t)FEFP_SLOT_BE * m->ld, m->ld * sizeof(double),
+                      m->n * sizeof(double), 6, hipMemcpyDeviceToDevice));
+  return 0;
+}

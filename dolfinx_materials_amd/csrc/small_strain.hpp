@@ -1,0 +1,255 @@
+// Small-strain constitutive updates for gfx950: isotropic elasticity, J2 plasticity with linear or
+// Voce isotropic hardening.  One fused kernel per law: trial state, yield test, local Newton,
+// stress, consistent tangent and state write-back.
+//
+// Replaces, per Gauss point, what the reference obtains from
+//   vmap(jacfwd(behavior.constitutive_update))      dolfinx_materials/jaxmat.py:147-164
+// Arithmetic spec (the only in-tree statement of the return mapping):
+//   tests/mfront/IsotropicLinearHardeningPlasticity.mfront:49-77
+//   python_materials/elasticity.py:12-24 (elastic), tests/test_FeFp_jax.py:14-15 (Voce law)
+//
+// Mapping (HBM-bound streaming kernel, ~1 flop/B fp64, no MFMA):
+//   * one thread per Gauss point, one wave per tile of 64 points, grid-stride over tiles;
+//   * the AoS boundary arrays (strain (N,6) in, stress (N,6) and tangent (N,36) out: the memory
+//     of the dolfinx quadrature Functions) are moved with 16 B-per-lane, fully coalesced
+//     accesses and re-distributed between lanes through a wave-private LDS region (no s_barrier);
+//   * persistent state (p, eps_p) is SoA in HBM: 8 B-per-lane coalesced loads/stores;
+//   * the 6x6 tangent is never materialised per thread: each point stages 9 doubles
+//     (c1, c2, c3, n[6]) in LDS and the whole wave then evaluates
+//         Ct = c1 1x1 + c2 I + c3 n x n
+//     entry by entry in output order, so the dominant 288 B/point stream leaves as contiguous
+//     1 KiB wave stores.
+#pragma once
+#include "dxm_common.hpp"
+
+namespace dxm {
+
+enum { LAW_ELASTIC = 0, LAW_J2_LINEAR = 1, LAW_J2_VOCE = 2 };
+
+// state slots (SoA, leading dimension ld): 0 = p, 1..6 = eps_p (Mandel)
+constexpr int SS_NSLOTS = 7;
+
+constexpr int SS_STAGE = 64 * 6;   // doubles per wave: strain in / stress out staging
+constexpr int SS_COEF = 64 * 9;    // doubles per wave: (c1,c2,c3,n0..n5) per point
+constexpr int SS_LDS_PER_WAVE = SS_STAGE + SS_COEF;
+
+template <int LAW>
+__device__ __forceinline__ double hardening_R(const LawParams& prm, double p) {
+  if constexpr (LAW == LAW_J2_LINEAR) {
+    return prm.sig0 + prm.h1 * p;
+  } else {
+    return prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exp(-prm.h2 * p));
+  }
+}
+template <int LAW>
+__device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
+  if constexpr (LAW == LAW_J2_LINEAR) {
+    return prm.h1;
+  } else {
+    return (prm.h1 - prm.sig0) * prm.h2 * exp(-prm.h2 * p);
+  }
+}
+
+template <int LAW, bool NT_STORE>
+__global__ void __launch_bounds__(BLOCK)
+small_strain_kernel(const LawParams prm, const int64_t n, const double* __restrict__ eps,
+                    const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
+                    double* __restrict__ sig, double* __restrict__ ct,
+                    BlockStats* __restrict__ stats) {
+  __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * SS_LDS_PER_WAVE];
+  __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
+
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x >> 6;
+  double* stage = lds_all + wid * SS_LDS_PER_WAVE;
+  double* coef = stage + SS_STAGE;
+  double2_t* stage2 = reinterpret_cast<double2_t*>(stage);
+
+  const int64_t ntiles = (n + WAVE - 1) / WAVE;
+  const int64_t tile_stride = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+
+  unsigned long long c_plastic = 0, c_notconv = 0, c_nan = 0, c_maxit = 0;
+
+  const double lambda = prm.lambda, mu = prm.mu;
+
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; tile < ntiles;
+       tile += tile_stride) {
+    const int64_t base = tile * WAVE;
+    const int npts = (n - base) < WAVE ? (int)(n - base) : WAVE;
+    const bool valid = lane < npts;
+    const int64_t gi = base + lane;
+
+    // ---- 1. coalesced strain load (3 x 1 KiB per wave) into LDS ------------------------------
+    {
+      const double2_t* gsrc = reinterpret_cast<const double2_t*>(eps + base * 6);
+      double2_t v[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = k * WAVE + lane;
+        v[k] = (idx < npts * 3) ? gsrc[idx] : double2_t{0.0, 0.0};
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) stage2[k * WAVE + lane] = v[k];
+    }
+    // ---- old state, SoA (issued before the LDS round trip completes) -------------------------
+    double p_n = 0.0, ep[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (LAW != LAW_ELASTIC) {
+      if (valid) {
+        p_n = s0[gi];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ep[c] = s0[(int64_t)(1 + c) * ld + gi];
+      }
+    }
+    wave_lds_sync();
+    // ---- 2. my point's strain ----------------------------------------------------------------
+    double e[6];
+    {
+      const double2_t a = stage2[lane * 3 + 0], b = stage2[lane * 3 + 1], c = stage2[lane * 3 + 2];
+      e[0] = a.x; e[1] = a.y; e[2] = b.x; e[3] = b.y; e[4] = c.x; e[5] = c.y;
+    }
+    wave_lds_sync();  // staging region is reused for the stress below
+
+    // ---- 3. constitutive update --------------------------------------------------------------
+    double c1 = lambda, c2 = 2.0 * mu, c3 = 0.0;
+    double nn[6] = {0, 0, 0, 0, 0, 0};
+    double p_new = p_n;
+    if constexpr (LAW != LAW_ELASTIC) {
+      // trial elastic strain                                   mfront:52  eel += deto
+#pragma unroll
+      for (int c = 0; c < 6; ++c) e[c] -= ep[c];
+      const double tr = e[0] + e[1] + e[2];
+      const double third = tr / 3.0;
+      double se[6];
+      se[0] = 2.0 * mu * (e[0] - third);
+      se[1] = 2.0 * mu * (e[1] - third);
+      se[2] = 2.0 * mu * (e[2] - third);
+      se[3] = 2.0 * mu * e[3];
+      se[4] = 2.0 * mu * e[4];
+      se[5] = 2.0 * mu * e[5];                                // mfront:53
+      double nrm2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) nrm2 += se[c] * se[c];
+      const double seq = sqrt(1.5 * nrm2);                    // mfront:54
+      const double f = seq - hardening_R<LAW>(prm, p_n);      // mfront:55
+      if (f > 0.0) {
+        double dp;
+        unsigned iters = 0;
+        if constexpr (LAW == LAW_J2_LINEAR) {
+          dp = f / (prm.h1 + 3.0 * mu);                       // mfront:62-63
+        } else {
+          // r(dp) = seq - 3 mu dp - R(p_n + dp) = 0, monotone Newton from dp = 0
+          dp = 0.0;
+          for (int it = 0;; ++it) {
+            const double r = seq - 3.0 * mu * dp - hardening_R<LAW>(prm, p_n + dp);
+            if (fabs(r) <= prm.tol) break;
+            if (it >= prm.maxit) { if (valid) ++c_notconv; break; }
+            const double dr = -3.0 * mu - hardening_dR<LAW>(prm, p_n + dp);
+            dp -= r / dr;
+            ++iters;
+          }
+        }
+        const double iseq = 1.0 / seq;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) nn[c] = 1.5 * se[c] * iseq;   // mfront:61
+        const double beta = dp * iseq;
+        const double gamma = 1.0 / (hardening_dR<LAW>(prm, p_n + dp) + 3.0 * mu);
+        // Dt = lambda IxI + 2mu Id - 4mu^2 [beta (M - n^n) + gamma n^n]      mfront:66-69
+        c1 = lambda + 2.0 * mu * mu * beta;
+        c2 = 2.0 * mu - 6.0 * mu * mu * beta;
+        c3 = 4.0 * mu * mu * (beta - gamma);
+        p_new = p_n + dp;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          ep[c] += dp * nn[c];
+          e[c] -= dp * nn[c];                                  // mfront:64
+        }
+        if (valid) {
+          ++c_plastic;
+          c_maxit = iters > c_maxit ? iters : c_maxit;
+        }
+      }
+    }
+    // sigma = lambda tr(eel) 1 + 2 mu eel                                      mfront:76
+    const double ltr = lambda * (e[0] + e[1] + e[2]);
+    double s[6];
+    s[0] = ltr + 2.0 * mu * e[0];
+    s[1] = ltr + 2.0 * mu * e[1];
+    s[2] = ltr + 2.0 * mu * e[2];
+    s[3] = 2.0 * mu * e[3];
+    s[4] = 2.0 * mu * e[4];
+    s[5] = 2.0 * mu * e[5];
+    {
+      const double chk = s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + p_new;
+      if (valid && !(fabs(chk) <= 1.79769313486231570e308)) ++c_nan;
+    }
+
+    // ---- 4. new state, SoA -------------------------------------------------------------------
+    if constexpr (LAW != LAW_ELASTIC) {
+      if (valid) {
+        s1[gi] = p_new;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s1[(int64_t)(1 + c) * ld + gi] = ep[c];
+      }
+    }
+
+    // ---- 5. stage stress and tangent coefficients in LDS --------------------------------------
+    stage2[lane * 3 + 0] = double2_t{s[0], s[1]};
+    stage2[lane * 3 + 1] = double2_t{s[2], s[3]};
+    stage2[lane * 3 + 2] = double2_t{s[4], s[5]};
+    if constexpr (LAW != LAW_ELASTIC) {
+      double* cf = coef + lane * 9;
+      cf[0] = c1; cf[1] = c2; cf[2] = c3;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) cf[3 + c] = nn[c];
+    }
+    wave_lds_sync();
+
+    // ---- 6. coalesced stress store (3 x 1 KiB) -----------------------------------------------
+    {
+      double2_t* gdst = reinterpret_cast<double2_t*>(sig + base * 6);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = k * WAVE + lane;
+        if (idx < npts * 3) {
+          if constexpr (NT_STORE) __builtin_nontemporal_store(stage2[idx], &gdst[idx]);
+          else gdst[idx] = stage2[idx];
+        }
+      }
+    }
+    // ---- 7. coalesced tangent store (18 x 1 KiB): entry pair (i, j..j+1) of point q ----------
+    {
+      double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 36);
+      const int lim = npts * 18;
+#pragma unroll 6
+      for (int it = 0; it < 18; ++it) {
+        const int k = it * WAVE + lane;   // pair index inside the tile, 18 pairs per point
+        const int q = k / 18;
+        const int r = k - q * 18;
+        const int i = r / 3;
+        const int j = (r - i * 3) * 2;
+        double2_t v;
+        if constexpr (LAW == LAW_ELASTIC) {
+          v.x = ((i < 3 && j < 3) ? lambda : 0.0) + ((i == j) ? 2.0 * mu : 0.0);
+          v.y = ((i < 3 && j + 1 < 3) ? lambda : 0.0) + ((i == j + 1) ? 2.0 * mu : 0.0);
+        } else {
+          const double* cf = coef + q * 9;
+          const double k1 = cf[0], k2 = cf[1], k3 = cf[2];
+          const double ni = cf[3 + i], nj0 = cf[3 + j], nj1 = cf[4 + j];
+          const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
+          const double t1 = ((i < 3 && j + 1 < 3) ? k1 : 0.0) + ((i == j + 1) ? k2 : 0.0);
+          v.x = t0 + (k3 * ni) * nj0;
+          v.y = t1 + (k3 * ni) * nj1;
+        }
+        if (k < lim) {
+          if constexpr (NT_STORE) __builtin_nontemporal_store(v, &gct[k]);
+          else gct[k] = v;
+        }
+      }
+    }
+    wave_lds_sync();  // LDS regions are rewritten by the next tile
+  }
+
+  store_block_stats(stats, c_plastic, c_notconv, c_nan, c_maxit, red);
+}
+
+}  // namespace dxm

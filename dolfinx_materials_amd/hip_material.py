@@ -1,0 +1,298 @@
+"""The reference's duck-typed ``Material`` protocol on top of ``libdxmat.so``.
+
+``HIPMaterial(behavior)`` is used exactly like ``JAXMaterial(behavior)``
+(reference ``dolfinx_materials/jaxmat.py:141-234``) or a ``generic.Material`` subclass
+(``dolfinx_materials/generic.py:103-201``): ``QuadratureMap`` (``quadrature_map.py:51-360``)
+consumes ``gradients / fluxes / internal_state_variables / tangent_blocks``,
+``set_data_manager``, ``set_initial_state_dict``, ``integrate`` and ``data_manager.update()``.
+
+Differences that are deliberate:
+  * the state is carried from s0 to s1 properly (the reference discards the converted state,
+    ``jaxmat.py:135-138``);
+  * the persistent state lives on the GPU in SoA form; the dicts returned here are host copies.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import S0, S1, DxmError, Stats
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _as_c(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class DataManager:
+    """``update`` / ``revert`` of ``generic.py:204-216`` and ``jaxmat.py:30-43``."""
+
+    def __init__(self, material: "HIPMaterial", ngauss: int):
+        self._m = material
+        self.ngauss = ngauss
+        num_gradients = sum(material.gradients.values())
+        num_fluxes = sum(material.fluxes.values())
+        self.K = np.zeros((num_fluxes, num_gradients))  # generic.py:208, jaxmat.py:34
+
+    def update(self):
+        """s0 <- s1 (end of a converged increment; ``quadrature_map.py:355``)."""
+        self._m._advance()
+
+    def revert(self):
+        """s1 <- s0."""
+        self._m._revert()
+
+    @property
+    def s0(self):
+        return self._m.get_initial_state_dict()
+
+    @property
+    def s1(self):
+        return self._m.get_final_state_dict()
+
+
+class HIPMaterial:
+    """A constitutive behaviour integrated on an MI355X through ``libdxmat.so``."""
+
+    def __init__(self, behavior, device: int = 0, gradient_name=None, flux_name=None):
+        self.behavior = behavior
+        self.device = int(device)
+        self._lib = _lib.load()
+        self._info = _lib.law_info(behavior.law)
+        self._gname = gradient_name or behavior.gradient_name
+        self._fname = flux_name or behavior.flux_name
+        self.material_properties = dict(behavior.flat_properties())  # jaxmat.py:146
+        self._handle = None
+        self._n = 0
+        self.data_manager = None
+        self.last_stats = None
+        self.dt = 0.0
+
+    # ---- protocol: names and sizes ---------------------------------------------------------
+    @property
+    def name(self):
+        return self.behavior.__class__.__name__
+
+    @property
+    def rotation_matrix(self):
+        return None  # generic.py:129-131
+
+    @property
+    def gradients(self):
+        return {self._gname: int(self._info.n_grad)}
+
+    @property
+    def fluxes(self):
+        return {self._fname: int(self._info.n_flux)}
+
+    @property
+    def tangent_blocks(self):
+        # generic.py:141-146
+        return {
+            (kf, kg): (vf, vg)
+            for (kf, vf), (kg, vg) in zip(self.fluxes.items(), self.gradients.items())
+        }
+
+    @property
+    def internal_state_variables(self):
+        return {
+            self._info.isv_name[f].decode(): int(self._info.isv_dim[f])
+            for f in range(self._info.n_isv_fields)
+        }
+
+    @property
+    def variables(self):
+        return {**self.gradients, **self.fluxes, **self.internal_state_variables}
+
+    @property
+    def gradient_names(self):
+        return list(self.gradients.keys())
+
+    @property
+    def flux_names(self):
+        return list(self.fluxes.keys())
+
+    @property
+    def internal_state_variable_names(self):
+        return list(self.internal_state_variables.keys())
+
+    @property
+    def algorithmic_bytes_per_point(self):
+        return int(self._info.algorithmic_bytes_per_point)
+
+    @property
+    def kernel_name(self):
+        return self._lib.dxm_kernel_name(self._handle).decode() if self._handle else ""
+
+    # ---- protocol: parameters ----------------------------------------------------------------
+    def update_material_property(self, key, value):
+        """``generic.py:119-120``; here the change reaches the kernel parameters."""
+        obj = self.behavior
+        parts = key.split(".")
+        for p in parts[:-1]:
+            obj = getattr(obj, p)
+        if not hasattr(obj, parts[-1]):
+            raise ValueError(f"Unknown material property {key!r}")
+        value = float(np.asarray(value).reshape(-1)[0]) if np.size(value) == 1 else value
+        if not np.isscalar(value):
+            raise NotImplementedError("per-point material property fields are not supported")
+        setattr(obj, parts[-1], value)
+        self.material_properties[key] = value
+        if self._handle:
+            prm = np.asarray(self.behavior.params(), dtype=np.float64)
+            _lib.check(
+                self._lib.dxm_set_params(
+                    self._handle, prm.ctypes.data_as(C.POINTER(C.c_double)), prm.size
+                )
+            )
+
+    def set_newton(self, maxit=25, rtol=1e-14):
+        _lib.check(self._lib.dxm_set_newton(self._require(), int(maxit), float(rtol)))
+
+    # ---- protocol: life cycle ------------------------------------------------------------------
+    def set_data_manager(self, ngauss):
+        """Allocate device state for ``ngauss`` points (``generic.py:172-174``, ``jaxmat.py:195-197``)."""
+        self.close()
+        prm = np.asarray(self.behavior.params(), dtype=np.float64)
+        h = self._lib.dxm_create(
+            self.behavior.law,
+            prm.ctypes.data_as(C.POINTER(C.c_double)),
+            prm.size,
+            int(ngauss),
+            self.device,
+        )
+        if not h:
+            raise DxmError(f"dxm_create failed: {_lib.last_error()}")
+        self._handle = h
+        self._n = int(ngauss)
+        ng, nf = self._info.n_grad, self._info.n_flux
+        nisv = self._info.n_isv_total
+        # host mirrors of the fields that are not device state (gradient and flux of s0 / s1)
+        self._grad = [self._initial_gradient(), self._initial_gradient()]
+        self._flux = [np.zeros((self._n, nf)), np.zeros((self._n, nf))]
+        self._out_isv = np.zeros((self._n, nisv))
+        self._out_ct = np.zeros((self._n, nf, ng))
+        self.data_manager = DataManager(self, self._n)
+
+    def _initial_gradient(self):
+        g = np.zeros((self._n, self._info.n_grad))
+        if self._info.n_grad == 9:
+            g[:, :3] = 1.0  # F = I
+        return g
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.dxm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _require(self):
+        if not self._handle:
+            raise DxmError("set_data_manager(ngauss) must be called first")
+        return self._handle
+
+    # ---- protocol: state dictionaries ------------------------------------------------------------
+    def _isv_dict(self, which):
+        h = self._require()
+        out = {}
+        for f, (name, dim) in enumerate(self.internal_state_variables.items()):
+            a = np.empty((self._n, dim))
+            _lib.check(self._lib.dxm_get_state(h, which, f, _ptr(a)))
+            out[name] = a
+        return out
+
+    def get_initial_state_dict(self):
+        self._require()
+        return {self._gname: self._grad[0], self._fname: self._flux[0], **self._isv_dict(S0)}
+
+    def get_final_state_dict(self):
+        self._require()
+        return {self._gname: self._grad[1], self._fname: self._flux[1], **self._isv_dict(S1)}
+
+    def set_initial_state_dict(self, state):
+        """``generic.py:200-201`` / ``quadrature_map.py:279,294``: any subset of the fields."""
+        h = self._require()
+        isv_names = self.internal_state_variable_names
+        unknown = [k for k in state if k not in self.variables]
+        assert len(unknown) == 0, "Material state contains unknown field to update with."
+        for key, value in state.items():
+            dim = self.variables[key]
+            a = _as_c(value, (self._n, max(1, dim)))
+            if key == self._gname:
+                self._grad[0] = a.copy()
+            elif key == self._fname:
+                self._flux[0] = a.copy()
+            else:
+                _lib.check(self._lib.dxm_set_state(h, S0, isv_names.index(key), _ptr(a)))
+
+    def _advance(self):
+        _lib.check(self._lib.dxm_advance(self._require()))
+        self._grad[0] = self._grad[1]
+        self._flux[0] = self._flux[1]
+
+    def _revert(self):
+        _lib.check(self._lib.dxm_revert(self._require()))
+        self._grad[1] = self._grad[0]
+        self._flux[1] = self._flux[0]
+
+    # ---- protocol: the hot path -----------------------------------------------------------------
+    def integrate(self, gradients, dt=0):
+        """``(N, ng)`` host gradients -> ``(flux (N,nf), isv (N,sum isv), Ct (N,nf,ng))``.
+
+        Same contract as ``JAXMaterial.integrate`` (``jaxmat.py:208-234``); the returned arrays
+        are fresh for flux (it becomes the s1 mirror) and reused buffers for isv / Ct, valid
+        until the next call (the reference returns views too: ``generic.py:185-189``).
+        """
+        h = self._require()
+        ng, nf = self._info.n_grad, self._info.n_flux
+        g = _as_c(gradients)
+        if g.shape != (self._n, ng):
+            raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
+        flux = np.empty((self._n, nf))
+        st = Stats()
+        rc = self._lib.dxm_integrate(
+            h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)
+        )
+        _lib.check(rc)
+        self.last_stats = st.as_dict()
+        if rc > 0:
+            warnings.warn(
+                f"local Newton did not converge at {rc} quadrature points", RuntimeWarning
+            )
+        self._grad[1] = g
+        self._flux[1] = flux
+        return flux, self._out_isv, self._out_ct
+
+    def integrate_device(self, grad_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
+        """Device-pointer form: asynchronous launch on ``stream`` (a ``hipStream_t`` value, e.g.
+        ``torch.cuda.current_stream().cuda_stream``); the three arguments are device addresses
+        of ``(N,ng)``, ``(N,nf)`` and ``(N,nf*ng)`` fp64 arrays on this material's device."""
+        _lib.check(
+            self._lib.dxm_integrate_device(
+                self._require(), int(grad_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None
+            )
+        )
+
+    def isv_device(self, which, isv_ptr, stream=0):
+        _lib.check(self._lib.dxm_isv_device(self._require(), which, int(isv_ptr), int(stream) or None))
+
+    def stats(self):
+        """Wait for the last integrate and return its per-batch status."""
+        st = Stats()
+        rc = _lib.check(self._lib.dxm_get_stats(self._require(), C.byref(st)))
+        self.last_stats = st.as_dict()
+        return rc, self.last_stats

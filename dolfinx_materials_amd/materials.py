@@ -1,0 +1,151 @@
+"""Behaviour descriptors with the constructor surface of ``jaxmat.materials`` as the reference
+uses it (``tests/test_FeFp_jax.py:17-19``, ``demos/jax/elastoplasticity/plane_elastoplasticity.py:67-71``,
+``demos/jax/finite_strain_elastoplasticity/finite_strain_elastoplasticity.py:165-169``).
+
+A descriptor only carries parameters and names; it selects one fused HIP kernel (a law id of
+``include/dxmat.h``).  Hardening must be one of the closed-form laws below: an arbitrary Python
+callable (``yield_stress(p)`` in ``tests/test_FeFp_jax.py:14-15``) cannot be compiled into the
+kernel and is rejected with a ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from . import _lib
+
+
+@dataclass
+class LinearElasticIsotropic:
+    """``jm.LinearElasticIsotropic(E=, nu=)``; Lame constants as ``python_materials/elasticity.py:12-13``."""
+
+    E: float
+    nu: float
+
+    @property
+    def mu(self):
+        return self.E / 2 / (1 + self.nu)
+
+    @property
+    def lmbda(self):
+        return self.E * self.nu / (1 + self.nu) / (1 - 2 * self.nu)
+
+    @property
+    def kappa(self):
+        return self.lmbda + 2 * self.mu / 3
+
+
+@dataclass
+class LinearHardening:
+    """R(p) = sig0 + H p (``tests/mfront/IsotropicPlasticMisesFlow.mfront:7-11``)."""
+
+    sig0: float
+    H: float
+
+
+@dataclass
+class VoceHardening:
+    """R(p) = sig0 + (sigu - sig0)(1 - exp(-b p)) (``tests/test_FeFp_jax.py:14-15``)."""
+
+    sig0: float
+    sigu: float
+    b: float
+
+
+class Behavior:
+    """Common part: law id, parameter vector, field names and sizes."""
+
+    law: int = -1
+    gradient_name = "strain"
+    flux_name = "stress"
+
+    def params(self):
+        raise NotImplementedError
+
+    def flat_properties(self):
+        raise NotImplementedError
+
+
+class SmallStrainBehavior(Behavior):
+    """gradient ``strain`` (6), flux ``stress`` (6): ``jaxmat.py:166-169, :177-180``."""
+
+    gradient_name = "strain"
+    flux_name = "stress"
+    ngrad = 6
+    nflux = 6
+
+
+class FiniteStrainBehavior(Behavior):
+    """gradient ``F`` (9), flux ``PK1`` (9): ``jaxmat.py:170-171, :181-182``."""
+
+    gradient_name = "F"
+    flux_name = "PK1"
+    ngrad = 9
+    nflux = 9
+
+
+def _check_hardening(yield_stress):
+    if isinstance(yield_stress, (LinearHardening, VoceHardening)):
+        return yield_stress
+    raise NotImplementedError(
+        "yield_stress must be a materials.LinearHardening or materials.VoceHardening instance: "
+        "an arbitrary Python callable cannot be fused into the HIP return-mapping kernel."
+    )
+
+
+class ElasticBehavior(SmallStrainBehavior):
+    """Linear isotropic elasticity as a small-strain behaviour."""
+
+    law = _lib.LAW_ELASTIC_ISO
+
+    def __init__(self, elasticity: LinearElasticIsotropic):
+        self.elasticity = elasticity
+
+    def params(self):
+        return [self.elasticity.E, self.elasticity.nu]
+
+    def flat_properties(self):
+        return {"elasticity.E": self.elasticity.E, "elasticity.nu": self.elasticity.nu}
+
+
+class vonMisesIsotropicHardening(SmallStrainBehavior):
+    """Small-strain J2 plasticity with isotropic hardening (``plane_elastoplasticity.py:67-71``)."""
+
+    def __init__(self, elasticity: LinearElasticIsotropic, yield_stress):
+        self.elasticity = elasticity
+        self.yield_stress = _check_hardening(yield_stress)
+        self.law = (
+            _lib.LAW_J2_LINEAR if isinstance(yield_stress, LinearHardening) else _lib.LAW_J2_VOCE
+        )
+
+    def params(self):
+        e, y = self.elasticity, self.yield_stress
+        if isinstance(y, LinearHardening):
+            return [e.E, e.nu, y.sig0, y.H]
+        return [e.E, e.nu, y.sig0, y.sigu, y.b]
+
+    def flat_properties(self):
+        out = {"elasticity.E": self.elasticity.E, "elasticity.nu": self.elasticity.nu}
+        out.update({f"yield_stress.{k}": v for k, v in vars(self.yield_stress).items()})
+        return out
+
+
+class FeFpJ2Plasticity(FiniteStrainBehavior):
+    """Finite-strain FeFp J2 plasticity (``tests/test_FeFp_jax.py:17-19``); Voce hardening."""
+
+    law = _lib.LAW_FEFP_J2_VOCE
+
+    def __init__(self, elasticity: LinearElasticIsotropic, yield_stress):
+        self.elasticity = elasticity
+        y = _check_hardening(yield_stress)
+        if isinstance(y, LinearHardening):
+            raise NotImplementedError("FeFpJ2Plasticity is built for VoceHardening")
+        self.yield_stress = y
+
+    def params(self):
+        e, y = self.elasticity, self.yield_stress
+        return [e.E, e.nu, y.sig0, y.sigu, y.b]
+
+    def flat_properties(self):
+        out = {"elasticity.E": self.elasticity.E, "elasticity.nu": self.elasticity.nu}
+        out.update({f"yield_stress.{k}": v for k, v in vars(self.yield_stress).items()})
+        return out

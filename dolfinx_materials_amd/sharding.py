@@ -1,0 +1,76 @@
+"""Sharding of a Gauss-point batch over the GPUs of one node (one process per GPU).
+
+The constitutive update has no cross-point dependency (reference ``jaxmat.py:147-151`` is a
+``vmap``; ``generic.py:77-79`` a loop), so rank ``r`` owns the contiguous block
+``[bounds[r], bounds[r+1])`` of the QuadratureMap ordering (cell-major, ``quadrature_map.py:255-260``)
+and keeps that block's state resident on its GPU.  No collective is needed for the update itself;
+``allgather_rows`` reassembles per-rank ``(n_r, dim)`` outputs (stress, tangent) into the full
+``(N, dim)`` array on every rank -- RCCL over xGMI when the process group backend is ``nccl``,
+``gloo`` in the CPU tests.
+
+In a multi-rank dolfinx run each MPI rank only consumes its own points
+(``quadrature_map.py:66-70``), so the gather is only for the single-consumer scenario.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    n_total: int
+    world_size: int
+
+    @property
+    def bounds(self):
+        """Balanced contiguous partition: the first ``n_total % world`` ranks get one more point."""
+        q, r = divmod(self.n_total, self.world_size)
+        b = [0]
+        for k in range(self.world_size):
+            b.append(b[-1] + q + (1 if k < r else 0))
+        return b
+
+    def range(self, rank):
+        b = self.bounds
+        return b[rank], b[rank + 1]
+
+    def count(self, rank):
+        lo, hi = self.range(rank)
+        return hi - lo
+
+    @property
+    def max_count(self):
+        return max(self.count(r) for r in range(self.world_size))
+
+
+def allgather_rows(local: torch.Tensor, plan: ShardPlan, out: torch.Tensor | None = None,
+                   scratch: torch.Tensor | None = None, group=None) -> torch.Tensor:
+    """All-gather row blocks of unequal length into ``out`` of shape ``(n_total, dim)``.
+
+    Equal shards use one ``all_gather_into_tensor`` straight into ``out`` (a single large
+    collective: xGMI is point-to-point, so few big messages beat many small ones).  Ragged
+    shards are padded to ``max_count`` rows in ``scratch`` and compacted afterwards.
+    """
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    assert world == plan.world_size
+    dim = local.shape[1]
+    assert local.shape[0] == plan.count(rank)
+    if out is None:
+        out = torch.empty((plan.n_total, dim), dtype=local.dtype, device=local.device)
+    if plan.n_total % world == 0:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    m = plan.max_count
+    if scratch is None:
+        scratch = torch.empty((world * m, dim), dtype=local.dtype, device=local.device)
+    padded = torch.zeros((m, dim), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    dist.all_gather_into_tensor(scratch, padded, group=group)
+    b = plan.bounds
+    for r in range(world):
+        out[b[r] : b[r + 1]] = scratch[r * m : r * m + (b[r + 1] - b[r])]
+    return out

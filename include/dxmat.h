@@ -1,0 +1,151 @@
+/*
+ * dxmat.h -- C ABI of libdxmat.so, the MI355X (gfx950) batched constitutive-update engine.
+ *
+ * This is the drop-in boundary for ONE path of bleyerj/dolfinx_materials: the per-Gauss-point
+ * constitutive update reached through
+ *     NonlinearMaterialProblem._constitutive_update   (dolfinx_materials/solvers.py:173-176)
+ *  -> QuadratureMap.update()                          (dolfinx_materials/quadrature_map.py:297-334)
+ *  -> material.integrate(gradients)                   (dolfinx_materials/jaxmat.py:208-234,
+ *                                                      dolfinx_materials/generic.py:176-189)
+ *  -> batched_constitutive_update = vmap(jacfwd(constitutive_update))
+ *                                                     (dolfinx_materials/jaxmat.py:147-155)
+ *
+ * The reference has no FFI of its own (its boundary is the duck-typed Python `Material` protocol);
+ * the Python classes in dolfinx_materials_amd/ implement that protocol on top of these entry
+ * points through ctypes.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *   - all floating point data is IEEE fp64;
+ *   - "AoS" = row-major (npoints, dim), component fastest: the memory layout of a dolfinx
+ *     quadrature Function (dolfinx_materials/utils.py:98-104, :136-143);
+ *   - symmetric tensors are Mandel 6-vectors, non-symmetric ones 9-vectors in the order
+ *     [11,22,33,12,21,13,31,23,32] (dolfinx_materials/utils.py:146-190);
+ *   - the tangent is Ct[i][j] = d flux_i / d gradient_j, row-major (npoints, nflux*ngrad)
+ *     (dolfinx_materials/quadrature_map.py:83-105, :334);
+ *   - int return codes: 0 = ok, > 0 = number of points whose local Newton did not converge,
+ *     < 0 = hard error (message from dxm_last_error());
+ *   - one handle per (material, device); a handle is not thread-safe (the reference calls the path
+ *     from the PETSc SNES callback on one thread: dolfinx_materials/solvers.py:72);
+ *   - there is NO CPU fallback: every entry point that computes fails with a negative code when no
+ *     HIP device is usable.
+ */
+#ifndef DXMAT_H
+#define DXMAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DXM_ABI_VERSION 1
+
+/* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
+enum {
+  /* sigma = C:eps, Ct = C.  Replaces python_materials/elasticity.py:21-24.
+   * params = [E, nu] */
+  DXM_LAW_ELASTIC_ISO = 0,
+  /* small-strain J2, linear isotropic hardening R(p) = sig0 + H p, implicit radial return +
+   * consistent tangent.  Spec: tests/mfront/IsotropicLinearHardeningPlasticity.mfront:49-77.
+   * params = [E, nu, sig0, H] */
+  DXM_LAW_J2_LINEAR = 1,
+  /* small-strain J2, Voce hardening R(p) = sig0 + (sigu - sig0)(1 - exp(-b p))
+   * (jaxmat vonMisesIsotropicHardening + VoceHardening as constructed in
+   * demos/jax/elastoplasticity/plane_elastoplasticity.py:60-73).
+   * params = [E, nu, sig0, sigu, b] */
+  DXM_LAW_J2_VOCE = 2,
+  /* finite-strain FeFp J2 plasticity with Voce hardening, gradient F (9), flux PK1 (9)
+   * (jaxmat FeFpJ2Plasticity as constructed in tests/test_FeFp_jax.py:7-20).
+   * params = [E, nu, sig0, sigu, b] */
+  DXM_LAW_FEFP_J2_VOCE = 3,
+  DXM_LAW_COUNT = 4
+};
+
+/* Which state: s0 = beginning of the increment, s1 = end (generic.py:204-216, jaxmat.py:30-43). */
+enum { DXM_S0 = 0, DXM_S1 = 1 };
+
+#define DXM_MAX_STATE_FIELDS 4
+
+typedef struct dxm_law_info {
+  int32_t n_grad;         /* gradient size (6 strain / 9 F)              jaxmat.py:166-175 */
+  int32_t n_flux;         /* flux size (6 stress / 9 PK1)                jaxmat.py:177-186 */
+  int32_t n_params;       /* number of material parameters                                 */
+  int32_t n_isv_fields;   /* number of user-visible internal state variables               */
+  int32_t isv_dim[DXM_MAX_STATE_FIELDS];      /* size of each (scalar = 1)  jaxmat.py:188-193 */
+  const char* isv_name[DXM_MAX_STATE_FIELDS]; /* e.g. "p", "epsp", "be_bar"                   */
+  int32_t n_isv_total;    /* sum of isv_dim = columns of the isv array of integrate()      */
+  int32_t algorithmic_bytes_per_point; /* 384 / 496 / 496 / 976    */
+} dxm_law_info;
+
+/* Per-batch status of the last integrate (the reference only has host-side NaN asserts,
+ * quadrature_map.py:322-324, and no local-Newton report on the JAX path). */
+typedef struct dxm_stats {
+  int64_t n_points;
+  int64_t n_plastic;        /* points that took the plastic branch */
+  int64_t n_not_converged;  /* local Newton hit maxit              */
+  int64_t n_nan;            /* points with a non-finite flux / isv */
+  int32_t max_local_iters;
+  int32_t reserved;
+} dxm_stats;
+
+typedef struct dxm_material dxm_material; /* opaque handle */
+
+/* ---- library / device ------------------------------------------------------------------- */
+int dxm_abi_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* dxm_last_error(void);
+/* Number of HIP devices, or < 0 if the HIP runtime cannot be initialised. */
+int dxm_device_count(void);
+int dxm_law_info_get(int law, dxm_law_info* out);
+
+/* ---- life cycle: Material.set_data_manager(ngauss)  (generic.py:172-174, jaxmat.py:195-197,
+ *      quadrature_map.py:231-233) ---------------------------------------------------------- */
+/* Allocates device-resident SoA state s0/s1 for npoints Gauss points on `device` and
+ * initialises it (p = 0, epsp = 0, be_bar = identity; cf. behavior.init_state, jaxmat.py:35). */
+dxm_material* dxm_create(int law, const double* params, int n_params, int64_t npoints, int device);
+int dxm_destroy(dxm_material* m);
+int64_t dxm_npoints(const dxm_material* m);
+int dxm_law(const dxm_material* m);
+/* Material.update_material_property (generic.py:119-120): replace the parameter vector. */
+int dxm_set_params(dxm_material* m, const double* params, int n_params);
+/* Local Newton controls: stop when |r| <= rtol * sig0, at most maxit iterations. */
+int dxm_set_newton(dxm_material* m, int maxit, double rtol);
+
+/* ---- state: set_initial_state_dict / get_initial_state_dict / get_final_state_dict
+ *      (generic.py:194-201, jaxmat.py:199-206; consumers quadrature_map.py:279,294,356-360) -- */
+/* host AoS (npoints, isv_dim[field]) -> device SoA of state `which` */
+int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos);
+/* device SoA -> host AoS (npoints, isv_dim[field]) */
+int dxm_get_state(dxm_material* m, int which, int field, double* host_aos);
+/* DataManager.update(): s0 <- s1   (generic.py:212-213, jaxmat.py:39-40; quadrature_map.py:355) */
+int dxm_advance(dxm_material* m);
+/* DataManager.revert(): s1 <- s0   (generic.py:215-216, jaxmat.py:42-43) */
+int dxm_revert(dxm_material* m);
+
+/* ---- the hot path: Material.integrate(gradients, dt)  (jaxmat.py:208-234, generic.py:176-189;
+ *      consumer quadrature_map.py:321) ------------------------------------------------------ */
+/* Host-buffer form (what QuadratureMap hands over): grad_aos (npoints, n_grad) in host memory;
+ * writes flux_aos (npoints, n_flux), isv_aos (npoints, n_isv_total) and ct_aos
+ * (npoints, n_flux*n_grad) to host memory (any of the three may be NULL to skip its download).
+ * Reads state s0, writes state s1.  Synchronous.  `stats` may be NULL. */
+int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
+                  double* isv_aos, double* ct_aos, dxm_stats* stats);
+/* Device-pointer form: all three arrays are device memory on the handle's device (e.g. torch
+ * tensors' data_ptr()); the kernel is enqueued on `hip_stream` (a hipStream_t, NULL = default
+ * stream) and the call returns without synchronising.  Returns 0 or < 0. */
+int dxm_integrate_device(dxm_material* m, const double* grad_dev, double dt, double* flux_dev,
+                         double* ct_dev, void* hip_stream);
+/* Waits for the last integrate on the handle and returns its status (same code as dxm_integrate). */
+int dxm_get_stats(dxm_material* m, dxm_stats* stats);
+/* Packs the user-visible ISVs of state `which` into a device AoS (npoints, n_isv_total) array,
+ * enqueued on hip_stream (the `_hcat_mixed` of jaxmat.py:46-58, :227-229, on device). */
+int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_stream);
+/* Device address of component `comp` of SoA state field `field` (npoints contiguous doubles). */
+const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp);
+/* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
+const char* dxm_kernel_name(const dxm_material* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DXMAT_H */

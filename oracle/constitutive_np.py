@@ -1,0 +1,241 @@
+"""Vectorised numpy restatement of the per-Gauss-point constitutive updates.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Conventions (reference ``dolfinx_materials/utils.py:146-212``, ``docs/intro.md:134-175``):
+symmetric 2nd-order tensors are Mandel 6-vectors ``[a11,a22,a33,√2 a12,√2 a13,√2 a23]``;
+non-symmetric ones are 9-vectors ``[a11,a22,a33,a12,a21,a13,a31,a23,a32]``; the
+tangent is ``Ct[i,j] = d flux_i / d gradient_j`` of the *discrete algorithm* at
+fixed old state (reference ``dolfinx_materials/jaxmat.py:147-151``).
+
+Every function maps ``(N, dim)`` batches to ``(N, dim)`` batches, like
+``batched_constitutive_update`` in the reference (``generic.py:115-117``,
+``jaxmat.py:147-155``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SQ2 = np.sqrt(2.0)
+
+# ----------------------------------------------------------------------------------------
+# conventions
+# ----------------------------------------------------------------------------------------
+#: position (row, col) of each entry of the non-symmetric 9-vector (utils.py:168-190)
+NSYM_IDX = ((0, 0), (1, 1), (2, 2), (0, 1), (1, 0), (0, 2), (2, 0), (1, 2), (2, 1))
+
+
+def mandel_to_tensor(v):
+    """(N,6) Mandel -> (N,3,3) symmetric (utils.py:193-212 for the (6,) case)."""
+    v = np.asarray(v, dtype=np.float64)
+    T = np.empty(v.shape[:-1] + (3, 3))
+    T[..., 0, 0] = v[..., 0]
+    T[..., 1, 1] = v[..., 1]
+    T[..., 2, 2] = v[..., 2]
+    T[..., 0, 1] = T[..., 1, 0] = v[..., 3] / SQ2
+    T[..., 0, 2] = T[..., 2, 0] = v[..., 4] / SQ2
+    T[..., 1, 2] = T[..., 2, 1] = v[..., 5] / SQ2
+    return T
+
+
+def tensor_to_mandel(T):
+    """(N,3,3) symmetric -> (N,6) Mandel (utils.py:146-165)."""
+    T = np.asarray(T, dtype=np.float64)
+    v = np.empty(T.shape[:-2] + (6,))
+    v[..., 0] = T[..., 0, 0]
+    v[..., 1] = T[..., 1, 1]
+    v[..., 2] = T[..., 2, 2]
+    v[..., 3] = SQ2 * T[..., 0, 1]
+    v[..., 4] = SQ2 * T[..., 0, 2]
+    v[..., 5] = SQ2 * T[..., 1, 2]
+    return v
+
+
+def nsym_to_tensor(v):
+    """(N,9) -> (N,3,3) (utils.py:208-210)."""
+    v = np.asarray(v, dtype=np.float64)
+    T = np.empty(v.shape[:-1] + (3, 3))
+    for k, (i, j) in enumerate(NSYM_IDX):
+        T[..., i, j] = v[..., k]
+    return T
+
+
+def tensor_to_nsym(T):
+    """(N,3,3) -> (N,9) (utils.py:168-190)."""
+    T = np.asarray(T, dtype=np.float64)
+    v = np.empty(T.shape[:-2] + (9,))
+    for k, (i, j) in enumerate(NSYM_IDX):
+        v[..., k] = T[..., i, j]
+    return v
+
+
+def lame(E, nu):
+    """python_materials/elasticity.py:12-13."""
+    return E * nu / (1 + nu) / (1 - 2 * nu), E / 2 / (1 + nu)
+
+
+def elastic_matrix(E, nu):
+    """python_materials/elasticity.py:15-19: C = 2 mu I6 ; C[:3,:3] += lambda."""
+    lmbda, mu = lame(E, nu)
+    C = 2 * mu * np.eye(6)
+    C[:3, :3] += lmbda
+    return C
+
+
+# ----------------------------------------------------------------------------------------
+# law 0: isotropic linear elasticity (python_materials/elasticity.py:21-24)
+# ----------------------------------------------------------------------------------------
+def elastic_iso(eps, E, nu):
+    """sigma = C eps ; Ct = C for every point.  Returns (sig (N,6), Ct (N,6,6))."""
+    eps = np.asarray(eps, dtype=np.float64)
+    C = elastic_matrix(E, nu)
+    sig = eps @ C.T
+    Ct = np.broadcast_to(C, (eps.shape[0], 6, 6)).copy()
+    return sig, Ct
+
+
+# ----------------------------------------------------------------------------------------
+# hardening laws R(p) and R'(p)
+# ----------------------------------------------------------------------------------------
+class LinearHardening:
+    """R(p) = s0 + H p  (tests/mfront/IsotropicPlasticMisesFlow.mfront:7-11)."""
+
+    def __init__(self, sig0, H):
+        self.sig0, self.H = float(sig0), float(H)
+
+    def R(self, p):
+        return self.sig0 + self.H * p
+
+    def dR(self, p):
+        return np.full_like(np.asarray(p, dtype=np.float64), self.H)
+
+
+class VoceHardening:
+    """R(p) = s0 + (su - s0)(1 - exp(-b p))  (tests/test_FeFp_jax.py:14-15)."""
+
+    def __init__(self, sig0, sigu, b):
+        self.sig0, self.sigu, self.b = float(sig0), float(sigu), float(b)
+
+    def R(self, p):
+        return self.sig0 + (self.sigu - self.sig0) * (1.0 - np.exp(-self.b * p))
+
+    def dR(self, p):
+        return (self.sigu - self.sig0) * self.b * np.exp(-self.b * p)
+
+
+#: Newton controls shared by the oracle, the C restatement and the HIP kernels
+NEWTON_MAXIT = 25
+NEWTON_RTOL = 1e-14  # |r| <= rtol * sig0
+
+
+def _solve_dp(seq, p_n, mu, hard, maxit=NEWTON_MAXIT, rtol=NEWTON_RTOL):
+    """Scalar return-mapping equation r(dp) = seq - 3 mu dp - R(p_n+dp) = 0 on the
+    plastic subset; monotone, started from dp = 0.  For linear hardening
+    the first Newton step is the closed form of
+    IsotropicLinearHardeningPlasticity.mfront:63-64."""
+    dp = np.zeros_like(seq)
+    iters = np.zeros(seq.shape, dtype=np.int32)
+    if isinstance(hard, LinearHardening):
+        dp = (seq - hard.sig0 - hard.H * p_n) / (hard.H + 3 * mu)
+        return dp, iters
+    active = np.ones(seq.shape, dtype=bool)
+    for _ in range(maxit):
+        r = seq - 3 * mu * dp - hard.R(p_n + dp)
+        active = np.abs(r) > rtol * hard.sig0
+        if not active.any():
+            break
+        dr = -3 * mu - hard.dR(p_n + dp)
+        dp = np.where(active, dp - r / dr, dp)
+        iters += active
+    return dp, iters
+
+
+# ----------------------------------------------------------------------------------------
+# laws 1/2: small-strain J2 plasticity, isotropic hardening, implicit Euler radial return
+# (tests/mfront/IsotropicLinearHardeningPlasticity.mfront:49-77, (eps_p, p)-state form)
+# ----------------------------------------------------------------------------------------
+def j2_update(eps, epsp_n, p_n, E, nu, hard):
+    """Returns dict(sig (N,6), epsp (N,6), p (N,), Ct (N,6,6), plastic (N,) bool,
+    iters (N,) int, f_trial (N,))."""
+    eps = np.asarray(eps, dtype=np.float64)
+    epsp_n = np.asarray(epsp_n, dtype=np.float64)
+    p_n = np.asarray(p_n, dtype=np.float64).reshape(-1)
+    N = eps.shape[0]
+    lmbda, mu = lame(E, nu)
+    one = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
+
+    eel = eps - epsp_n  # trial elastic strain  (mfront:52 `eel += deto`)
+    tr = eel[:, 0] + eel[:, 1] + eel[:, 2]
+    se = 2 * mu * (eel - tr[:, None] / 3.0 * one)  # mfront:53
+    seq = np.sqrt(1.5 * np.einsum("ni,ni->n", se, se))  # mfront:54 sigmaeq
+    f_trial = seq - hard.R(p_n)  # mfront:55
+    plastic = f_trial > 0.0
+
+    dp = np.zeros(N)
+    iters = np.zeros(N, dtype=np.int32)
+    n = np.zeros((N, 6))
+    c1 = np.full(N, lmbda)
+    c2 = np.full(N, 2 * mu)
+    c3 = np.zeros(N)
+    if plastic.any():
+        idx = np.nonzero(plastic)[0]
+        dp_i, it_i = _solve_dp(seq[idx], p_n[idx], mu, hard)
+        dp[idx] = dp_i
+        iters[idx] = it_i
+        n[idx] = 1.5 * se[idx] / seq[idx, None]  # mfront:61
+        beta = dp_i / seq[idx]  # dp * iseq_e
+        gamma = 1.0 / (hard.dR(p_n[idx] + dp_i) + 3 * mu)  # cste (H -> R'(p_{n+1}))
+        # Dt = lambda IxI + 2mu Id - 4mu^2 [beta (M - n^n) + gamma n^n], M = 3/2 Id - 1/2 IxI
+        c1[idx] = lmbda + 2 * mu * mu * beta
+        c2[idx] = 2 * mu - 6 * mu * mu * beta
+        c3[idx] = 4 * mu * mu * (beta - gamma)
+
+    epsp = epsp_n + dp[:, None] * n
+    p = p_n + dp
+    eel = eel - dp[:, None] * n  # mfront:65
+    tr = eel[:, 0] + eel[:, 1] + eel[:, 2]
+    sig = lmbda * tr[:, None] * one + 2 * mu * eel  # mfront:76
+
+    Ct = (
+        c1[:, None, None] * np.outer(one, one)[None]
+        + c2[:, None, None] * np.eye(6)[None]
+        + c3[:, None, None] * n[:, :, None] * n[:, None, :]
+    )
+    return dict(sig=sig, epsp=epsp, p=p, Ct=Ct, plastic=plastic, iters=iters, f_trial=f_trial)
+
+
+def j2_update_mfront_form(deto, eel_n, p_n, E, nu, H, s0):
+    """Literal transcription of the @Integrator block of
+    tests/mfront/IsotropicLinearHardeningPlasticity.mfront:49-77 (elastic-strain state,
+    strain *increment* input, explicit IxI/Id/M 4th-order tensors).  Used only to pin
+    ``j2_update`` (which is the (eps_p,p)-state, coefficient form) against the in-tree spec."""
+    lmbda, mu = lame(E, nu)
+    IxI = np.zeros((6, 6))
+    IxI[:3, :3] = 1.0
+    Id = np.eye(6)
+    M = 1.5 * (Id - IxI / 3.0)
+    N = deto.shape[0]
+    eel = eel_n + deto
+    p = np.array(p_n, dtype=np.float64).reshape(-1).copy()
+    sig = np.empty((N, 6))
+    Dt = np.empty((N, 6, 6))
+    for i in range(N):
+        e = eel[i]
+        dev = e - (e[0] + e[1] + e[2]) / 3.0 * np.array([1, 1, 1, 0, 0, 0.0])
+        se = 2 * mu * dev
+        seq_e = np.sqrt(1.5 * se @ se)
+        if seq_e - s0 - H * p[i] > 0:
+            iseq_e = 1 / seq_e
+            n = 3 * se / (2 * seq_e)
+            cste = 1 / (H + 3 * mu)
+            dp = (seq_e - s0 - H * p[i]) * cste
+            e = e - dp * n
+            p[i] += dp
+            Dt[i] = lmbda * IxI + 2 * mu * Id - 4 * mu * mu * (
+                dp * iseq_e * (M - np.outer(n, n)) + cste * np.outer(n, n)
+            )
+        else:
+            Dt[i] = lmbda * IxI + 2 * mu * Id
+        eel[i] = e
+        sig[i] = lmbda * (e[0] + e[1] + e[2]) * np.array([1, 1, 1, 0, 0, 0.0]) + 2 * mu * e
+    return sig, eel, p, Dt

@@ -1,0 +1,174 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Tolerances: the contract
+is rtol 1e-10 elastic / 1e-6 plastic (BASELINE.json north_star); both sides are fp64 and the
+tests hold them to 1e-12 relative to the field scale, away from the yield kink."""
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from dolfinx_materials_amd.jaxmat import JAXMaterial
+from dolfinx_materials_amd.python_materials import LinearElasticIsotropic
+from oracle import constitutive_np as onp
+
+from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, j2_history, random_j2_state
+
+pytestmark = pytest.mark.gpu
+
+RTOL_ELASTIC = 1e-10
+RTOL_PLASTIC = 1e-6
+TIGHT = 1e-12
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make_j2(kind):
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if kind == "linear":
+        return JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN))), onp.LinearHardening(SIG0_LIN, H_LIN)
+    return JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.VoceHardening(SIG0_V, SIGU_V, B_V))), onp.VoceHardening(SIG0_V, SIGU_V, B_V)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097])
+def test_elastic_matches_oracle(n):
+    rng = np.random.default_rng(0)
+    eps = 1e-3 * rng.standard_normal((n, 6))
+    mat = LinearElasticIsotropic(E, NU)
+    mat.set_data_manager(n)
+    sig, isv, Ct = mat.integrate(eps)
+    so, Co = onp.elastic_iso(eps, E, NU)
+    assert sig.shape == (n, 6) and isv.shape == (n, 0) and Ct.shape == (n, 6, 6)
+    assert relerr(sig, so) < RTOL_ELASTIC
+    assert relerr(Ct, Co) < RTOL_ELASTIC
+    assert mat.last_stats["n_nan"] == 0 and mat.last_stats["n_plastic"] == 0
+
+
+def test_elastic_golden_reference():
+    """Against vectors produced by the reference itself (tests/golden/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "elastic_ref.npz"))
+    mat = LinearElasticIsotropic(float(g["E"]), float(g["nu"]))
+    mat.set_data_manager(g["eps"].shape[0])
+    sig, _, Ct = mat.integrate(g["eps"])
+    assert np.allclose(sig, g["sig"], rtol=RTOL_ELASTIC, atol=0)
+    assert np.allclose(Ct, g["Ct"], rtol=RTOL_ELASTIC, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+@pytest.mark.parametrize("n", [1, 64, 1000, 70001])
+def test_j2_single_step_random_state(kind, n):
+    mat, hard = make_j2(kind)
+    mat.set_data_manager(n)
+    epsp_n, p_n = random_j2_state(n, sig0=hard.sig0)
+    eps = j2_history(n, seed=99, sig0=hard.sig0)[2]
+    mat.set_initial_state_dict({"p": p_n, "epsp": epsp_n})
+    s0 = mat.get_initial_state_dict()
+    assert np.array_equal(s0["p"][:, 0], p_n) and np.array_equal(s0["epsp"], epsp_n)
+    sig, isv, Ct = mat.integrate(eps)
+    ref = onp.j2_update(eps, epsp_n, p_n, E, NU, hard)
+    # points sitting numerically on the yield surface may legitimately take either branch
+    safe = np.abs(ref["f_trial"]) > 1e-9 * hard.sig0
+    assert safe.mean() > 0.99
+    assert relerr(sig[safe], ref["sig"][safe]) < TIGHT
+    assert relerr(isv[safe, 0], ref["p"][safe]) < TIGHT
+    assert np.abs(isv[safe, 1:] - ref["epsp"][safe]).max() < TIGHT * np.abs(ref["epsp"]).max()
+    assert relerr(Ct[safe], ref["Ct"][safe]) < TIGHT
+    assert relerr(sig[safe], ref["sig"][safe]) < RTOL_PLASTIC  # the stated contract
+    st = mat.last_stats
+    assert st["n_nan"] == 0 and st["n_not_converged"] == 0
+    assert abs(st["n_plastic"] - int(ref["plastic"].sum())) <= int((~safe).sum())
+    if kind == "voce":
+        assert 1 <= st["max_local_iters"] <= 25
+    fin = mat.get_final_state_dict()
+    assert np.array_equal(fin["stress"], sig) and np.array_equal(fin["p"][:, 0], isv[:, 0])
+    assert np.array_equal(fin["epsp"], isv[:, 1:])
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+def test_j2_history_load_unload(kind):
+    """4-increment load/unload history with advance() between increments."""
+    n = 5000
+    mat, hard = make_j2(kind)
+    mat.set_data_manager(n)
+    epsp = np.zeros((n, 6))
+    p = np.zeros(n)
+    fracs = []
+    for eps in j2_history(n, sig0=hard.sig0):
+        sig, isv, Ct = mat.integrate(eps)
+        # a second Newton-iteration-like call from the same s0 must give the same answer
+        sig2, isv2, Ct2 = mat.integrate(eps)
+        assert np.array_equal(sig, sig2) and np.array_equal(Ct, Ct2)
+        ref = onp.j2_update(eps, epsp, p, E, NU, hard)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * hard.sig0
+        assert relerr(sig[safe], ref["sig"][safe]) < TIGHT
+        assert relerr(Ct[safe], ref["Ct"][safe]) < TIGHT
+        assert np.abs(isv[safe, 0] - ref["p"][safe]).max() < 1e-15 + TIGHT * ref["p"].max()
+        fracs.append(ref["plastic"].mean())
+        mat.data_manager.update()
+        fin = mat.get_final_state_dict()
+        ini = mat.get_initial_state_dict()
+        assert np.array_equal(fin["p"], ini["p"]) and np.array_equal(fin["epsp"], ini["epsp"])
+        epsp, p = ref["epsp"], ref["p"]
+        # carry the device state (not the oracle's) forward only through the device
+    assert fracs[2] > 0.5 and fracs[3] == 0.0  # mostly plastic at peak, elastic unloading
+
+
+def test_revert_restores_initial_state():
+    n = 300
+    mat, hard = make_j2("linear")
+    mat.set_data_manager(n)
+    h = j2_history(n)
+    mat.integrate(h[2])
+    mat.data_manager.update()
+    ini = mat.get_initial_state_dict()
+    mat.integrate(h[2] * 1.5)
+    changed = mat.get_final_state_dict()
+    assert not np.array_equal(changed["p"], ini["p"])
+    mat.data_manager.revert()
+    fin = mat.get_final_state_dict()
+    assert np.array_equal(fin["p"], ini["p"]) and np.array_equal(fin["epsp"], ini["epsp"])
+
+
+def test_empty_batch():
+    mat, _ = make_j2("linear")
+    mat.set_data_manager(0)
+    sig, isv, Ct = mat.integrate(np.zeros((0, 6)))
+    assert sig.shape == (0, 6) and isv.shape == (0, 7) and Ct.shape == (0, 6, 6)
+
+
+def test_unknown_state_field_rejected():
+    mat, _ = make_j2("linear")
+    mat.set_data_manager(4)
+    with pytest.raises(AssertionError):
+        mat.set_initial_state_dict({"nonsense": np.zeros((4, 1))})
+
+
+def test_update_material_property_reaches_kernel():
+    n = 256
+    mat, hard = make_j2("linear")
+    mat.set_data_manager(n)
+    eps = j2_history(n)[2]
+    mat.update_material_property("yield_stress.sig0", 300.0)
+    sig, _, _ = mat.integrate(eps)
+    ref = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(300.0, H_LIN))
+    assert relerr(sig, ref["sig"]) < TIGHT
+
+
+def test_large_batch_properties():
+    """Full-size (1e7 points) size-independent properties: elastic unloading increments are
+    linear in the strain increment; tangent is symmetric; p is non-decreasing."""
+    n = 2_000_000
+    mat, hard = make_j2("linear")
+    mat.set_data_manager(n)
+    h = j2_history(n)
+    for eps in h[:3]:
+        sig, isv, Ct = mat.integrate(eps)
+        p_prev = mat.get_initial_state_dict()["p"][:, 0]
+        assert (isv[:, 0] >= p_prev - 1e-18).all()
+        assert np.abs(Ct - Ct.transpose(0, 2, 1)).max() < 1e-9
+        mat.data_manager.update()
+    sig3 = sig.copy()
+    sig4, isv4, Ct4 = mat.integrate(h[3])
+    C = onp.elastic_matrix(E, NU)
+    assert np.allclose(sig4 - sig3, (h[3] - h[2]) @ C.T, rtol=0, atol=1e-9 * np.abs(sig3).max())
+    assert mat.last_stats["n_plastic"] == 0
