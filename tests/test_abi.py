@@ -1,0 +1,100 @@
+"""CPU tests of the drop-in boundary: libdxmat.so loads, exports every symbol include/dxmat.h
+declares, reports the law table, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dolfinx_materials_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "dxmat.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dxm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_declare_the_same_symbols():
+    syms = header_symbols()
+    assert len(syms) >= 20
+    assert syms == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    for s in header_symbols():
+        assert hasattr(lib, s), s
+    assert lib.dxm_abi_version() == 1
+
+
+def test_law_table():
+    expect = {
+        _lib.LAW_ELASTIC_ISO: (6, 6, 2, {}, 384),
+        _lib.LAW_J2_LINEAR: (6, 6, 4, {"p": 1, "epsp": 6}, 496),
+        _lib.LAW_J2_VOCE: (6, 6, 5, {"p": 1, "epsp": 6}, 496),
+        _lib.LAW_FEFP_J2_VOCE: (9, 9, 5, {"p": 1, "be_bar": 6}, 976),
+    }
+    for law, (ng, nf, npar, isv, alg) in expect.items():
+        i = _lib.law_info(law)
+        assert (i.n_grad, i.n_flux, i.n_params, i.algorithmic_bytes_per_point) == (ng, nf, npar, alg)
+        got = {i.isv_name[f].decode(): i.isv_dim[f] for f in range(i.n_isv_fields)}
+        assert got == isv and i.n_isv_total == sum(isv.values())
+    with pytest.raises(_lib.DxmError):
+        _lib.law_info(99)
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.Stats) == 40
+    assert C.sizeof(_lib.LawInfo) == 16 + 16 + 32 + 8
+
+
+def test_protocol_surface_without_gpu():
+    """Names/sizes the QuadratureMap consumes exist before any device is touched
+    (quadrature_map.py:84-117)."""
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+    from dolfinx_materials_amd.python_materials import LinearElasticIsotropic
+
+    el = jm.LinearElasticIsotropic(E=70e3, nu=0.3)
+    m = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.VoceHardening(350.0, 500.0, 1e3)))
+    assert m.gradients == {"strain": 6} and m.fluxes == {"stress": 6}
+    assert m.internal_state_variables == {"p": 1, "epsp": 6}
+    assert m.tangent_blocks == {("stress", "strain"): (6, 6)}
+    assert m.variables == {"strain": 6, "stress": 6, "p": 1, "epsp": 6}
+    assert m.rotation_matrix is None and m.name == "vonMisesIsotropicHardening"
+    assert m.material_properties["yield_stress.sigu"] == 500.0
+    f = JAXMaterial(jm.FeFpJ2Plasticity(el, jm.VoceHardening(500.0, 750.0, 1000.0)))
+    assert f.gradients == {"F": 9} and f.fluxes == {"PK1": 9}
+    assert f.internal_state_variables == {"p": 1, "be_bar": 6}
+    e = LinearElasticIsotropic(70e3, 0.3)
+    assert e.gradients == {"Strain": 6} and e.fluxes == {"Stress": 6} and e.internal_state_variables == {}
+    with pytest.raises(NotImplementedError):
+        jm.vonMisesIsotropicHardening(el, lambda p: 250.0 + p)
+    with pytest.raises(_lib.DxmError):
+        m.integrate(np.zeros((4, 6)))  # set_data_manager not called
+
+
+def test_no_cpu_fallback():
+    """Without a usable HIP device the product path must raise, never compute on the host."""
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+
+    m = JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=1.0, nu=0.2)))
+    with pytest.raises(_lib.DxmError, match="no usable HIP device"):
+        m.set_data_manager(8)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "dolfinx_materials_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "oracle_c" not in txt and "liboracle" not in txt, f

@@ -1,0 +1,196 @@
+"""CPU tests that pin the oracle (numpy + plain C) against the reference's golden vectors, the
+in-tree closed-form spec and AD / finite-difference tangents.  No GPU, no product code."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import constitutive_np as onp
+from oracle import oracle_c
+from oracle.ref_import import import_reference, reference_available
+
+from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, j2_history, random_j2_state
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+HARDS = {
+    "linear": (onp.LinearHardening(SIG0_LIN, H_LIN), (0, SIG0_LIN, H_LIN, 0.0)),
+    "voce": (onp.VoceHardening(SIG0_V, SIGU_V, B_V), (1, SIG0_V, SIGU_V, B_V)),
+}
+
+
+def test_elastic_oracle_matches_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "elastic_ref.npz"))
+    for fn in (onp.elastic_iso, oracle_c.elastic_iso):
+        sig, Ct = fn(g["eps"], float(g["E"]), float(g["nu"]))
+        assert np.allclose(sig, g["sig"], rtol=1e-10, atol=0)
+        assert np.allclose(Ct, g["Ct"], rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference tree only exists in the build container")
+def test_elastic_oracle_matches_live_reference():
+    import warnings
+
+    _, pm = import_reference()
+    rng = np.random.default_rng(5)
+    eps = 1e-3 * rng.standard_normal((40, 6))
+    mat = pm.LinearElasticIsotropic(210e3, 0.25)
+    mat.set_data_manager(40)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sig, isv, Ct = mat.integrate(eps)
+    so, Co = onp.elastic_iso(eps, 210e3, 0.25)
+    assert np.allclose(so, sig, rtol=1e-10, atol=0) and np.allclose(Co, Ct, rtol=1e-10, atol=1e-9)
+    assert isv.shape == (40, 0) and Ct.shape == (40, 6, 6)
+
+
+def test_j2_coefficient_form_equals_mfront_literal_form():
+    """j2_update (eps_p state, Ct = c1 1x1 + c2 I + c3 nxn) == literal transcription of
+    IsotropicLinearHardeningPlasticity.mfront:49-77 (eel state, IxI/Id/M tensors)."""
+    n = 400
+    eps = j2_history(n, seed=3)[2]
+    epsp_n, p_n = random_j2_state(n)
+    r = onp.j2_update(eps, epsp_n, p_n, E, NU, HARDS["linear"][0])
+    sig, eel, p, Dt = onp.j2_update_mfront_form(eps, -epsp_n, p_n, E, NU, H_LIN, SIG0_LIN)
+    assert 0.3 < r["plastic"].mean() < 0.95
+    assert np.allclose(r["sig"], sig, rtol=1e-13, atol=1e-10)
+    assert np.allclose(r["Ct"], Dt, rtol=1e-13, atol=1e-9)
+    assert np.allclose(r["p"], p, rtol=1e-13, atol=1e-18)
+    assert np.allclose(r["epsp"], eps - eel, rtol=1e-12, atol=1e-18)
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+def test_tangent_matches_central_differences(kind):
+    hard = HARDS[kind][0]
+    n = 300
+    eps = j2_history(n, seed=11, sig0=hard.sig0)[2]
+    epsp_n, p_n = random_j2_state(n, sig0=hard.sig0)
+    r = onp.j2_update(eps, epsp_n, p_n, E, NU, hard)
+    h = 1e-8
+    fd = np.zeros((n, 6, 6))
+    for j in range(6):
+        d = np.zeros(6)
+        d[j] = h
+        fd[:, :, j] = (onp.j2_update(eps + d, epsp_n, p_n, E, NU, hard)["sig"] - onp.j2_update(eps - d, epsp_n, p_n, E, NU, hard)["sig"]) / (2 * h)
+    safe = np.abs(r["f_trial"]) > 1e-4 * hard.sig0  # FD straddles the kink otherwise
+    assert np.abs(fd[safe] - r["Ct"][safe]).max() < 2e-8 * np.abs(r["Ct"]).max()
+    assert np.abs(r["Ct"] - r["Ct"].transpose(0, 2, 1)).max() < 1e-9  # associative J2: symmetric
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+def test_tangent_matches_forward_mode_ad(kind):
+    """Same construction as the reference: vmap(jacfwd(constitutive_update, has_aux=True))
+    (jaxmat.py:147-151), with torch.func on a per-point restatement whose local Newton is
+    differentiated through (fixed iteration count), i.e. the derivative of the algorithm."""
+    torch = pytest.importorskip("torch")
+    from torch.func import jacfwd, vmap
+
+    hard, (k, s0, h1, h2) = HARDS[kind]
+    lmbda, mu = onp.lame(E, NU)
+    one = torch.tensor([1.0, 1, 1, 0, 0, 0], dtype=torch.float64)
+
+    def R(p):
+        return s0 + h1 * p if k == 0 else s0 + (h1 - s0) * (1 - torch.exp(-h2 * p))
+
+    def dR(p):
+        return torch.as_tensor(h1, dtype=torch.float64) if k == 0 else (h1 - s0) * h2 * torch.exp(-h2 * p)
+
+    def update(eps, epsp_n, p_n):
+        eel = eps - epsp_n
+        tr = eel[:3].sum()
+        se = 2 * mu * (eel - tr / 3 * one)
+        seq = torch.sqrt(1.5 * (se * se).sum())
+        dp = torch.zeros((), dtype=torch.float64)
+        for _ in range(12):
+            r = seq - 3 * mu * dp - R(p_n + dp)
+            dp = dp - r / (-3 * mu - dR(p_n + dp))
+        plastic = (seq - R(p_n)) > 0
+        dp = torch.where(plastic, dp, torch.zeros_like(dp))
+        nrm = 1.5 * se / torch.where(plastic, seq, torch.ones_like(seq))
+        eel = eel - dp * nrm
+        sig = lmbda * eel[:3].sum() * one + 2 * mu * eel
+        return sig, (epsp_n + dp * nrm, p_n + dp)
+
+    n = 64
+    eps = j2_history(n, seed=21, sig0=hard.sig0)[2]
+    epsp_n, p_n = random_j2_state(n, sig0=hard.sig0)
+    Ct_ad, (epsp_ad, p_ad) = vmap(jacfwd(update, argnums=0, has_aux=True))(
+        torch.from_numpy(eps), torch.from_numpy(epsp_n), torch.from_numpy(p_n)
+    )
+    r = onp.j2_update(eps, epsp_n, p_n, E, NU, hard)
+    safe = np.abs(r["f_trial"]) > 1e-6 * hard.sig0
+    assert np.abs(Ct_ad.numpy()[safe] - r["Ct"][safe]).max() < 1e-9 * np.abs(r["Ct"]).max()
+    assert np.allclose(p_ad.numpy()[safe], r["p"][safe], rtol=1e-10, atol=1e-16)
+    assert np.allclose(epsp_ad.numpy()[safe], r["epsp"][safe], rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+def test_return_lands_on_yield_surface_and_unloading_is_elastic(kind):
+    hard = HARDS[kind][0]
+    n = 500
+    h = j2_history(n, seed=8, sig0=hard.sig0)
+    _, mu = onp.lame(E, NU)
+    r = onp.j2_update(h[2], np.zeros((n, 6)), np.zeros(n), E, NU, hard)
+    s = r["sig"].copy()
+    s[:, :3] -= s[:, :3].mean(axis=1)[:, None]
+    seq = np.sqrt(1.5 * (s * s).sum(axis=1))
+    pl = r["plastic"]
+    assert np.allclose(seq[pl], hard.R(r["p"][pl]), rtol=1e-12)          # f(sigma, p) = 0
+    assert (seq[~pl] <= hard.R(r["p"][~pl]) + 1e-9).all()
+    assert np.allclose(r["epsp"][:, :3].sum(axis=1), 0, atol=1e-16)       # isochoric flow
+    assert np.allclose(np.sqrt(2 / 3 * (r["epsp"] ** 2).sum(axis=1)), r["p"], rtol=1e-12, atol=1e-18)
+    r2 = onp.j2_update(h[3], r["epsp"], r["p"], E, NU, hard)             # unloading
+    assert not r2["plastic"].any()
+    C = onp.elastic_matrix(E, NU)
+    assert np.allclose(r2["sig"] - r["sig"], (h[3] - h[2]) @ C.T, atol=1e-9 * np.abs(r["sig"]).max())
+    assert np.allclose(r2["Ct"], C[None], atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+def test_c_oracle_equals_numpy_oracle(kind):
+    hard, (k, s0, h1, h2) = HARDS[kind]
+    n = 3001
+    eps = j2_history(n, seed=5, sig0=hard.sig0)[2]
+    epsp_n, p_n = random_j2_state(n, sig0=hard.sig0)
+    r = onp.j2_update(eps, epsp_n, p_n, E, NU, hard)
+    for nt in (1, 3):
+        c = oracle_c.j2(eps, epsp_n, p_n, E, NU, k, s0, h1, h2, nthreads=nt)
+        safe = np.abs(r["f_trial"]) > 1e-9 * hard.sig0
+        for key in ("sig", "epsp", "p", "Ct"):
+            assert np.abs(c[key][safe] - r[key][safe]).max() <= 1e-13 * max(np.abs(r[key]).max(), 1e-300), key
+        assert c["n_not_converged"] == 0 and abs(c["n_plastic"] - r["plastic"].sum()) <= (~safe).sum()
+
+
+def test_protocol_golden_from_reference_plumbing():
+    """The (eps_p, p)-state oracle replays the sequence that was recorded through the reference's
+    own Material/DataManager machinery (tests/golden/make_golden.py::make_protocol)."""
+    g = np.load(os.path.join(GOLDEN, "protocol_ref.npz"))
+    hard = onp.LinearHardening(250.0, 5e3)
+    n = g["eps_hat"].shape[0]
+    s0 = dict(stress=np.zeros((n, 6)), p=np.zeros(n), epsp=np.zeros((n, 6)))
+    s1 = {k: v.copy() for k, v in s0.items()}
+    for k, (op, sc) in enumerate(zip(g["script"], g["scale"])):
+        if op == "integrate":
+            r = onp.j2_update(sc * g["eps_hat"], s0["epsp"], s0["p"], 70e3, 0.3, hard)
+            s1 = dict(stress=r["sig"], p=r["p"], epsp=r["epsp"])
+            assert np.allclose(r["sig"], g[f"flux_{k}"], rtol=1e-12, atol=1e-9)
+            assert np.allclose(np.hstack([r["p"][:, None], r["epsp"]]), g[f"isv_{k}"], rtol=1e-12, atol=1e-18)
+            assert np.allclose(r["Ct"], g[f"Ct_{k}"], rtol=1e-12, atol=1e-8)
+        elif op == "update":
+            s0 = {k2: v.copy() for k2, v in s1.items()}
+        else:
+            s1 = {k2: v.copy() for k2, v in s0.items()}
+        for key in ("stress", "p", "epsp"):
+            assert np.allclose(s0[key].reshape(n, -1), g[f"s0_{key}_{k}"], rtol=1e-12, atol=1e-9 if key == "stress" else 1e-18)
+            assert np.allclose(s1[key].reshape(n, -1), g[f"s1_{key}_{k}"], rtol=1e-12, atol=1e-9 if key == "stress" else 1e-18)
+
+
+def test_uniaxial_known_answer():
+    """tests/mfront/test_elastoplasticity.py:31-36: final sigma[:3] = 2/sqrt(3) [sig0, 0, sig0/2]."""
+    g = np.load(os.path.join(GOLDEN, "j2_uniaxial_kat.npz"))
+    hard = onp.LinearHardening(float(g["sig0"]), float(g["H"]))
+    epsp, p = np.zeros((1, 6)), np.zeros(1)
+    for eps, sig in zip(g["strain"][1:], g["stress"][1:]):
+        r = onp.j2_update(eps[None], epsp, p, float(g["E"]), float(g["nu"]), hard)
+        assert np.allclose(r["sig"][0], sig, rtol=1e-12, atol=1e-9)
+        epsp, p = r["epsp"], r["p"]
+    assert np.allclose(r["sig"][0, :3], g["expected"], rtol=1e-2, atol=1e-8)

@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: two gloo ranks own contiguous point blocks, update them independently
+(here with the oracle as the per-shard compute -- test infrastructure) and all-gather stress and
+tangent; the result must equal the single-process full-batch update."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows
+from oracle import constitutive_np as onp
+
+from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
+
+
+def test_shard_plan_partitions():
+    for n, w in [(10, 2), (11, 2), (7, 8), (0, 4), (100_000_001, 8)]:
+        p = ShardPlan(n, w)
+        b = p.bounds
+        assert b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(w))
+        counts = [p.count(r) for r in range(w)]
+        assert sum(counts) == n and max(counts) - min(counts) <= 1 and p.max_count == max(counts)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = ShardPlan(n, world)
+        lo, hi = plan.range(rank)
+        eps = j2_history(n, seed=77)[2]  # same global batch on every rank; each takes its block
+        hard = onp.LinearHardening(SIG0_LIN, H_LIN)
+        r = onp.j2_update(eps[lo:hi], np.zeros((hi - lo, 6)), np.zeros(hi - lo), E, NU, hard)
+        sig = allgather_rows(torch.from_numpy(r["sig"]), plan)
+        ct = allgather_rows(torch.from_numpy(r["Ct"].reshape(-1, 36)), plan)
+        if rank == 0:
+            q.put((sig.numpy(), ct.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 101])
+def test_two_rank_update_and_allgather_matches_single_process(n):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    sig, ct = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    eps = j2_history(n, seed=77)[2]
+    ref = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
+    assert np.array_equal(sig, ref["sig"]) and np.array_equal(ct, ref["Ct"].reshape(n, 36))
