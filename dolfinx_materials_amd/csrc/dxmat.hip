@@ -50,6 +50,7 @@ static int fail(int code, const char* fmt, ...) {
 struct LawDesc {
   int n_grad, n_flux, n_params;
   int n_isv_fields;                       // user-visible
+  int n_fields;                           // incl. hidden state fields (addressable by set/get_state)
   int isv_dim[DXM_MAX_STATE_FIELDS];
   const char* isv_name[DXM_MAX_STATE_FIELDS];
   int isv_slot[DXM_MAX_STATE_FIELDS];     // first SoA slot of the field
@@ -59,13 +60,14 @@ struct LawDesc {
 };
 
 static const LawDesc kLaws[DXM_LAW_COUNT] = {
-    {6, 6, 2, 0, {0, 0, 0, 0}, {nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, 0, 384,
+    {6, 6, 2, 0, 0, {0, 0, 0, 0}, {nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, 0, 384,
      "small_strain_kernel<0"},
-    {6, 6, 4, 2, {1, 6, 0, 0}, {"p", "epsp", nullptr, nullptr}, {0, 1, 0, 0}, SS_NSLOTS, 496,
+    {6, 6, 4, 2, 2, {1, 6, 0, 0}, {"p", "epsp", nullptr, nullptr}, {0, 1, 0, 0}, SS_NSLOTS, 496,
      "small_strain_kernel<1"},
-    {6, 6, 5, 2, {1, 6, 0, 0}, {"p", "epsp", nullptr, nullptr}, {0, 1, 0, 0}, SS_NSLOTS, 496,
+    {6, 6, 5, 2, 2, {1, 6, 0, 0}, {"p", "epsp", nullptr, nullptr}, {0, 1, 0, 0}, SS_NSLOTS, 496,
      "small_strain_kernel<2"},
-    {9, 9, 5, 2, {1, 6, 0, 0}, {"p", "be_bar", nullptr, nullptr}, {0, 1, 0, 0}, FEFP_NSLOTS, 976,
+    // field 2 is hidden state: the isochoric inverse plastic right Cauchy-Green tensor
+    {9, 9, 5, 2, 3, {1, 6, 6, 0}, {"p", "be_bar", "cp_bar_inv", nullptr}, {FEFP_SLOT_P, FEFP_SLOT_BE, FEFP_SLOT_CPI, 0}, FEFP_NSLOTS, 976,
      "fefp_kernel"},
 };
 
@@ -284,7 +286,7 @@ static int check_field(const dxm_material* m, int which, int field) {
   if (!m) return fail(-1, "null handle");
   if (which != DXM_S0 && which != DXM_S1) return fail(-1, "state selector must be DXM_S0 or DXM_S1");
   const LawDesc& d = kLaws[m->law];
-  if (field < 0 || field >= d.n_isv_fields) return fail(-1, "law %d has no state field %d", m->law, field);
+  if (field < 0 || field >= d.n_fields) return fail(-1, "law %d has no state field %d", m->law, field);
   return 0;
 }
 
@@ -310,8 +312,6 @@ static int materialize_s1(dxm_material* m) {
   return 0;
 }
 
-// forward
-static int refresh_hidden_state(dxm_material* m, int which);
 
 int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos) {
   if (int rc = check_field(m, which, field)) return rc;
@@ -329,7 +329,7 @@ int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos)
   double* dst = state_of(m, which) + (size_t)d.isv_slot[field] * m->ld;
   HIP_TRY(hipMemcpy2D(dst, m->ld * sizeof(double), tmp.data(), n * sizeof(double),
                       n * sizeof(double), dim, hipMemcpyHostToDevice));
-  return refresh_hidden_state(m, which);
+  return 0;
 }
 
 int dxm_get_state(dxm_material* m, int which, int field, double* host_aos) {
@@ -512,14 +512,3 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
 const char* dxm_kernel_name(const dxm_material* m) { return m ? kLaws[m->law].kernel : ""; }
 
 }  // extern "C"
-
-// FeFp keeps a hidden state field (isochoric Cp^-1) next to the user-visible be_bar; when the
-// user overwrites be_bar through set_initial_state_dict, rebuild it assuming F_n = I
-// (be_bar = Cp^-1 in that configuration).
-static int refresh_hidden_state(dxm_material* m, int which) {
-  if (m->law != DXM_LAW_FEFP_J2_VOCE || m->n == 0) return 0;
-  HIP_TRY(hipMemcpy2D(state_of(m, which) + (size_t)FEFP_SLOT_CPI * m->ld, m->ld * sizeof(double),
-                      state_of(m, which) + (size_t)FEFP_SLOT_BE * m->ld, m->ld * sizeof(double),
-                      m->n * sizeof(double), 6, hipMemcpyDeviceToDevice));
-  return 0;
-}

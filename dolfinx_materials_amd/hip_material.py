@@ -236,8 +236,18 @@ class HIPMaterial:
                 self._grad[0] = a.copy()
             elif key == self._fname:
                 self._flux[0] = a.copy()
+            elif key == "be_bar" and self.behavior.law == _lib.LAW_FEFP_J2_VOCE:
+                continue  # handled below together with F
             else:
                 _lib.check(self._lib.dxm_set_state(h, S0, isv_names.index(key), _ptr(a)))
+        if self.behavior.law == _lib.LAW_FEFP_J2_VOCE and ("be_bar" in state or self._gname in state):
+            # the kernel's state is the isochoric Cp^-1 (hidden field 2), rebuilt from (F_n, be_bar_n)
+            from .conventions import cp_bar_inv_from_be_bar
+
+            be = _as_c(state["be_bar"], (self._n, 6)) if "be_bar" in state else self._isv_dict(S0)["be_bar"]
+            cpi, be = cp_bar_inv_from_be_bar(self._grad[0], be)
+            _lib.check(self._lib.dxm_set_state(h, S0, 1, _ptr(_as_c(be))))
+            _lib.check(self._lib.dxm_set_state(h, S0, 2, _ptr(_as_c(cpi))))
 
     def _advance(self):
         _lib.check(self._lib.dxm_advance(self._require()))

@@ -239,3 +239,197 @@ def j2_update_mfront_form(deto, eel_n, p_n, E, nu, H, s0):
         eel[i] = e
         sig[i] = lmbda * (e[0] + e[1] + e[2]) * np.array([1, 1, 1, 0, 0, 0.0]) + 2 * mu * e
     return sig, eel, p, Dt
+
+
+# ----------------------------------------------------------------------------------------
+# law 3: finite-strain FeFp J2 plasticity (gradient F, flux PK1)
+# ----------------------------------------------------------------------------------------
+# The reference only fixes the interface of this law (gradient "F" (9), flux "PK1" (9), ISVs p
+# and be_bar initialised to the identity: jaxmat.py:170-186,
+# demos/jax/finite_strain_elastoplasticity/finite_strain_elastoplasticity.py:165-181, driver and
+# parameters tests/test_FeFp_jax.py:7-31); the arithmetic lives in the absent third-party
+# jaxmat package.  PARITY UNPINNED.  The algorithm below is the build's own documented choice
+# (DESIGN.md "FeFp"): Simo's multiplicative J2 model (Simo & Hughes 1998, ch. 9; Simo 1992)
+# with the isochoric elastic left Cauchy-Green tensor be_bar as internal variable,
+#   psi  = kappa/2 (1/2 (J^2-1) - ln J) + mu/2 (tr be_bar - 3)
+#   tau  = kappa/2 (J^2-1) 1 + mu dev(be_bar),        P = tau F^-T
+#   f    = sqrt(3/2) |dev tau| - R(p),  R = Voce
+#   flow : dev(be_bar) = dev(be_bar_trial) - 2 dp (tr be_bar / 3) n,  n = sqrt(3/2) s/|s|
+#          det(be_bar) = 1   (exactly isochoric update instead of Simo's tr-preserving one)
+# with be_bar_trial = J^(-2/3) F Cp_bar^-1 F^T.  Because the return is radial in the direction
+# s_hat of dev(be_bar_trial), the 7 unknowns (dp, be_bar) reduce to two scalars (dp, Ie) with
+# be_bar = Ie 1 + a s_hat:
+#   r1 = a_tr - a(dp) - sqrt(6) dp Ie = 0,  a(dp) = sqrt(2/3) R(p_n + dp) / mu
+#   r2 = Ie^3 - a^2 Ie / 2 + a^3 det(s_hat) - 1 = 0
+# solved by a 2x2 Newton from (0, tr(be_bar_trial)/3).  Persistent state: p and the isochoric
+# inverse plastic right Cauchy-Green tensor Cp_bar^-1 = J^(2/3) F^-1 be_bar F^-T (hidden), plus
+# be_bar itself as the user-visible ISV.  The tangent dP/dF is the exact derivative of this
+# algorithm (implicit differentiation of the 2x2 system), column by column.
+
+SQ32 = np.sqrt(1.5)
+SQ6 = np.sqrt(6.0)
+
+
+def _det3(A):
+    return (
+        A[..., 0, 0] * (A[..., 1, 1] * A[..., 2, 2] - A[..., 1, 2] * A[..., 2, 1])
+        - A[..., 0, 1] * (A[..., 1, 0] * A[..., 2, 2] - A[..., 1, 2] * A[..., 2, 0])
+        + A[..., 0, 2] * (A[..., 1, 0] * A[..., 2, 1] - A[..., 1, 1] * A[..., 2, 0])
+    )
+
+
+def _cof3(A):
+    """Cofactor matrix: d det(A) / dA (valid for singular A)."""
+    C = np.empty_like(A)
+    for i in range(3):
+        for j in range(3):
+            i1, i2 = (i + 1) % 3, (i + 2) % 3
+            j1, j2 = (j + 1) % 3, (j + 2) % 3
+            C[..., i, j] = A[..., i1, j1] * A[..., i2, j2] - A[..., i1, j2] * A[..., i2, j1]
+    return C
+
+
+def fefp_scale_tol(hard, mu, a_tr, rtol=NEWTON_RTOL):
+    return rtol * np.maximum(hard.sig0, SQ32 * mu * a_tr)
+
+
+def fefp_update(F9, cpinv_n, p_n, E, nu, hard, maxit=NEWTON_MAXIT, rtol=NEWTON_RTOL, tangent=True):
+    """F9 (N,9) non-symmetric ordering; cpinv_n (N,6) Mandel; p_n (N,).
+    Returns dict(P (N,9), be_bar (N,6), cpinv (N,6), p (N,), Ct (N,9,9), plastic, iters, notconv)."""
+    F9 = np.asarray(F9, dtype=np.float64)
+    N = F9.shape[0]
+    lmbda, mu = lame(E, nu)
+    kappa = lmbda + 2 * mu / 3
+    I3 = np.eye(3)
+    F = nsym_to_tensor(F9)
+    G = mandel_to_tensor(cpinv_n)
+    p_n = np.asarray(p_n, dtype=np.float64).reshape(-1)
+
+    J = _det3(F)
+    Finv = _cof3(F).transpose(0, 2, 1) / J[:, None, None]
+    Jm23 = J ** (-2.0 / 3.0)
+    GFt = G @ F.transpose(0, 2, 1)
+    B = F @ GFt
+    btr = Jm23[:, None, None] * B
+    Itr = (btr[:, 0, 0] + btr[:, 1, 1] + btr[:, 2, 2]) / 3.0
+    d = btr - Itr[:, None, None] * I3
+    a_tr = np.sqrt(np.einsum("nij,nij->n", d, d))
+    f_trial = SQ32 * mu * a_tr - hard.R(p_n)
+    plastic = f_trial > 0.0
+
+    dp = np.zeros(N)
+    Ie = Itr.copy()
+    a = a_tr.copy()
+    shat = np.zeros((N, 3, 3))
+    delta = np.zeros(N)
+    iters = np.zeros(N, dtype=np.int32)
+    notconv = np.zeros(N, dtype=bool)
+    idx = np.nonzero(plastic)[0]
+    if idx.size:
+        sh = d[idx] / a_tr[idx, None, None]
+        de = _det3(sh)
+        atr = a_tr[idx]
+        pn = p_n[idx]
+        x_dp = np.zeros(idx.size)
+        x_Ie = Itr[idx].copy()
+        tol1 = fefp_scale_tol(hard, mu, atr, rtol)
+        it = np.zeros(idx.size, dtype=np.int32)
+        done = np.zeros(idx.size, dtype=bool)
+        for k in range(maxit + 1):
+            aa = np.sqrt(2.0 / 3.0) * hard.R(pn + x_dp) / mu
+            r1 = atr - aa - SQ6 * x_dp * x_Ie
+            r2 = x_Ie**3 - 0.5 * aa * aa * x_Ie + aa**3 * de - 1.0
+            conv = (np.abs(SQ32 * mu * r1) <= tol1) & (np.abs(r2) <= 1e-14)
+            done |= conv
+            if done.all():
+                break
+            if k == maxit:
+                notconv[idx[~done]] = True
+                break
+            ap = np.sqrt(2.0 / 3.0) * hard.dR(pn + x_dp) / mu
+            j11 = -ap - SQ6 * x_Ie
+            j12 = -SQ6 * x_dp
+            j21 = (-aa * x_Ie + 3 * aa * aa * de) * ap
+            j22 = 3 * x_Ie**2 - 0.5 * aa * aa
+            det = j11 * j22 - j12 * j21
+            ddp = (-r1 * j22 + r2 * j12) / det
+            dIe = (-j11 * r2 + j21 * r1) / det
+            act = ~done
+            x_dp = np.where(act, x_dp + ddp, x_dp)
+            x_Ie = np.where(act, x_Ie + dIe, x_Ie)
+            it += act
+        dp[idx] = x_dp
+        Ie[idx] = x_Ie
+        a[idx] = np.sqrt(2.0 / 3.0) * hard.R(pn + x_dp) / mu
+        shat[idx] = sh
+        delta[idx] = de
+        iters[idx] = it
+
+    be = np.where(plastic[:, None, None], Ie[:, None, None] * I3 + a[:, None, None] * shat, btr)
+    s = mu * (be - ((be[:, 0, 0] + be[:, 1, 1] + be[:, 2, 2]) / 3.0)[:, None, None] * I3)
+    tau = 0.5 * kappa * (J * J - 1.0)[:, None, None] * I3 + s
+    FinvT = Finv.transpose(0, 2, 1)
+    P = tau @ FinvT
+    p = p_n + dp
+    cpinv = (J ** (2.0 / 3.0))[:, None, None] * (Finv @ be @ FinvT)
+
+    out = dict(
+        P=tensor_to_nsym(P), be_bar=tensor_to_mandel(be), cpinv=tensor_to_mandel(0.5 * (cpinv + cpinv.transpose(0, 2, 1))),
+        p=p, plastic=plastic, iters=iters, notconv=notconv, f_trial=f_trial,
+    )
+    if not tangent:
+        return out
+
+    # ---- consistent tangent dP/dF, one column per basis direction dF = e_k (x) e_l -------------
+    Ct = np.empty((N, 9, 9))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ap = np.sqrt(2.0 / 3.0) * hard.dR(p) / mu
+        gI = 3 * Ie**2 - 0.5 * a * a
+        dIe_da = (a * Ie - 3 * a * a * delta) / gI
+        dIe_dd = -(a**3) / gI
+        r_dp = -ap - SQ6 * Ie - SQ6 * dp * dIe_da * ap
+        r_dd = -SQ6 * dp * dIe_dd
+        cof_s = _cof3(shat)
+    for col, (k, l) in enumerate(NSYM_IDX):
+        dF = np.zeros((N, 3, 3))
+        dF[:, k, l] = 1.0
+        trFinvdF = Finv[:, l, k]
+        dJ = J * trFinvdF
+        M = dF @ GFt
+        dB = M + M.transpose(0, 2, 1)
+        dbtr = Jm23[:, None, None] * dB - (2.0 / 3.0) * trFinvdF[:, None, None] * btr
+        dItr = (dbtr[:, 0, 0] + dbtr[:, 1, 1] + dbtr[:, 2, 2]) / 3.0
+        dd = dbtr - dItr[:, None, None] * I3
+        ds_el = mu * dd
+        with np.errstate(divide="ignore", invalid="ignore"):
+            datr = np.einsum("nij,nij->n", shat, dd)
+            dsh = (dd - shat * datr[:, None, None]) / a_tr[:, None, None]
+            ddel = np.einsum("nij,nij->n", cof_s, dsh)
+            ddp = -(datr + r_dd * ddel) / r_dp
+            da = ap * ddp
+            ds_pl = mu * (da[:, None, None] * shat + a[:, None, None] * dsh)
+        ds = np.where(plastic[:, None, None], ds_pl, ds_el)
+        dtau = (kappa * J * dJ)[:, None, None] * I3 + ds
+        dP = dtau @ FinvT - P @ dF.transpose(0, 2, 1) @ FinvT
+        Ct[:, :, col] = tensor_to_nsym(dP)
+    out["Ct"] = Ct
+    return out
+
+
+def fefp_initial_state(n):
+    """p = 0, be_bar = Cp_bar^-1 = identity (behavior.init_state, jaxmat.py:35;
+    finite_strain_elastoplasticity.py:181)."""
+    ident = np.zeros((n, 6))
+    ident[:, :3] = 1.0
+    return dict(p=np.zeros(n), be_bar=ident.copy(), cpinv=ident.copy())
+
+
+def cpinv_from_be_bar(F9, be_bar):
+    """Hidden state from the user-visible pair (F_n, be_bar_n):
+    Cp_bar^-1 = J^(2/3) F^-1 be_bar F^-T."""
+    F = nsym_to_tensor(F9)
+    be = mandel_to_tensor(be_bar)
+    J = _det3(F)
+    Finv = _cof3(F).transpose(0, 2, 1) / J[:, None, None]
+    G = (J ** (2.0 / 3.0))[:, None, None] * (Finv @ be @ Finv.transpose(0, 2, 1))
+    return tensor_to_mandel(0.5 * (G + G.transpose(0, 2, 1)))

@@ -19,6 +19,8 @@ Fixtures
                      (E=70e3, nu=0.3, H=1e-6, sig0=250, 50 steps to eps_xx=2e-2, eps_zz=0,
                      sig_yy=0): strain path and stresses from the oracle; the known answer
                      2/sqrt(3)*[sig0, 0, sig0/2] (rtol 1e-2) is asserted at generation time.
+  fefp_self.npz      SELF-golden (parity unpinned): the build's FeFp oracle along the path of
+                     tests/test_FeFp_jax.py:21-33 (Nbatch=10, 19 steps).
 """
 import os
 import sys
@@ -138,7 +140,26 @@ def make_uniaxial():
     np.savez(os.path.join(HERE, "j2_uniaxial_kat.npz"), E=E, nu=nu, sig0=sig0, H=H, strain=np.array(path), stress=sigs, expected=expected)
 
 
+def make_fefp_self():
+    """Self-golden (parity unpinned: tests/test_FeFp_jax.py has no assertions and jaxmat is
+    absent): stresses and p of the build's own FeFp oracle along the exact driver path of
+    tests/test_FeFp_jax.py:21-33."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import E, NU, SIG0_F, SIGU_F, B_F, fefp_path
+
+    hard = onp.VoceHardening(SIG0_F, SIGU_F, B_F)
+    st = onp.fefp_initial_state(10)
+    cp, p = st["cpinv"], st["p"]
+    Ps, ps, Fs = [], [], []
+    for F in fefp_path(10, pert=0.0):
+        r = onp.fefp_update(F, cp, p, E, NU, hard, tangent=False)
+        Ps.append(r["P"]); ps.append(r["p"]); Fs.append(F)
+        cp, p = r["cpinv"], r["p"]
+    np.savez(os.path.join(HERE, "fefp_self.npz"), F=np.array(Fs), P=np.array(Ps), p=np.array(ps))
+
+
 if __name__ == "__main__":
+    make_fefp_self()
     make_elastic()
     make_protocol()
     make_uniaxial()

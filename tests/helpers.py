@@ -30,3 +30,24 @@ def random_j2_state(n, seed=7, sig0=SIG0_LIN):
     epsp[:, :3] -= epsp[:, :3].mean(axis=1)[:, None]
     p = rng.uniform(0.0, 2e-3, n)
     return epsp, p
+
+
+# FeFp (tests/test_FeFp_jax.py:7-15)
+SIG0_F, SIGU_F, B_F = 500.0, 750.0, 1000.0
+
+
+def fefp_path(n, nsteps=19, eps=2e-2, seed=4321, pert=0.2, n_exact=10):
+    """F_k = I + t_k (eps diag(1,-1/2,-1/2) + pert eps G), t_k = k/nsteps, G ~ N(0,1)^{3x3};
+    the first `n_exact` points have G = 0, i.e. exactly the path of tests/test_FeFp_jax.py:28-30
+    (F = diag(1 + eps t, 1 - eps t/2, 1 - eps t/2)).  Returns a list of (n,9) arrays."""
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, 3, 3))
+    G[: min(n_exact, n)] = 0.0
+    out = []
+    for k in range(1, nsteps + 1):
+        t = k / nsteps
+        F = np.zeros((n, 3, 3))
+        F[:] = np.eye(3)
+        F += t * (eps * np.diag([1.0, -0.5, -0.5]) + pert * eps * G)
+        out.append(onp.tensor_to_nsym(F))
+    return out

@@ -194,3 +194,82 @@ def test_uniaxial_known_answer():
         assert np.allclose(r["sig"][0], sig, rtol=1e-12, atol=1e-9)
         epsp, p = r["epsp"], r["p"]
     assert np.allclose(r["sig"][0, :3], g["expected"], rtol=1e-2, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------
+# FeFp (parity unpinned; the oracle is pinned by construction checks only)
+# ---------------------------------------------------------------------------------------------
+from helpers import SIG0_F, SIGU_F, B_F, fefp_path  # noqa: E402
+
+HARD_F = onp.VoceHardening(SIG0_F, SIGU_F, B_F)
+
+
+def test_fefp_tangent_matches_central_differences_and_be_bar_is_isochoric():
+    n = 120
+    st = onp.fefp_initial_state(n)
+    cp, p = st["cpinv"], st["p"]
+    path = fefp_path(n)
+    for k, F in enumerate(path):
+        r = onp.fefp_update(F, cp, p, E, NU, HARD_F, tangent=(k in (0, 6, 18)))
+        if "Ct" in r:
+            h = 1e-7
+            fd = np.zeros((n, 9, 9))
+            for j in range(9):
+                e = np.zeros(9)
+                e[j] = h
+                fd[:, :, j] = (onp.fefp_update(F + e, cp, p, E, NU, HARD_F, tangent=False)["P"] - onp.fefp_update(F - e, cp, p, E, NU, HARD_F, tangent=False)["P"]) / (2 * h)
+            safe = np.abs(r["f_trial"]) > 1e-3 * SIG0_F
+            assert np.abs(fd[safe] - r["Ct"][safe]).max() < 2e-8 * np.abs(r["Ct"]).max()
+        assert not r["notconv"].any() and r["iters"].max() <= 8
+        be = onp.mandel_to_tensor(r["be_bar"])
+        assert np.abs(onp._det3(be) - 1).max() < 1e-13
+        cp, p = r["cpinv"], r["p"]
+    assert r["plastic"].all()
+    # uniaxial points of tests/test_FeFp_jax.py: saturated Voce stress, Kirchhoff tau_eq = R(p)
+    tau = onp.nsym_to_tensor(r["P"][:10]) @ onp.nsym_to_tensor(path[-1][:10]).transpose(0, 2, 1)
+    s = tau - np.trace(tau, axis1=1, axis2=2)[:, None, None] / 3 * np.eye(3)
+    assert np.allclose(np.sqrt(1.5 * (s * s).sum((1, 2))), HARD_F.R(r["p"][:10]), rtol=1e-11)
+
+
+def test_fefp_small_strain_limit_is_j2_voce():
+    n = 200
+    rng = np.random.default_rng(2)
+    scale = 1e-6
+    # tiny strains with a yield stress scaled down so that the step is plastic
+    hard = onp.VoceHardening(SIG0_F * 1e-4, SIGU_F * 1e-4, B_F)
+    H = scale * rng.standard_normal((n, 3, 3))
+    eps = onp.tensor_to_mandel(0.5 * (H + H.transpose(0, 2, 1)))
+    r_ss = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, hard)
+    r_fs = onp.fefp_update(onp.tensor_to_nsym(np.eye(3) + H), onp.fefp_initial_state(n)["cpinv"], np.zeros(n), E, NU, hard)
+    assert r_ss["plastic"].mean() > 0.5
+    P = onp.nsym_to_tensor(r_fs["P"])
+    sig = onp.mandel_to_tensor(r_ss["sig"])
+    assert np.abs(P - sig).max() < 50 * scale * np.abs(sig).max()  # O(|H|) relative difference
+    assert np.abs(r_fs["p"] - r_ss["p"]).max() < 50 * scale * r_ss["p"].max()
+
+
+def test_fefp_objectivity_of_the_oracle():
+    n = 64
+    rng = np.random.default_rng(10)
+    F = np.eye(3) + 0.04 * rng.standard_normal((n, 3, 3))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, 3, 3)))
+    Q *= np.sign(np.linalg.det(Q))[:, None, None]
+    cp = onp.fefp_initial_state(n)["cpinv"]
+    r1 = onp.fefp_update(onp.tensor_to_nsym(F), cp, np.zeros(n), E, NU, HARD_F, tangent=False)
+    r2 = onp.fefp_update(onp.tensor_to_nsym(Q @ F), cp, np.zeros(n), E, NU, HARD_F, tangent=False)
+    assert np.allclose(onp.nsym_to_tensor(r2["P"]), Q @ onp.nsym_to_tensor(r1["P"]), rtol=0, atol=1e-10 * np.abs(r1["P"]).max())
+    assert np.allclose(r1["p"], r2["p"], rtol=1e-11, atol=1e-18)
+    assert np.allclose(r1["cpinv"], r2["cpinv"], rtol=0, atol=1e-13)  # material tensor: unchanged
+
+
+def test_fefp_self_golden_reference_smoke_path():
+    """Self-golden (parity unpinned): the oracle's stresses along the exact path of
+    tests/test_FeFp_jax.py:21-33 (Nbatch=10, 19 steps), committed as tests/golden/fefp_self.npz."""
+    g = np.load(os.path.join(GOLDEN, "fefp_self.npz"))
+    st = onp.fefp_initial_state(10)
+    cp, p = st["cpinv"], st["p"]
+    for k, F in enumerate(fefp_path(10, pert=0.0)):
+        r = onp.fefp_update(F, cp, p, E, NU, HARD_F, tangent=False)
+        assert np.allclose(r["P"], g["P"][k], rtol=1e-12, atol=1e-9)
+        assert np.allclose(r["p"], g["p"][k], rtol=1e-11, atol=1e-18)
+        cp, p = r["cpinv"], r["p"]
