@@ -90,6 +90,8 @@ struct dxm_material {
   int maxit = 25;
   double rtol = 1e-14;
   double* state[2] = {nullptr, nullptr};  // [n_slots][ld] each
+  double* state_base = nullptr;           // one allocation holds s0 and s1
+  size_t s1_skew = 0;
   bool s1_alias = false;  // after advance()/revert() s1 == s0 until the next integrate: no copy is made
   BlockStats* d_stats = nullptr;
   int stats_capacity = 0;
@@ -221,8 +223,13 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   m->law = law;
   m->device = device;
   m->n = npoints;
-  m->ld = ((npoints + 255) / 256) * 256;
-  if (m->ld == 0) m->ld = 256;
+  // SoA leading dimension: N rounded up to 256 plus 32 doubles.  With a slot stride that is a
+  // multiple of 2 KiB the s0 read streams and s1 write streams of all slots stay congruent and the
+  // kernel falls into a slow mode (0.91 vs 0.83 ms at 1e7 points, bimodal by allocation address);
+  // a 256 B stagger per slot removes it (profiles/r01_tune_state_stride.txt).
+  m->ld = ((npoints + 255) / 256) * 256 + 32;
+  if (const char* s = getenv("DXM_LD_PAD")) m->ld += (atoi(s) / 2) * 2 - 32;   // tuning knob (doubles)
+  if (const char* s = getenv("DXM_S1_SKEW")) m->s1_skew = (size_t)atol(s) & ~(size_t)15;  // tuning knob (bytes)
   if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : 5;
   if (const char* s = getenv("DXM_NT_STORE")) m->nt_store = atoi(s) != 0;
   auto bail = [&](void) -> dxm_material* { dxm_destroy(m); return nullptr; };
@@ -236,11 +243,11 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   const LawDesc& d = kLaws[law];
   if (d.n_slots > 0) {
     const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
-    for (int w = 0; w < 2; ++w) {
-      if (hipMalloc(&m->state[w], bytes) != hipSuccess) {
-        fail(-3, "hipMalloc of %zu state bytes failed", bytes); return bail();
-      }
+    if (hipMalloc(&m->state_base, 2 * bytes + m->s1_skew) != hipSuccess) {
+      fail(-3, "hipMalloc of %zu state bytes failed", 2 * bytes + m->s1_skew); return bail();
     }
+    m->state[0] = m->state_base;
+    m->state[1] = reinterpret_cast<double*>(reinterpret_cast<char*>(m->state_base) + bytes + m->s1_skew);
   }
   m->stats_capacity = m->num_cu * 16;
   if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {
@@ -255,7 +262,7 @@ int dxm_destroy(dxm_material* m) {
   if (!m) return 0;
   (void)hipSetDevice(m->device);
   if (m->launched && m->last_stream) (void)hipStreamSynchronize(m->last_stream);
-  for (int w = 0; w < 2; ++w) if (m->state[w]) (void)hipFree(m->state[w]);
+  if (m->state_base) (void)hipFree(m->state_base);
   if (m->d_stats) (void)hipFree(m->d_stats);
   if (m->d_grad) (void)hipFree(m->d_grad);
   if (m->d_flux) (void)hipFree(m->d_flux);
