@@ -115,11 +115,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DXM_BENCH_SHARE_GPU=1 (debug only): all ranks use GPU 0 and gloo, to exercise the N > 1
+    # code path on a 1-GPU box; never used for reported numbers.
+    share = os.environ.get("DXM_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n = args.points
     K, W = args.steps, args.warmup
@@ -134,7 +141,7 @@ def main():
     def make():
         m = JAXMaterial(
             jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)),
-            device=local_rank,
+            device=dev_index,
         )
         m.set_data_manager(n)
         return m
@@ -182,19 +189,20 @@ def main():
 
     gather = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if share else dev  # gloo debug mode keeps collectives on the host
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         # gather-inclusive variant: reassemble stress and tangent on every rank over xGMI
         plan = ShardPlan(n * world, world)
-        g_flux = torch.empty((n * world, 6), dtype=torch.float64, device=dev)
-        g_ct = torch.empty((n * world, 36), dtype=torch.float64, device=dev)
+        g_flux = torch.empty((n * world, 6), dtype=torch.float64, device=cdev)
+        g_ct = torch.empty((n * world, 36), dtype=torch.float64, device=cdev)
         G = max(1, args.gather_steps)
 
         def gstep(i):
             step(i)
-            allgather_rows(flux, plan, out=g_flux)
-            allgather_rows(ct, plan, out=g_ct)
+            allgather_rows(flux.to(cdev), plan, out=g_flux)
+            allgather_rows(ct.to(cdev), plan, out=g_ct)
 
         gstep(0)
         barrier()
@@ -202,7 +210,7 @@ def main():
         for i in range(G):
             gstep(i)
         barrier()
-        gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
+        gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=cdev)
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
         gather = {
             "value": round(n * world * G / float(gt.item()) / 1e6, 3),
@@ -240,7 +248,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "cfg2: J2 von-Mises plasticity, linear isotropic hardening, small strain, "
-                "1e7 Gauss points per GPU, stress + 6x6 consistent tangent, load/unload history increments 2-4",
+                f"{n:.3g} Gauss points per GPU, stress + 6x6 consistent tangent, load/unload history increments 2-4",
                 "points_per_gpu": n,
                 "law": "j2_linear",
                 "E": E, "nu": NU, "sig0": SIG0, "H": H,

@@ -230,7 +230,6 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   m->ld = ((npoints + 255) / 256) * 256 + 32;
   if (const char* s = getenv("DXM_LD_PAD")) m->ld += (atoi(s) / 2) * 2 - 32;   // tuning knob (doubles)
   if (const char* s = getenv("DXM_S1_SKEW")) m->s1_skew = (size_t)atol(s) & ~(size_t)15;  // tuning knob (bytes)
-  if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : 5;
   if (const char* s = getenv("DXM_NT_STORE")) m->nt_store = atoi(s) != 0;
   auto bail = [&](void) -> dxm_material* { dxm_destroy(m); return nullptr; };
   if (build_params(m, params, n_params) != 0) return bail();
@@ -248,6 +247,21 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
     }
     m->state[0] = m->state_base;
     m->state[1] = reinterpret_cast<double*>(reinterpret_cast<char*>(m->state_base) + bytes + m->s1_skew);
+  }
+  // persistent grid = workgroups that are resident at once (occupancy query per kernel)
+  {
+    int occ = 0;
+    const void* fn = nullptr;
+    switch (law) {
+      case DXM_LAW_ELASTIC_ISO: fn = (const void*)small_strain_kernel<LAW_ELASTIC, false>; break;
+      case DXM_LAW_J2_LINEAR: fn = (const void*)small_strain_kernel<LAW_J2_LINEAR, false>; break;
+      case DXM_LAW_J2_VOCE: fn = (const void*)small_strain_kernel<LAW_J2_VOCE, false>; break;
+      default: fn = (const void*)fefp_kernel; break;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, BLOCK, 0) == hipSuccess && occ > 0)
+      m->blocks_per_cu = occ;
+    if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : m->blocks_per_cu;
+    if (m->blocks_per_cu > 16) m->blocks_per_cu = 16;
   }
   m->stats_capacity = m->num_cu * 16;
   if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {

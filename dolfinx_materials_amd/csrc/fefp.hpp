@@ -25,7 +25,7 @@ constexpr int FEFP_SLOT_BE = 1;   // be_bar, Mandel (user-visible ISV)
 constexpr int FEFP_SLOT_CPI = 7;  // isochoric Cp^-1, Mandel (hidden state)
 constexpr int FEFP_NSLOTS = 13;
 
-constexpr int FEFP_PPR = 16;                 // points per tangent round
+constexpr int FEFP_PPR = 32;                 // points per tangent round
 constexpr int FEFP_NCOEF = 54;               // staged doubles per point
 constexpr int FEFP_STAGE = 64 * 9;           // F in / PK1 out staging (doubles per wave)
 constexpr int FEFP_LDS_PER_WAVE = FEFP_STAGE + FEFP_PPR * FEFP_NCOEF;
@@ -186,12 +186,13 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       const double tol1 = (prm.tol / fabs(prm.sig0)) * fmax(fabs(prm.sig0), SQ32 * mu * atr);
       unsigned iters = 0;
       for (int it = 0;; ++it) {
-        const double aa = SQ23 * voce_R(prm, p_n + dp) / mu;
+        const double ex = exp(-prm.h2 * (p_n + dp));
+        const double aa = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - ex)) / mu;
         const double r1 = atr - aa - SQ6 * dp * Ie;
         const double r2 = Ie * Ie * Ie - 0.5 * aa * aa * Ie + aa * aa * aa * delta - 1.0;
         if (fabs(SQ32 * mu * r1) <= tol1 && fabs(r2) <= 1e-14) break;
         if (it >= prm.maxit) { if (valid) ++c_notconv; break; }
-        const double ap = SQ23 * voce_dR(prm, p_n + dp) / mu;
+        const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * ex) / mu;
         const double j11 = -ap - SQ6 * Ie;
         const double j12 = -SQ6 * dp;
         const double j21 = (-aa * Ie + 3.0 * aa * aa * delta) * ap;
@@ -202,8 +203,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         ++iters;
       }
       const double p_new = p_n + dp;
-      a = SQ23 * voce_R(prm, p_new) / mu;
-      const double ap = SQ23 * voce_dR(prm, p_new) / mu;
+      const double exn = exp(-prm.h2 * p_new);
+      a = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exn)) / mu;
+      const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * exn) / mu;
       theta = a * iatr;
 #pragma unroll
       for (int k = 0; k < 9; ++k) sdev[k] = a * sh[k];
