@@ -1,0 +1,34 @@
+"""GPU: the engine inside a real global Newton loop (stand-in FE driver of examples/, the 3-D
+analogue of the reference's tests/uniaxial_tension.py driver; BASELINE.json configs[4])."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+
+def test_uniaxial_tension_3d_j2_closed_form_and_quadratic_convergence():
+    from uniaxial_tension_3d import run
+
+    out = run(n=6, steps=8, law="j2_linear", verbose=False)
+    h = out["history"][-1]
+    expect = (out["sig0"] + out["H"] * h["exx"]) / (1 + out["H"] / out["E"])
+    assert abs(h["sxx"] - expect) < 1e-8 * expect and h["sxx_spread"] < 1e-6
+    assert abs(h["p"] - (h["exx"] - expect / out["E"])) < 1e-10
+    for step in out["history"]:
+        assert step["iters"] <= 6 and step["norms"][-1] < 1e-6 * step["norms"][0]
+
+
+def test_uniaxial_tension_3d_fefp_runs_and_saturates():
+    from uniaxial_tension_3d import run
+
+    out = run(n=4, steps=10, law="fefp", exx_max=5e-2, verbose=False)
+    for step in out["history"]:
+        assert step["iters"] <= 8
+    h = out["history"][-1]
+    # homogeneous uniaxial Kirchhoff stress tau_xx = R(p); PK1_xx = tau_xx / F_xx
+    R = 250.0 + 250.0 * (1 - np.exp(-100.0 * h["p"]))
+    assert abs(h["sxx"] * (1 + h["exx"]) - R) < 1e-6 * R and h["sxx_spread"] < 1e-6
