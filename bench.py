@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--points", type=int, default=10_000_000, help="Gauss points per GPU")
+    ap.add_argument("--law", choices=["j2_linear", "j2_voce"], default="j2_linear",
+                    help="j2_voce + --points 12500000 is cfg 3 (sig0=350, sigu=500, b=1e3); the default is cfg 2")
     ap.add_argument("--gather-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -131,6 +133,9 @@ def main():
     n = args.points
     K, W = args.steps, args.warmup
     seed = 1234 + rank
+    global SIG0
+    if args.law == "j2_voce":
+        SIG0 = 350.0  # demos/jax/elastoplasticity/plane_elastoplasticity.py:60-71
     hist = history(n, seed)
     eps = [torch.from_numpy(h).to(dev) for h in hist]
     del hist
@@ -139,10 +144,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def make():
-        m = JAXMaterial(
-            jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)),
-            device=dev_index,
-        )
+        hard = jm.LinearHardening(SIG0, H) if args.law == "j2_linear" else jm.VoceHardening(350.0, 500.0, 1e3)
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard), device=dev_index)
         m.set_data_manager(n)
         return m
 
@@ -229,7 +232,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 t = json.load(open(tfile))
-                if t.get("points") == n and t.get("law") == "j2_linear":
+                if t.get("points") == n and t.get("law") == args.law:
                     traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -247,11 +250,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "cfg2: J2 von-Mises plasticity, linear isotropic hardening, small strain, "
-                f"{n:.3g} Gauss points per GPU, stress + 6x6 consistent tangent, load/unload history increments 2-4",
+                "workload": ("cfg2: J2 von-Mises plasticity, linear isotropic hardening, small strain, "
+                             if args.law == "j2_linear" else
+                             "cfg3: J2 von-Mises plasticity, Voce hardening (sig0=350, sigu=500, b=1e3), small strain, ")
+                + f"{n:.3g} Gauss points per GPU, stress + 6x6 consistent tangent, load/unload history increments 2-4",
                 "points_per_gpu": n,
-                "law": "j2_linear",
-                "E": E, "nu": NU, "sig0": SIG0, "H": H,
+                "law": args.law,
+                "E": E, "nu": NU, "sig0": SIG0, "H": H if args.law == "j2_linear" else None,
                 "plastic_fraction_inc2_3_4": [round(x, 4) for x in plastic_frac],
                 "layout": "AoS (N,6)/(N,36) boundary arrays in HBM, SoA resident state",
                 "sharding": "independent contiguous point blocks, no data-path collective",
@@ -270,7 +275,7 @@ def main():
         }
         if gather is not None:
             out["gather_inclusive"] = gather
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.law == "j2_linear":
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), seed)
         print(json.dumps(out), flush=True)
 

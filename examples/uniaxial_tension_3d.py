@@ -43,6 +43,10 @@ def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True):
         evaluator = lambda cells: mesh.deformation_gradient(u, cells)  # noqa: E731
     qmap = QuadratureFieldMap(mesh.num_cells, mesh.nqp, material)
     qmap.register_gradient(gname, evaluator)
+    # first call at u = 0, as the reference demos do (plane_elastoplasticity.py:146-149,
+    # finite_strain_elastoplasticity.py:181-184): QuadratureMap.initialize_state records the
+    # *current* gradient as the initial one, which must be F = I for the FeFp law
+    qmap.update()
 
     x0, x1 = mesh.nodes_on(0, 0.0), mesh.nodes_on(0, 1.0)
     y0, z0 = mesh.nodes_on(1, 0.0), mesh.nodes_on(2, 0.0)
