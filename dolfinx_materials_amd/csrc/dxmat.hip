@@ -258,8 +258,19 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
       case DXM_LAW_J2_VOCE: fn = (const void*)small_strain_kernel<LAW_J2_VOCE, false>; break;
       default: fn = (const void*)fefp_kernel; break;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, BLOCK, 0) == hipSuccess && occ > 0)
+    // residency from the kernel's own resources (the occupancy API over-reports on ROCm 7.2):
+    // waves/SIMD by allocated VGPRs (512-entry file, granule 8), workgroups by LDS (160 KiB/CU)
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
+      const int alloc = ((fa.numRegs + 7) / 8) * 8;
+      int waves_simd = 512 / alloc;
+      if (waves_simd > 8) waves_simd = 8;
+      int by_vgpr = waves_simd * 4 / WAVES_PER_BLOCK;
+      int by_lds = fa.sharedSizeBytes > 0 ? (int)(160 * 1024 / fa.sharedSizeBytes) : 8;
+      occ = by_vgpr < by_lds ? by_vgpr : by_lds;
+      if (occ < 1) occ = 1;
       m->blocks_per_cu = occ;
+    }
     if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : m->blocks_per_cu;
     if (m->blocks_per_cu > 16) m->blocks_per_cu = 16;
   }

@@ -91,6 +91,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
   unsigned long long c_plastic = 0, c_notconv = 0, c_nan = 0, c_maxit = 0;
 
   const double mu = prm.mu, kappa = prm.kappa;
+  const double imu = 1.0 / mu;
   const double SQ32 = 1.2247448713915890491;   // sqrt(3/2)
   const double SQ23 = 0.81649658092772603273;  // sqrt(2/3)
   const double SQ6 = 2.4494897427831780982;    // sqrt(6)
@@ -164,7 +165,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     for (int k = 0; k < 9; ++k) h[k] *= Jm23;
     double d[9];  // be_bar_trial = F h, then its deviator
     mm(F, h, d);
-    const double Itr = (d[0] + d[4] + d[8]) / 3.0;
+    const double Itr = (d[0] + d[4] + d[8]) / 3.0;  // exact for F = I (zero stress)
     d[0] -= Itr; d[4] -= Itr; d[8] -= Itr;
     double atr2 = 0.0;
 #pragma unroll
@@ -187,12 +188,12 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       unsigned iters = 0;
       for (int it = 0;; ++it) {
         const double ex = exp(-prm.h2 * (p_n + dp));
-        const double aa = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - ex)) / mu;
+        const double aa = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - ex)) * imu;
         const double r1 = atr - aa - SQ6 * dp * Ie;
         const double r2 = Ie * Ie * Ie - 0.5 * aa * aa * Ie + aa * aa * aa * delta - 1.0;
         if (fabs(SQ32 * mu * r1) <= tol1 && fabs(r2) <= 1e-14) break;
         if (it >= prm.maxit) { if (valid) ++c_notconv; break; }
-        const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * ex) / mu;
+        const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * ex) * imu;
         const double j11 = -ap - SQ6 * Ie;
         const double j12 = -SQ6 * dp;
         const double j21 = (-aa * Ie + 3.0 * aa * aa * delta) * ap;
@@ -204,15 +205,15 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       }
       const double p_new = p_n + dp;
       const double exn = exp(-prm.h2 * p_new);
-      a = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exn)) / mu;
-      const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * exn) / mu;
+      a = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exn)) * imu;
+      const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * exn) * imu;
       theta = a * iatr;
 #pragma unroll
       for (int k = 0; k < 9; ++k) sdev[k] = a * sh[k];
       // implicit differentiation of (r1, r2) = 0 with respect to (atr, delta)
-      const double gI = 3.0 * Ie * Ie - 0.5 * a * a;
-      const double dIe_da = (a * Ie - 3.0 * a * a * delta) / gI;
-      const double dIe_dd = -(a * a * a) / gI;
+      const double igI = 1.0 / (3.0 * Ie * Ie - 0.5 * a * a);
+      const double dIe_da = (a * Ie - 3.0 * a * a * delta) * igI;
+      const double dIe_dd = -(a * a * a) * igI;
       const double r_dp = -ap - SQ6 * Ie - SQ6 * dp * dIe_da * ap;
       const double r_dd = -SQ6 * dp * dIe_dd;
       double cs[9], hs[9], hc[9];

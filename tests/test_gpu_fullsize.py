@@ -1,0 +1,71 @@
+"""GPU, BASELINE.json full size (1e7 points, device-resident path used by bench.py): a strided
+sample of the batch is checked against the oracle, the rest through size-independent properties
+(tangent symmetry, monotone p, elastic unloading is linear, checksums stable across repeats)."""
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from dolfinx_materials_amd.jaxmat import JAXMaterial
+from oracle import constitutive_np as onp
+
+from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, eps_yield
+
+pytestmark = pytest.mark.gpu
+N = 10_000_000
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+def test_j2_full_size_device_path(kind):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    if kind == "linear":
+        hard_d, hard_o = jm.LinearHardening(SIG0_LIN, H_LIN), onp.LinearHardening(SIG0_LIN, H_LIN)
+    else:
+        hard_d, hard_o = jm.VoceHardening(SIG0_V, SIGU_V, B_V), onp.VoceHardening(SIG0_V, SIGU_V, B_V)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    d = torch.randn((N, 6), generator=g, device=dev, dtype=torch.float64)
+    d /= d.norm(dim=1, keepdim=True)
+    s = torch.rand((N, 1), generator=g, device=dev, dtype=torch.float64) * 4.0 * eps_yield(hard_o.sig0)
+    eps_hat = d * s
+    del d, s
+    mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard_d))
+    mat.set_data_manager(N)
+    sig = torch.empty((N, 6), dtype=torch.float64, device=dev)
+    ct = torch.empty((N, 36), dtype=torch.float64, device=dev)
+    isv = torch.empty((N, 7), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    idx = torch.arange(0, N, 9973, device=dev)
+    idx = torch.cat([idx, torch.tensor([N - 1, N - 2, N - 63, N - 64, N - 65], device=dev)])
+    eps_s = eps_hat[idx].cpu().numpy()
+    epsp, p = np.zeros((len(idx), 6)), np.zeros(len(idx))
+    p_prev = torch.zeros(N, dtype=torch.float64, device=dev)
+    for k, fac in enumerate([1 / 3, 2 / 3, 1.0, 0.5]):
+        eps = eps_hat * fac
+        mat.integrate_device(eps.data_ptr(), sig.data_ptr(), ct.data_ptr(), st)
+        mat.isv_device(1, isv.data_ptr(), st)
+        rc, stats = mat.stats()
+        assert rc == 0 and stats["n_nan"] == 0 and stats["n_points"] == N
+        ref = onp.j2_update(eps_s * fac, epsp, p, E, NU, hard_o)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * hard_o.sig0
+        for got, exp in ((sig[idx].cpu().numpy(), ref["sig"]), (ct[idx].cpu().numpy().reshape(-1, 6, 6), ref["Ct"]),
+                         (isv[idx, 0].cpu().numpy(), ref["p"]), (isv[idx, 1:].cpu().numpy(), ref["epsp"])):
+            assert np.abs(got[safe] - exp[safe]).max() <= 1e-12 * max(np.abs(exp).max(), 1e-300)
+        # whole-batch properties
+        c3 = ct.view(N, 6, 6)
+        assert float((c3 - c3.transpose(1, 2)).abs().max()) < 1e-9
+        assert bool((isv[:, 0] >= p_prev - 1e-18).all())
+        frac = stats["n_plastic"] / N
+        assert abs(frac - ref["plastic"].mean()) < 0.05
+        if k == 3:
+            assert stats["n_plastic"] == 0
+            C = torch.from_numpy(onp.elastic_matrix(E, NU)).to(dev)
+            assert float((sig - sig_prev - (eps - eps_prev) @ C.T).abs().max()) < 1e-9 * float(sig_prev.abs().max())
+        # a repeated update from the same s0 is bit-identical (no cross-point interference)
+        chk = (float(sig.sum()), float(ct.sum()))
+        mat.integrate_device(eps.data_ptr(), sig.data_ptr(), ct.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert chk == (float(sig.sum()), float(ct.sum()))
+        p_prev = isv[:, 0].clone()
+        sig_prev, eps_prev = sig.clone(), eps
+        mat.data_manager.update()
+        epsp, p = ref["epsp"], ref["p"]
