@@ -273,3 +273,17 @@ def test_fefp_self_golden_reference_smoke_path():
         assert np.allclose(r["P"], g["P"][k], rtol=1e-12, atol=1e-9)
         assert np.allclose(r["p"], g["p"][k], rtol=1e-11, atol=1e-18)
         cp, p = r["cpinv"], r["p"]
+
+
+def test_fefp_c_oracle_equals_numpy_oracle():
+    n = 257
+    st = onp.fefp_initial_state(n)
+    cp, p = st["cpinv"], st["p"]
+    for k, F in enumerate(fefp_path(n)):
+        r = onp.fefp_update(F, cp, p, E, NU, HARD_F)
+        c = oracle_c.fefp(F, cp, p, E, NU, SIG0_F, SIGU_F, B_F, nthreads=2)
+        safe = np.abs(r["f_trial"]) > 1e-9 * SIG0_F
+        for key in ("P", "Ct", "be_bar", "cpinv", "p"):
+            assert np.abs(c[key][safe] - r[key][safe]).max() <= 1e-12 * max(np.abs(r[key]).max(), 1e-300), (k, key)
+        assert c["n_not_converged"] == 0
+        cp, p = r["cpinv"], r["p"]

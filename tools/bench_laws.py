@@ -16,11 +16,49 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def cpu_port(law, ns, budget=4.0):
+    """Plain-C oracle (oracle/oracle_c.c) on the host cores: best of a small thread-count scan."""
+    import time
+
+    from oracle import oracle_c as oc
+    from oracle import constitutive_np as onp
+    from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, SIG0_F, SIGU_F, B_F, j2_history, fefp_path
+
+    if law == "fefp":
+        path = fefp_path(ns)
+        st = onp.fefp_initial_state(ns)
+        r0 = oc.fefp(path[9], st["cpinv"], st["p"], E, NU, SIG0_F, SIGU_F, B_F, nthreads=8)
+        cp, p = r0["cpinv"].copy(), r0["p"].copy()
+        fn = lambda nt: oc.fefp(path[18], cp, p, E, NU, SIG0_F, SIGU_F, B_F, nthreads=nt, out=r0)  # noqa: E731
+    elif law == "elastic":
+        eps = j2_history(ns)[2]
+        fn = lambda nt: oc.elastic_iso(eps, E, NU, nthreads=nt)  # noqa: E731
+    else:
+        kind, s0, h1, h2 = (0, SIG0_LIN, H_LIN, 0.0) if law == "j2_linear" else (1, SIG0_V, SIGU_V, B_V)
+        h = j2_history(ns, sig0=s0)
+        r0 = oc.j2(h[1], np.zeros((ns, 6)), np.zeros(ns), E, NU, kind, s0, h1, h2, nthreads=8)
+        ep, p = r0["epsp"].copy(), r0["p"].copy()
+        fn = lambda nt: oc.j2(h[2], ep, p, E, NU, kind, s0, h1, h2, nthreads=nt, out=r0)  # noqa: E731
+    ncpu = os.cpu_count() or 1
+    best = (0.0, 1)
+    for nt in sorted({t for t in (1, 8, 16, 32, 64) if t <= ncpu}):
+        fn(nt)
+        t0, calls = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget / 5 or calls < 2:
+            fn(nt)
+            calls += 1
+        rate = ns * calls / (time.perf_counter() - t0) / 1e6
+        if rate > best[0]:
+            best = (rate, nt)
+    return {"Mpoints_per_s": round(best[0], 2), "threads": best[1], "sample": ns, "kind": "port (oracle/oracle_c.c)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--laws", nargs="+", default=["elastic", "j2_linear", "j2_voce", "fefp"])
+    ap.add_argument("--cpu-sample", type=int, default=0, help="also time the plain-C oracle on this many points")
     a = ap.parse_args()
     import torch
 
@@ -69,6 +107,8 @@ def main():
             "plastic_fraction": round(stats["n_plastic"] / n, 4), "max_local_iters": stats["max_local_iters"],
             "not_converged": stats["n_not_converged"], "rc": rc,
         }
+        if a.cpu_sample:
+            r["cpu_port"] = cpu_port(law, a.cpu_sample)
         print(json.dumps(r), flush=True)
         res.append(r)
         del m, g, flux, ct
