@@ -80,6 +80,14 @@ SYMBOLS = {
     "dxm_isv_device": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_void_p]),
     "dxm_state_ptr": (C.c_void_p, [_h, C.c_int, C.c_int, C.c_int]),
     "dxm_kernel_name": (C.c_char_p, [_h]),
+    "dxm_mesh_create_hex8": (_h, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
+    "dxm_mesh_destroy": (C.c_int, [_h]),
+    "dxm_mesh_npoints": (C.c_int64, [_h]),
+    "dxm_mesh_gradient_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dxm_integrate_displacement": (
+        C.c_int,
+        [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],
+    ),
 }
 
 _lib = None

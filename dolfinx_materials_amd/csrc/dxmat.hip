@@ -18,6 +18,7 @@
 #include "../../include/dxmat.h"
 #include "dxm_common.hpp"
 #include "fefp.hpp"
+#include "gradient.hpp"
 #include "small_strain.hpp"
 
 using namespace dxm;
@@ -43,6 +44,24 @@ static int fail(int code, const char* fmt, ...) {
     if (_e != hipSuccess)                                                                  \
       return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
+
+// Selects the handle's device for the duration of a call and restores the caller's current
+// device afterwards (the host application, e.g. torch, owns the thread's current device).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = (hipSetDevice(device) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+#define DEVICE_GUARD(m)                                                        \
+  DeviceGuard _guard((m)->device);                                             \
+  if (!_guard.ok) return fail(-2, "hipSetDevice(%d) failed", (m)->device)
 
 // ------------------------------------------------------------------------------------------
 // law descriptors
@@ -233,7 +252,8 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   if (const char* s = getenv("DXM_NT_STORE")) m->nt_store = atoi(s) != 0;
   auto bail = [&](void) -> dxm_material* { dxm_destroy(m); return nullptr; };
   if (build_params(m, params, n_params) != 0) return bail();
-  if (hipSetDevice(device) != hipSuccess) { fail(-2, "hipSetDevice(%d) failed", device); return bail(); }
+  DeviceGuard guard(device);
+  if (!guard.ok) { fail(-2, "hipSetDevice(%d) failed", device); return bail(); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -285,8 +305,8 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
 
 int dxm_destroy(dxm_material* m) {
   if (!m) return 0;
-  (void)hipSetDevice(m->device);
-  if (m->launched && m->last_stream) (void)hipStreamSynchronize(m->last_stream);
+  DeviceGuard guard(m->device);
+  if (m->launched) (void)hipStreamSynchronize(m->last_stream);
   if (m->state_base) (void)hipFree(m->state_base);
   if (m->d_stats) (void)hipFree(m->d_stats);
   if (m->d_grad) (void)hipFree(m->d_grad);
@@ -348,7 +368,7 @@ static int materialize_s1(dxm_material* m) {
 int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos) {
   if (int rc = check_field(m, which, field)) return rc;
   if (!host_aos) return fail(-1, "null host pointer");
-  HIP_TRY(hipSetDevice(m->device));
+  DEVICE_GUARD(m);
   if (int rc = sync_last(m)) return rc;
   const LawDesc& d = kLaws[m->law];
   const int dim = d.isv_dim[field];
@@ -367,7 +387,7 @@ int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos)
 int dxm_get_state(dxm_material* m, int which, int field, double* host_aos) {
   if (int rc = check_field(m, which, field)) return rc;
   if (!host_aos) return fail(-1, "null host pointer");
-  HIP_TRY(hipSetDevice(m->device));
+  DEVICE_GUARD(m);
   if (int rc = sync_last(m)) return rc;
   const LawDesc& d = kLaws[m->law];
   const int dim = d.isv_dim[field];
@@ -451,7 +471,7 @@ int dxm_integrate_device(dxm_material* m, const double* grad_dev, double dt, dou
   (void)dt;  // rate-independent laws; QuadratureMap never forwards dt (quadrature_map.py:321)
   if (!m) return fail(-1, "null handle");
   if (m->n > 0 && (!grad_dev || !flux_dev || !ct_dev)) return fail(-1, "null device pointer");
-  HIP_TRY(hipSetDevice(m->device));
+  DEVICE_GUARD(m);
   return launch(m, grad_dev, flux_dev, ct_dev, (hipStream_t)hip_stream);
 }
 
@@ -460,7 +480,7 @@ int dxm_get_stats(dxm_material* m, dxm_stats* stats) {
   dxm_stats s{};
   s.n_points = m->n;
   if (m->launched && m->last_grid > 0) {
-    HIP_TRY(hipSetDevice(m->device));
+    DEVICE_GUARD(m);
     std::vector<BlockStats> h(m->last_grid);
     HIP_TRY(hipMemcpyAsync(h.data(), m->d_stats, sizeof(BlockStats) * m->last_grid,
                            hipMemcpyDeviceToHost, m->last_stream));
@@ -485,7 +505,7 @@ int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_st
   const int total = isv_total(d);
   if (total == 0 || m->n == 0) return 0;
   if (!isv_aos_dev) return fail(-1, "null device pointer");
-  HIP_TRY(hipSetDevice(m->device));
+  DEVICE_GUARD(m);
   PackMap map{};
   map.n = total;
   int k = 0;
@@ -499,17 +519,9 @@ int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_st
   return 0;
 }
 
-int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
-                  double* isv_aos, double* ct_aos, dxm_stats* stats) {
-  if (!m) return fail(-1, "null handle");
+static int ensure_host_path_buffers(dxm_material* m) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
-  if (n == 0) {
-    if (stats) memset(stats, 0, sizeof(*stats));
-    return 0;
-  }
-  if (!grad_aos) return fail(-1, "null gradient pointer");
-  HIP_TRY(hipSetDevice(m->device));
   const int total = isv_total(d);
   if (!m->d_grad) {
     HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * n * d.n_grad));
@@ -517,11 +529,17 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
     HIP_TRY(hipMalloc(&m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad));
     if (total > 0) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * n * total));
   }
+  return 0;
+}
+
+// constitutive kernel on m->d_grad, then the requested downloads; synchronises own_stream
+static int run_and_download(dxm_material* m, double* flux_aos, double* isv_aos, double* ct_aos,
+                            dxm_stats* stats) {
+  const LawDesc& d = kLaws[m->law];
+  const int64_t n = m->n;
+  const int total = isv_total(d);
   hipStream_t st = m->own_stream;
-  if (m->launched && m->last_stream != st) HIP_TRY(hipStreamSynchronize(m->last_stream));
-  HIP_TRY(hipMemcpyAsync(m->d_grad, grad_aos, sizeof(double) * n * d.n_grad, hipMemcpyHostToDevice, st));
   if (int rc = launch(m, m->d_grad, m->d_flux, m->d_ct, st)) return rc;
-  (void)dt;
   if (flux_aos)
     HIP_TRY(hipMemcpyAsync(flux_aos, m->d_flux, sizeof(double) * n * d.n_flux, hipMemcpyDeviceToHost, st));
   if (isv_aos && total > 0) {
@@ -532,6 +550,116 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
     HIP_TRY(hipMemcpyAsync(ct_aos, m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad,
                            hipMemcpyDeviceToHost, st));
   return dxm_get_stats(m, stats);  // synchronises st
+}
+
+int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
+                  double* isv_aos, double* ct_aos, dxm_stats* stats) {
+  (void)dt;
+  if (!m) return fail(-1, "null handle");
+  const LawDesc& d = kLaws[m->law];
+  const int64_t n = m->n;
+  if (n == 0) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    return 0;
+  }
+  if (!grad_aos) return fail(-1, "null gradient pointer");
+  DEVICE_GUARD(m);
+  if (int rc = ensure_host_path_buffers(m)) return rc;
+  hipStream_t st = m->own_stream;
+  if (m->launched && m->last_stream != st) HIP_TRY(hipStreamSynchronize(m->last_stream));
+  HIP_TRY(hipMemcpyAsync(m->d_grad, grad_aos, sizeof(double) * n * d.n_grad, hipMemcpyHostToDevice, st));
+  return run_and_download(m, flux_aos, isv_aos, ct_aos, stats);
+}
+
+// ---- gradient evaluation on device ----------------------------------------------------------
+struct dxm_mesh {
+  int device = 0;
+  int64_t n_nodes = 0, n_cells = 0;
+  QuadPoints qp{};
+  double* d_coords = nullptr;
+  int32_t* d_conn = nullptr;
+  double* d_u = nullptr;
+};
+
+dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int32_t* conn,
+                               int64_t n_cells, const double* qpoints, int nqp, int device) {
+  if (!coords || !conn || !qpoints || n_nodes <= 0 || n_cells <= 0 || nqp <= 0 || nqp > 27) {
+    fail(-1, "invalid mesh arguments");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    fail(-2, "no usable HIP device %d (libdxmat has no CPU fallback)", device);
+    return nullptr;
+  }
+  for (int64_t k = 0; k < n_cells * 8; ++k)
+    if (conn[k] < 0 || conn[k] >= n_nodes) { fail(-1, "connectivity entry %lld out of range", (long long)k); return nullptr; }
+  dxm_mesh* mesh = new dxm_mesh();
+  mesh->device = device;
+  mesh->n_nodes = n_nodes;
+  mesh->n_cells = n_cells;
+  mesh->qp.nqp = nqp;
+  for (int q = 0; q < nqp; ++q)
+    for (int d = 0; d < 3; ++d) mesh->qp.xi[q][d] = qpoints[3 * q + d];
+  DeviceGuard guard(device);
+  bool ok = guard.ok;
+  ok = ok && hipMalloc(&mesh->d_coords, sizeof(double) * 3 * n_nodes) == hipSuccess;
+  ok = ok && hipMalloc(&mesh->d_conn, sizeof(int32_t) * 8 * n_cells) == hipSuccess;
+  ok = ok && hipMalloc(&mesh->d_u, sizeof(double) * 3 * n_nodes) == hipSuccess;
+  ok = ok && hipMemcpy(mesh->d_coords, coords, sizeof(double) * 3 * n_nodes, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(mesh->d_conn, conn, sizeof(int32_t) * 8 * n_cells, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    fail(-3, "device allocation / upload of the mesh failed");
+    dxm_mesh_destroy(mesh);
+    return nullptr;
+  }
+  return mesh;
+}
+
+int dxm_mesh_destroy(dxm_mesh* mesh) {
+  if (!mesh) return 0;
+  DeviceGuard guard(mesh->device);
+  if (mesh->d_coords) (void)hipFree(mesh->d_coords);
+  if (mesh->d_conn) (void)hipFree(mesh->d_conn);
+  if (mesh->d_u) (void)hipFree(mesh->d_u);
+  delete mesh;
+  return 0;
+}
+
+int64_t dxm_mesh_npoints(const dxm_mesh* mesh) { return mesh ? mesh->n_cells * mesh->qp.nqp : -1; }
+
+int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, double* grad_dev,
+                             void* hip_stream) {
+  if (!mesh || !u_dev || !grad_dev) return fail(-1, "null argument");
+  if (kind != 0 && kind != 1) return fail(-1, "gradient kind must be 0 (strain) or 1 (F)");
+  DEVICE_GUARD(mesh);
+  const int64_t npts = mesh->n_cells * mesh->qp.nqp;
+  const int blocks = (int)((npts + 255) / 256);
+  if (kind == 0)
+    hipLaunchKernelGGL(hex8_gradient_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
+                       mesh->d_coords, mesh->d_conn, u_dev, mesh->n_cells, mesh->qp, grad_dev);
+  else
+    hipLaunchKernelGGL(hex8_gradient_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
+                       mesh->d_coords, mesh->d_conn, u_dev, mesh->n_cells, mesh->qp, grad_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
+                               double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats) {
+  (void)dt;
+  if (!m || !mesh || !u_host) return fail(-1, "null argument");
+  if (mesh->device != m->device) return fail(-1, "mesh and material live on different devices");
+  if (dxm_mesh_npoints(mesh) != m->n) return fail(-1, "mesh has %lld Gauss points, material %lld",
+                                                   (long long)dxm_mesh_npoints(mesh), (long long)m->n);
+  DEVICE_GUARD(m);
+  if (int rc = ensure_host_path_buffers(m)) return rc;
+  hipStream_t st = m->own_stream;
+  if (m->launched && m->last_stream != st) HIP_TRY(hipStreamSynchronize(m->last_stream));
+  HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * 3 * mesh->n_nodes, hipMemcpyHostToDevice, st));
+  const int kind = kLaws[m->law].n_grad == 9 ? 1 : 0;
+  if (int rc = dxm_mesh_gradient_device(mesh, mesh->d_u, kind, m->d_grad, st)) return rc;
+  return run_and_download(m, flux_aos, isv_aos, ct_aos, stats);
 }
 
 const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp) {

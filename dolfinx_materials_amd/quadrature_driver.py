@@ -66,6 +66,7 @@ class QuadratureFieldMap:
         }
         self.gradients = {}
         self._grad_eval = {}
+        self._device_gradient = None
         self.set_data_manager(self.cells)
         self._initialized = False
 
@@ -90,6 +91,14 @@ class QuadratureFieldMap:
             raise ValueError(f"Gradient '{name}' is not available from the material law.")
         self.gradients[name] = ArrayFunction(name, self.material.gradients[name], self.num_cells_total * self.nqp)
         self._grad_eval[name] = evaluator
+
+    def register_device_gradient(self, mesh, displacement):
+        """Evaluate the gradient on the GPU (``gradient.Hex8Mesh``) from ``displacement()`` instead
+        of on the host: only the displacement vector is uploaded per update.  Needs a map over all
+        cells in mesh order (point = cell * nqp + q)."""
+        if len(self.cells) != self.num_cells_total or mesh.npoints != len(self.dofs):
+            raise ValueError("device gradient evaluation needs a map over all cells of the mesh")
+        self._device_gradient = (mesh, displacement)
 
     def get_gradient_vals(self, name, cells):
         fun = self.gradients[name]
@@ -122,10 +131,14 @@ class QuadratureFieldMap:
     def update(self):
         if not self._initialized:
             self.initialize_state()
-        grad_vals = np.concatenate(
-            [self.get_gradient_vals(name, self.cells) for name in self.material.gradients.keys()], axis=1
-        )
-        flux_vals, isv_vals, Ct_vals = self.material.integrate(grad_vals)
+        if self._device_gradient is not None:
+            mesh, displacement = self._device_gradient
+            flux_vals, isv_vals, Ct_vals = self.material.integrate_displacement(mesh, displacement())
+        else:
+            grad_vals = np.concatenate(
+                [self.get_gradient_vals(name, self.cells) for name in self.material.gradients.keys()], axis=1
+            )
+            flux_vals, isv_vals, Ct_vals = self.material.integrate(grad_vals)
         # the reference makes three full np.isnan passes here (quadrature_map.py:322-324); the
         # engine reports the same condition from the device
         stats = getattr(self.material, "last_stats", None)

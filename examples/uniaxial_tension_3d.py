@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 from hex_fem import HexMesh, newton_solve  # noqa: E402
 
 
-def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True):
+def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True, device_gradient=False):
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
     from dolfinx_materials_amd.quadrature_driver import QuadratureFieldMap
@@ -43,6 +43,10 @@ def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True):
         evaluator = lambda cells: mesh.deformation_gradient(u, cells)  # noqa: E731
     qmap = QuadratureFieldMap(mesh.num_cells, mesh.nqp, material)
     qmap.register_gradient(gname, evaluator)
+    if device_gradient:  # strain / F evaluated on the GPU from u: only u is uploaded per update
+        from dolfinx_materials_amd.gradient import Hex8Mesh
+
+        qmap.register_device_gradient(Hex8Mesh(mesh.coords, mesh.conn), lambda: u)
     # first call at u = 0, as the reference demos do (plane_elastoplasticity.py:146-149,
     # finite_strain_elastoplasticity.py:181-184): QuadratureMap.initialize_state records the
     # *current* gradient as the initial one, which must be F = I for the FeFp law
@@ -71,8 +75,9 @@ if __name__ == "__main__":
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--law", default="j2_linear")
+    ap.add_argument("--device-gradient", action="store_true")
     a = ap.parse_args()
-    out = run(a.n, a.steps, a.law)
+    out = run(a.n, a.steps, a.law, device_gradient=a.device_gradient)
     h = out["history"][-1]
     if a.law == "j2_linear":
         # homogeneous uniaxial stress: sigma_xx = sig0 + H p and eps_xx = sigma_xx / E + p

@@ -145,6 +145,28 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
 /* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
 const char* dxm_kernel_name(const dxm_material* m);
 
+/* ---- gradient evaluation on device (the step before the path; first-order hexahedra) ---------
+ * Replaces, for the device-resident flow, QuadratureExpression.eval -> fem.Expression.eval
+ * (quadrature_function.py:45-51; consumer quadrature_map.py:247-253): only the displacement
+ * vector crosses PCIe, the (npoints, n_grad) gradient array is produced in HBM in the layout
+ * the constitutive kernels read (point = cell * nqp + q). */
+typedef struct dxm_mesh dxm_mesh; /* opaque: device copies of coordinates and connectivity */
+/* coords (n_nodes,3) fp64, conn (n_cells,8) int32 with the corner order
+ * (-,-,-)(+,-,-)(+,+,-)(-,+,-)(-,-,+)(+,-,+)(+,+,+)(-,+,+); qpoints (nqp,3) in [-1,1]^3, nqp <= 27. */
+dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int32_t* conn,
+                               int64_t n_cells, const double* qpoints, int nqp, int device);
+int dxm_mesh_destroy(dxm_mesh* mesh);
+int64_t dxm_mesh_npoints(const dxm_mesh* mesh);
+/* kind 0: Mandel strain (6); kind 1: deformation gradient F = I + grad u (9).  u_dev: device
+ * (n_nodes*3); grad_dev: device (npoints, 6|9).  Asynchronous on hip_stream. */
+int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, double* grad_dev,
+                             void* hip_stream);
+/* dxm_integrate with the gradient computed on the device from the host displacement vector
+ * u_host (n_nodes*3): uploads u, evaluates the law's gradient, runs the constitutive update,
+ * downloads flux / isv / tangent (any may be NULL).  mesh npoints must equal the handle's. */
+int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
+                               double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,3 +32,15 @@ def test_uniaxial_tension_3d_fefp_runs_and_saturates():
     # homogeneous uniaxial Kirchhoff stress tau_xx = R(p); PK1_xx = tau_xx / F_xx
     R = 250.0 + 250.0 * (1 - np.exp(-100.0 * h["p"]))
     assert abs(h["sxx"] * (1 + h["exx"]) - R) < 1e-6 * R and h["sxx_spread"] < 1e-6
+
+
+def test_device_gradient_run_equals_host_gradient_run():
+    """f3 of SURVEY.md section 8: the gradient evaluated on the GPU from the displacement vector gives
+    the same Newton history as the host evaluation."""
+    from uniaxial_tension_3d import run
+
+    a = run(n=4, steps=4, law="j2_linear", verbose=False)
+    b = run(n=4, steps=4, law="j2_linear", verbose=False, device_gradient=True)
+    for sa, sb in zip(a["history"], b["history"]):
+        assert sa["iters"] == sb["iters"]
+        assert abs(sa["sxx"] - sb["sxx"]) < 1e-9 * abs(sa["sxx"]) and abs(sa["p"] - sb["p"]) < 1e-12
