@@ -80,6 +80,8 @@ SYMBOLS = {
     "dxm_isv_device": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_void_p]),
     "dxm_state_ptr": (C.c_void_p, [_h, C.c_int, C.c_int, C.c_int]),
     "dxm_kernel_name": (C.c_char_p, [_h]),
+    "dxm_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "dxm_host_free": (C.c_int, [C.c_void_p]),
     "dxm_mesh_create_hex8": (_h, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     "dxm_mesh_destroy": (C.c_int, [_h]),
     "dxm_mesh_npoints": (C.c_int64, [_h]),
@@ -135,6 +137,35 @@ def check(rc: int) -> int:
 def device_count() -> int:
     n = load().dxm_device_count()
     return max(n, 0)
+
+
+class PinnedArray:
+    """A C-contiguous fp64 numpy array in page-locked host memory (``dxm_host_alloc``)."""
+
+    def __init__(self, shape):
+        import numpy as np
+
+        self.shape = tuple(int(s) for s in shape)
+        n = 1
+        for s in self.shape:
+            n *= s
+        self._ptr = load().dxm_host_alloc(8 * max(n, 1))
+        if not self._ptr:
+            raise DxmError(f"dxm_host_alloc failed: {last_error()}")
+        buf = (C.c_double * max(n, 1)).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=np.float64, count=n).reshape(self.shape)
+
+    def free(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            load().dxm_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def law_info(law: int) -> LawInfo:

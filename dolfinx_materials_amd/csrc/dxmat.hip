@@ -571,6 +571,22 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   return run_and_download(m, flux_aos, isv_aos, ct_aos, stats);
 }
 
+void* dxm_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0) bytes = 8;
+  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    fail(-3, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+int dxm_host_free(void* p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return 0;
+}
+
 // ---- gradient evaluation on device ----------------------------------------------------------
 struct dxm_mesh {
   int device = 0;

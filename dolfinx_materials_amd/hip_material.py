@@ -179,8 +179,14 @@ class HIPMaterial:
         # host mirrors of the fields that are not device state (gradient and flux of s0 / s1)
         self._grad = [self._initial_gradient(), self._initial_gradient()]
         self._flux = [np.zeros((self._n, nf)), np.zeros((self._n, nf))]
-        self._out_isv = np.zeros((self._n, nisv))
-        self._out_ct = np.zeros((self._n, nf, ng))
+        # output arrays owned by the material, page-locked so that D2H runs at full PCIe rate
+        self._pinned = [_lib.PinnedArray((self._n, nisv)), _lib.PinnedArray((self._n, nf, ng)),
+                        _lib.PinnedArray((self._n, nf)), _lib.PinnedArray((self._n, nf))]
+        self._out_isv, self._out_ct = self._pinned[0].array, self._pinned[1].array
+        self._out_isv[...] = 0.0
+        self._out_ct[...] = 0.0
+        self._flux_buf = [self._pinned[2].array, self._pinned[3].array]
+        self._flux_next = 0
         self.data_manager = DataManager(self, self._n)
 
     def _initial_gradient(self):
@@ -193,6 +199,9 @@ class HIPMaterial:
         if getattr(self, "_handle", None):
             self._lib.dxm_destroy(self._handle)
             self._handle = None
+        for p in getattr(self, "_pinned", []):
+            p.free()
+        self._pinned = []
 
     def __del__(self):
         try:
@@ -272,7 +281,7 @@ class HIPMaterial:
         g = _as_c(gradients)
         if g.shape != (self._n, ng):
             raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
-        flux = np.empty((self._n, nf))
+        flux = self._next_flux_buffer()
         st = Stats()
         rc = self._lib.dxm_integrate(
             h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)
@@ -287,6 +296,16 @@ class HIPMaterial:
         self._flux[1] = flux
         return flux, self._out_isv, self._out_ct
 
+    def _next_flux_buffer(self):
+        """Two pinned flux buffers alternate so that the s0 mirror (the flux of the last converged
+        increment) is never the one being overwritten."""
+        cand = self._flux_buf[self._flux_next]
+        if cand is self._flux[0]:
+            self._flux_next ^= 1
+            cand = self._flux_buf[self._flux_next]
+        self._flux_next ^= 1
+        return cand
+
     def integrate_displacement(self, mesh, u, dt=0):
         """Same as :meth:`integrate`, with the gradient evaluated on the device from the nodal
         displacement vector ``u`` (``mesh``: :class:`dolfinx_materials_amd.gradient.Hex8Mesh`):
@@ -297,7 +316,7 @@ class HIPMaterial:
         u = _as_c(u).reshape(-1)
         if u.size != 3 * mesh.n_nodes:
             raise ValueError(f"u must have {3 * mesh.n_nodes} entries, got {u.size}")
-        flux = np.empty((self._n, nf))
+        flux = self._next_flux_buffer()
         st = Stats()
         rc = self._lib.dxm_integrate_displacement(
             h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)

@@ -145,6 +145,13 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
 /* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
 const char* dxm_kernel_name(const dxm_material* m);
 
+/* ---- pinned host memory for the host-buffer form --------------------------------------------
+ * integrate() returns arrays owned by the material (the reference returns views of its state
+ * manager: generic.py:185-189); allocating them page-locked lets the D2H copies run at full PCIe
+ * rate without the runtime's staging copy.  Returns NULL on failure. */
+void* dxm_host_alloc(uint64_t bytes);
+int dxm_host_free(void* p);
+
 /* ---- gradient evaluation on device (the step before the path; first-order hexahedra) ---------
  * Replaces, for the device-resident flow, QuadratureExpression.eval -> fem.Expression.eval
  * (quadrature_function.py:45-51; consumer quadrature_map.py:247-253): only the displacement
