@@ -64,6 +64,8 @@ SYMBOLS = {
     "dxm_law": (C.c_int, [_h]),
     "dxm_set_params": (C.c_int, [_h, _dp, C.c_int]),
     "dxm_set_newton": (C.c_int, [_h, C.c_int, C.c_double]),
+    "dxm_set_tangent_layout": (C.c_int, [_h, C.c_int]),
+    "dxm_tangent_size": (C.c_int, [_h]),
     "dxm_set_state": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     "dxm_get_state": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     "dxm_advance": (C.c_int, [_h]),

@@ -64,3 +64,24 @@ def cp_bar_inv_from_be_bar(F9, be_bar6):
     Finv = np.linalg.inv(F)
     G = (J ** (2.0 / 3.0))[..., None, None] * (Finv @ be @ np.swapaxes(Finv, -1, -2))
     return tensor_to_mandel(0.5 * (G + np.swapaxes(G, -1, -2))), tensor_to_mandel(be)
+
+
+#: (i, j) of the 21 entries of the symmetric-packed 6x6 tangent (upper triangle, row-major)
+SYM_IDX = tuple((i, j) for i in range(6) for j in range(i, 6))
+
+
+def pack_sym_tangent(ct):
+    """(N,6,6) symmetric -> (N,21)."""
+    ct = np.asarray(ct, dtype=np.float64).reshape(-1, 6, 6)
+    ii, jj = np.array([p[0] for p in SYM_IDX]), np.array([p[1] for p in SYM_IDX])
+    return ct[:, ii, jj]
+
+
+def unpack_sym_tangent(ct21):
+    """(N,21) -> (N,6,6) symmetric (what ``jacobian_flatten`` of quadrature_map.py:83-105 holds)."""
+    ct21 = np.asarray(ct21, dtype=np.float64).reshape(-1, 21)
+    out = np.empty((ct21.shape[0], 6, 6))
+    for t, (i, j) in enumerate(SYM_IDX):
+        out[:, i, j] = ct21[:, t]
+        out[:, j, i] = ct21[:, t]
+    return out

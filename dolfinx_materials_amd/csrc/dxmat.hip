@@ -90,6 +90,8 @@ static const LawDesc kLaws[DXM_LAW_COUNT] = {
      "fefp_kernel"},
 };
 
+static int tangent_size(const dxm_material* m);
+
 static int isv_total(const LawDesc& d) {
   int t = 0;
   for (int f = 0; f < d.n_isv_fields; ++f) t += d.isv_dim[f];
@@ -120,7 +122,7 @@ struct dxm_material {
   hipStream_t own_stream = nullptr;
   int num_cu = 256;
   int blocks_per_cu = 5;
-  bool nt_store = false;
+  bool sym_tangent = false;  // symmetric-packed (21) tangent instead of the full 6x6 (36)
   // host-path staging (device side), allocated on first dxm_integrate
   double* d_grad = nullptr;
   double* d_flux = nullptr;
@@ -149,6 +151,11 @@ static int build_params(dxm_material* m, const double* p, int np) {
   m->prm = q;
   m->raw_params.assign(p, p + np);
   return 0;
+}
+
+static int tangent_size(const dxm_material* m) {
+  const LawDesc& d = kLaws[m->law];
+  return m->sym_tangent ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -249,7 +256,6 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   m->ld = ((npoints + 255) / 256) * 256 + 32;
   if (const char* s = getenv("DXM_LD_PAD")) m->ld += (atoi(s) / 2) * 2 - 32;   // tuning knob (doubles)
   if (const char* s = getenv("DXM_S1_SKEW")) m->s1_skew = (size_t)atol(s) & ~(size_t)15;  // tuning knob (bytes)
-  if (const char* s = getenv("DXM_NT_STORE")) m->nt_store = atoi(s) != 0;
   auto bail = [&](void) -> dxm_material* { dxm_destroy(m); return nullptr; };
   if (build_params(m, params, n_params) != 0) return bail();
   DeviceGuard guard(device);
@@ -325,6 +331,17 @@ int dxm_set_params(dxm_material* m, const double* params, int n_params) {
   if (!m || !params) return fail(-1, "null argument");
   return build_params(m, params, n_params);
 }
+
+int dxm_set_tangent_layout(dxm_material* m, int layout) {
+  if (!m) return fail(-1, "null handle");
+  if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_SYM) return fail(-1, "unknown tangent layout %d", layout);
+  if (layout == DXM_TANGENT_SYM && m->law == DXM_LAW_FEFP_J2_VOCE)
+    return fail(-1, "the FeFp tangent dP/dF is not symmetric: only DXM_TANGENT_FULL is available");
+  m->sym_tangent = (layout == DXM_TANGENT_SYM);
+  return 0;
+}
+
+int dxm_tangent_size(const dxm_material* m) { return m ? tangent_size(m) : -1; }
 
 int dxm_set_newton(dxm_material* m, int maxit, double rtol) {
   if (!m) return fail(-1, "null handle");
@@ -428,7 +445,7 @@ int dxm_revert(dxm_material* m) {
 template <int LAW>
 static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, const double* grad,
                                 double* flux, double* ct) {
-  if (m->nt_store)
+  if (m->sym_tangent)
     hipLaunchKernelGGL((small_strain_kernel<LAW, true>), dim3(grid), dim3(BLOCK), 0, st, m->prm,
                        m->n, grad, m->state[0], m->state[1], m->ld, flux, ct, m->d_stats);
   else
@@ -526,7 +543,7 @@ static int ensure_host_path_buffers(dxm_material* m) {
   if (!m->d_grad) {
     HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * n * d.n_grad));
     HIP_TRY(hipMalloc(&m->d_flux, sizeof(double) * n * d.n_flux));
-    HIP_TRY(hipMalloc(&m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad));
+    HIP_TRY(hipMalloc(&m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad));  // sized for the full layout
     if (total > 0) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * n * total));
   }
   return 0;
@@ -547,7 +564,7 @@ static int run_and_download(dxm_material* m, double* flux_aos, double* isv_aos, 
     HIP_TRY(hipMemcpyAsync(isv_aos, m->d_isv, sizeof(double) * n * total, hipMemcpyDeviceToHost, st));
   }
   if (ct_aos)
-    HIP_TRY(hipMemcpyAsync(ct_aos, m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad,
+    HIP_TRY(hipMemcpyAsync(ct_aos, m->d_ct, sizeof(double) * n * tangent_size(m),
                            hipMemcpyDeviceToHost, st));
   return dxm_get_stats(m, stats);  // synchronises st
 }

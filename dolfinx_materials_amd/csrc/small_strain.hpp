@@ -18,7 +18,7 @@
 //     (c1, c2, c3, n[6]) in LDS and the whole wave then evaluates
 //         Ct = c1 1x1 + c2 I + c3 n x n
 //     entry by entry in output order, so the dominant 288 B/point stream leaves as contiguous
-//     1 KiB wave stores.
+//     1 KiB wave stores (SYM = true: only the 21 entries of the upper triangle, 168 B/point).
 #pragma once
 #include "dxm_common.hpp"
 
@@ -50,7 +50,7 @@ __device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
   }
 }
 
-template <int LAW, bool NT_STORE>
+template <int LAW, bool SYM>
 __global__ void __launch_bounds__(BLOCK)
 small_strain_kernel(const LawParams prm, const int64_t n, const double* __restrict__ eps,
                     const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
@@ -211,18 +211,18 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
       for (int k = 0; k < 3; ++k) {
         const int idx = k * WAVE + lane;
         if (idx < npts * 3) {
-          if constexpr (NT_STORE) __builtin_nontemporal_store(stage2[idx], &gdst[idx]);
-          else gdst[idx] = stage2[idx];
+          gdst[idx] = stage2[idx];
         }
       }
     }
-    // ---- 7. coalesced tangent store (18 x 1 KiB): entry pair (i, j..j+1) of point q ----------
-    {
+    // ---- 7. coalesced tangent store: entry pair (i, j..j+1) of point q ---------------------------
+    if constexpr (!SYM) {
+      // full 6x6, row-major (quadrature_map.py:83-105): 18 x 1 KiB per tile, 18 pairs per point
       double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 36);
       const int lim = npts * 18;
 #pragma unroll 6
       for (int it = 0; it < 18; ++it) {
-        const int k = it * WAVE + lane;   // pair index inside the tile, 18 pairs per point
+        const int k = it * WAVE + lane;   // pair index inside the tile
         const int q = k / 18;
         const int r = k - q * 18;
         const int i = r / 3;
@@ -240,10 +240,41 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           v.x = t0 + (k3 * ni) * nj0;
           v.y = t1 + (k3 * ni) * nj1;
         }
-        if (k < lim) {
-          if constexpr (NT_STORE) __builtin_nontemporal_store(v, &gct[k]);
-          else gct[k] = v;
+        if (k < lim) gct[k] = v;
+      }
+    } else {
+      // symmetric-packed: the 21 entries (i <= j) of the upper triangle, row-major, per point
+      // (the J2 tangent is symmetric).  10.5 x 1 KiB per tile.
+      constexpr unsigned long long IP = 0x0ull | (1ull << 18) | (1ull << 21) | (1ull << 24) | (1ull << 27) | (1ull << 30) |
+                                        (2ull << 33) | (2ull << 36) | (2ull << 39) | (2ull << 42) | (3ull << 45) |
+                                        (3ull << 48) | (3ull << 51) | (4ull << 54) | (4ull << 57) | (5ull << 60);
+      constexpr unsigned long long JP = (0ull << 0) | (1ull << 3) | (2ull << 6) | (3ull << 9) | (4ull << 12) | (5ull << 15) |
+                                        (1ull << 18) | (2ull << 21) | (3ull << 24) | (4ull << 27) | (5ull << 30) |
+                                        (2ull << 33) | (3ull << 36) | (4ull << 39) | (5ull << 42) | (3ull << 45) |
+                                        (4ull << 48) | (5ull << 51) | (4ull << 54) | (5ull << 57) | (5ull << 60);
+      double* gct = ct + base * 21;
+      const int lim = npts * 21;
+#pragma unroll 4
+      for (int it = 0; it < 11; ++it) {
+        const int e0 = (it * WAVE + lane) * 2;
+        double v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = e0 + u;
+          const int q = e / 21;
+          const int t = e - q * 21;
+          const int i = (int)((IP >> (3 * t)) & 7ull), j = (int)((JP >> (3 * t)) & 7ull);
+          double x;
+          if constexpr (LAW == LAW_ELASTIC) {
+            x = ((i < 3 && j < 3) ? lambda : 0.0) + ((i == j) ? 2.0 * mu : 0.0);
+          } else {
+            const double* cf = coef + (q < WAVE ? q : 0) * 9;
+            x = ((i < 3 && j < 3) ? cf[0] : 0.0) + ((i == j) ? cf[1] : 0.0) + (cf[2] * cf[3 + i]) * cf[3 + j];
+          }
+          v[u] = x;
         }
+        if (e0 + 1 < lim) *reinterpret_cast<double2_t*>(gct + e0) = double2_t{v[0], v[1]};
+        else if (e0 < lim) gct[e0] = v[0];
       }
     }
     wave_lds_sync();  // LDS regions are rewritten by the next tile

@@ -63,7 +63,13 @@ class DataManager:
 class HIPMaterial:
     """A constitutive behaviour integrated on an MI355X through ``libdxmat.so``."""
 
-    def __init__(self, behavior, device: int = 0, gradient_name=None, flux_name=None):
+    def __init__(self, behavior, device: int = 0, gradient_name=None, flux_name=None, tangent_layout="full"):
+        """``tangent_layout="sym"`` (small-strain laws only) makes ``integrate`` return the 21
+        upper-triangle entries per point, ``(N, 21)``, instead of the full ``(N, 6, 6)`` block the
+        reference's ``jacobian_flatten`` expects (``conventions.unpack_sym_tangent`` expands it)."""
+        if tangent_layout not in ("full", "sym"):
+            raise ValueError("tangent_layout must be 'full' or 'sym'")
+        self.tangent_layout = tangent_layout
         self.behavior = behavior
         self.device = int(device)
         self._lib = _lib.load()
@@ -174,13 +180,20 @@ class HIPMaterial:
             raise DxmError(f"dxm_create failed: {_lib.last_error()}")
         self._handle = h
         self._n = int(ngauss)
+        if self.tangent_layout == "sym":
+            try:
+                _lib.check(self._lib.dxm_set_tangent_layout(h, 1))
+            except Exception:
+                self.close()
+                raise
         ng, nf = self._info.n_grad, self._info.n_flux
         nisv = self._info.n_isv_total
         # host mirrors of the fields that are not device state (gradient and flux of s0 / s1)
         self._grad = [self._initial_gradient(), self._initial_gradient()]
         self._flux = [np.zeros((self._n, nf)), np.zeros((self._n, nf))]
         # output arrays owned by the material, page-locked so that D2H runs at full PCIe rate
-        self._pinned = [_lib.PinnedArray((self._n, nisv)), _lib.PinnedArray((self._n, nf, ng)),
+        ct_shape = (self._n, nf, ng) if self.tangent_layout == "full" else (self._n, nf * (nf + 1) // 2)
+        self._pinned = [_lib.PinnedArray((self._n, nisv)), _lib.PinnedArray(ct_shape),
                         _lib.PinnedArray((self._n, nf)), _lib.PinnedArray((self._n, nf))]
         self._out_isv, self._out_ct = self._pinned[0].array, self._pinned[1].array
         self._out_isv[...] = 0.0

@@ -108,6 +108,15 @@ int64_t dxm_npoints(const dxm_material* m);
 int dxm_law(const dxm_material* m);
 /* Material.update_material_property (generic.py:119-120): replace the parameter vector. */
 int dxm_set_params(dxm_material* m, const double* params, int n_params);
+/* Tangent layout written by integrate: the full row-major (n_flux*n_grad) block the reference's
+ * `jacobian_flatten` holds (quadrature_map.py:83-105), or -- small-strain laws only, whose
+ * tangent is symmetric -- the 21 upper-triangle entries (i <= j, row-major).  The packed form
+ * cuts the dominant store / D2H / all-gather stream by 42 %; its consumer must index it itself
+ * (the reference's UFL side expects the full block). */
+enum { DXM_TANGENT_FULL = 0, DXM_TANGENT_SYM = 1 };
+int dxm_set_tangent_layout(dxm_material* m, int layout);
+/* doubles per point of the tangent array integrate writes (36 / 21 / 81). */
+int dxm_tangent_size(const dxm_material* m);
 /* Local Newton controls: stop when |r| <= rtol * sig0, at most maxit iterations. */
 int dxm_set_newton(dxm_material* m, int maxit, double rtol);
 

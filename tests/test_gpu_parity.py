@@ -172,3 +172,39 @@ def test_large_batch_properties():
     C = onp.elastic_matrix(E, NU)
     assert np.allclose(sig4 - sig3, (h[3] - h[2]) @ C.T, rtol=0, atol=1e-9 * np.abs(sig3).max())
     assert mat.last_stats["n_plastic"] == 0
+
+
+@pytest.mark.parametrize("kind", ["elastic", "linear", "voce"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1001, 70001])
+def test_symmetric_packed_tangent_equals_upper_triangle_of_full(kind, n):
+    """the 21-entry packed layout carries exactly the upper triangle of the
+    full 6x6 tangent, everything else (stress, state) unchanged."""
+    from dolfinx_materials_amd.conventions import pack_sym_tangent, unpack_sym_tangent
+
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if kind == "elastic":
+        beh, sig0 = jm.ElasticBehavior(el), SIG0_LIN
+    elif kind == "linear":
+        beh, sig0 = jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN)), SIG0_LIN
+    else:
+        beh, sig0 = jm.vonMisesIsotropicHardening(el, jm.VoceHardening(SIG0_V, SIGU_V, B_V)), SIG0_V
+    full, sym = JAXMaterial(beh), JAXMaterial(beh, tangent_layout="sym")
+    full.set_data_manager(n)
+    sym.set_data_manager(n)
+    for eps in j2_history(n, seed=31, sig0=sig0)[:3]:
+        sf, isvf, cf = full.integrate(eps)
+        ss, isvs, cs = sym.integrate(eps)
+        assert cs.shape == (n, 21)
+        assert np.array_equal(sf, ss) and np.array_equal(isvf, isvs)
+        assert np.array_equal(cs, pack_sym_tangent(cf))
+        assert np.abs(unpack_sym_tangent(cs) - cf).max() < 1e-9
+        full.data_manager.update()
+        sym.data_manager.update()
+
+
+def test_symmetric_layout_rejected_for_fefp():
+    from dolfinx_materials_amd import _lib
+
+    m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(500.0, 750.0, 1e3)), tangent_layout="sym")
+    with pytest.raises(_lib.DxmError, match="not symmetric"):
+        m.set_data_manager(8)

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--laws", nargs="+", default=["elastic", "j2_linear", "j2_voce", "fefp"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="also time the plain-C oracle on this many points")
+    ap.add_argument("--sym", action="store_true", help="symmetric-packed tangent (small-strain laws)")
     a = ap.parse_args()
     import torch
 
@@ -80,7 +81,8 @@ def main():
         else:
             path = fefp_path(n)
             beh, hist = jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F)), [path[9], path[18]]
-        m = JAXMaterial(beh)
+        sym = a.sym and law != "fefp"
+        m = JAXMaterial(beh, tangent_layout="sym" if sym else "full")
         m.set_data_manager(n)
         ng, nf = m._info.n_grad, m._info.n_flux
         g = [torch.from_numpy(h).to(dev) for h in hist]
@@ -100,9 +102,9 @@ def main():
             e1.record()
         torch.cuda.synchronize()
         ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
-        ab = m.algorithmic_bytes_per_point
+        ab = m.algorithmic_bytes_per_point - (15 * 8 if sym else 0)
         r = {
-            "law": law, "points": n, "kernel_ms": round(ms, 4), "Mpoints_per_s": round(n / ms / 1e3, 1),
+            "law": law + ("+sym21" if sym else ""), "points": n, "kernel_ms": round(ms, 4), "Mpoints_per_s": round(n / ms / 1e3, 1),
             "algorithmic_bytes_per_point": ab, "GBs": round(ab * n / ms / 1e6, 1), "frac_of_8TBs": round(ab * n / ms / 1e6 / 8000, 4),
             "plastic_fraction": round(stats["n_plastic"] / n, 4), "max_local_iters": stats["max_local_iters"],
             "not_converged": stats["n_not_converged"], "rc": rc,
