@@ -12,9 +12,10 @@
 // 16 B-per-lane coalesced accesses through wave-private LDS.  The 81-entry tangent (648 of the
 // 976 B/point) is never held per thread: with Fi = F^-1 it has the closed form
 //   A[(i,J),(k,L)] = V[k][L] Fi[J][i] + U[i][L] Fi[J][k] + W[k][L] Sd[i][J] + (i==k) g[L][J]
-// (derivation in DESIGN.md), so each point stages 54 doubles in LDS and the whole wave evaluates
-// the entries in output order and stores them as contiguous 1 KiB wave stores, PPR points per
-// round to bound the LDS footprint.
+// (derivation in DESIGN.md).  Each point stages 54 doubles in LDS, 14 points per round; lane
+// (point slot, tangent column) then evaluates the 9 rows of its column with compile-time row
+// indices (4 FMAs per entry, no per-entry index arithmetic), the results are transposed through
+// an LDS out-tile and leave as contiguous 1 KiB wave stores (full 64 B HBM write requests).
 #pragma once
 #include "dxm_common.hpp"
 
@@ -25,15 +26,14 @@ constexpr int FEFP_SLOT_BE = 1;   // be_bar, Mandel (user-visible ISV)
 constexpr int FEFP_SLOT_CPI = 7;  // isochoric Cp^-1, Mandel (hidden state)
 constexpr int FEFP_NSLOTS = 13;
 
-constexpr int FEFP_PPR = 32;                 // points per tangent round
-constexpr int FEFP_NCOEF = 54;               // staged doubles per point
 constexpr int FEFP_STAGE = 64 * 9;           // F in / PK1 out staging (doubles per wave)
-constexpr int FEFP_LDS_PER_WAVE = FEFP_STAGE + FEFP_PPR * FEFP_NCOEF;
-
-// (row, col) of entry t of the 9-vector, packed 2 bits each: rows [0,1,2,0,1,0,2,1,2],
-// cols [0,1,2,1,0,2,0,2,1]  (utils.py:168-190)
-constexpr unsigned FEFP_ROWS = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (1u << 8) | (0u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
-constexpr unsigned FEFP_COLS = 0u | (1u << 2) | (2u << 4) | (1u << 6) | (0u << 8) | (2u << 10) | (0u << 12) | (2u << 14) | (1u << 16);
+constexpr int F2_PPR = 14;   // points per tangent round: two steps of 7 point slots x 9 columns
+constexpr int F2_REC = 73;   // record stride: 54 staged doubles per point, padded to 146 dwords = 18 mod 64,
+                             // so that the 14 owner lanes write conflict-free (18 l mod 32 distinct) and the
+                             // point slots of a 32-lane read group land on (almost) disjoint banks
+constexpr int F2_OUT = ((F2_PPR * 81 + 127) / 128) * 128;   // out-tile, padded to whole KiB
+static_assert(F2_OUT >= FEFP_STAGE, "the out-tile aliases the F / PK1 staging region");
+constexpr int F2_LDS_PER_WAVE = F2_OUT + F2_PPR * F2_REC;
 
 __device__ __forceinline__ double det3(const double* A) {
   return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) +
@@ -77,13 +77,14 @@ __global__ void __launch_bounds__(BLOCK, 2)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
             const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
             double* __restrict__ Pout, double* __restrict__ ct, BlockStats* __restrict__ stats) {
-  __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * FEFP_LDS_PER_WAVE];
+  __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * F2_LDS_PER_WAVE];
   __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
 
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x >> 6;
-  double* stage = lds_all + wid * FEFP_LDS_PER_WAVE;
-  double* coef = stage + FEFP_STAGE;
+  double* stage = lds_all + wid * F2_LDS_PER_WAVE;   // F in / PK1 out staging ...
+  double* outt = stage;                              // ... reused as the tangent out-tile
+  double* coef = stage + F2_OUT;
   double2_t* stage2 = reinterpret_cast<double2_t*>(stage);
 
   const int64_t ntiles = (n + WAVE - 1) / WAVE;
@@ -97,6 +98,15 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
   const double SQ6 = 2.4494897427831780982;    // sqrt(6)
   const double RS2 = 0.70710678118654752440;   // 1/sqrt(2)
   const double SQ2 = 1.4142135623730950488;
+
+  constexpr int TI[9] = {0, 1, 2, 0, 1, 0, 2, 1, 2};  // row index of entry t of the 9-vector
+  constexpr int TJ[9] = {0, 1, 2, 1, 0, 2, 0, 2, 1};  // column index           (utils.py:168-190)
+  // tangent epilogue: lane = (point slot ps, tangent column cc); lane 63 idles
+  const int ps = lane / 9;
+  const int cc = lane - ps * 9;
+  const int kk = (0x26124 >> (2 * cc)) & 3;   // TI[cc] packed 2 bits each: 0,1,2,0,1,0,2,1,2
+  const int LL = (0x18864 >> (2 * cc)) & 3;   // TJ[cc]: 0,1,2,1,0,2,0,2,1
+  const double mk0 = kk == 0 ? 1.0 : 0.0, mk1 = kk == 1 ? 1.0 : 0.0, mk2 = kk == 2 ? 1.0 : 0.0;
 
   for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; tile < ntiles; tile += tile_stride) {
     const int64_t base = tile * WAVE;
@@ -303,7 +313,13 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       }
     }
 
-    // ---- 6. tangent: per-point coefficients, then cooperative entry evaluation ----------------------
+    // ---- 6. tangent.  Per point 54 doubles are staged in LDS:
+    //   Fi[J][i] 0..8 | Vc[col] 9..17 | U[i][L] 18..26 | Wc[col] 27..35 | Sr[row] 36..44 | g[L][J] 45..53
+    // A[row=(i,J)][col=(k,L)] = Vc[col] Fi[J][i] + Wc[col] Sr[row] + U[i][L] Fi[J][k] + (i==k) g[L][J].
+    // Lane (ps, cc) owns tangent COLUMN cc of point slot ps: k, L and the (i==k) masks are lane
+    // constants, the 9 rows are unrolled with compile-time (i, J), so an entry costs 4 FMAs and
+    // ~3 LDS reads with immediate offsets.  Results are transposed through an LDS out-tile of
+    // F2_PPR points and leave as contiguous 1 KiB wave stores (full 64 B HBM write requests).
     const double mt = mu * theta;
     const double c0 = kappa * J * J;
     double V[9], U[9], Sd[9];
@@ -319,49 +335,77 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     const double gs = mt * Jm23;
 
 #pragma unroll 1
-    for (int round = 0; round < WAVE / FEFP_PPR; ++round) {
-      if ((lane / FEFP_PPR) == round) {
-        double2_t* c2 = reinterpret_cast<double2_t*>(coef + (lane % FEFP_PPR) * FEFP_NCOEF);
-        // layout: Fi 0..8 | V 9..17 | U 18..26 | W 27..35 | Sd 36..44 | g 45..53
-        double buf[FEFP_NCOEF];
+    for (int rd = 0; rd < (WAVE + F2_PPR - 1) / F2_PPR; ++rd) {
+      const int p0 = rd * F2_PPR;                               // first point of the round
+      const int cnt = (WAVE - p0) < F2_PPR ? (WAVE - p0) : F2_PPR;  // points staged this round
+      if (lane >= p0 && lane < p0 + cnt) {
+        double* rec = coef + (lane - p0) * F2_REC;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          buf[k] = Fi[k]; buf[9 + k] = V[k]; buf[18 + k] = U[k]; buf[27 + k] = Q[k];
-          buf[36 + k] = Sd[k]; buf[45 + k] = gs * G[k];
+        for (int t = 0; t < 9; ++t) {
+          rec[t] = Fi[t];
+          rec[9 + t] = V[TI[t] * 3 + TJ[t]];
+          rec[18 + t] = U[t];
+          rec[27 + t] = Q[TI[t] * 3 + TJ[t]];
+          rec[36 + t] = Sd[TI[t] * 3 + TJ[t]];
+          rec[45 + t] = gs * G[t];
         }
-#pragma unroll
-        for (int k = 0; k < FEFP_NCOEF / 2; ++k) c2[k] = double2_t{buf[2 * k], buf[2 * k + 1]};
       }
       wave_lds_sync();
-      const int p0 = round * FEFP_PPR;              // first point of the round
-      int np_round = npts - p0;
-      np_round = np_round < 0 ? 0 : (np_round > FEFP_PPR ? FEFP_PPR : np_round);
-      const int nent = np_round * 81;               // entries of this round
-      double* gct = ct + (base + p0) * 81;
-      constexpr int NITER = (FEFP_PPR * 81 + 2 * WAVE - 1) / (2 * WAVE);
-      // (base + p0) * 81 is even: every round starts 16 B aligned
-#pragma unroll 2
-      for (int it = 0; it < NITER; ++it) {
-        const int e0 = (it * WAVE + lane) * 2;
-        double v[2];
+#pragma unroll 1
+      for (int st = 0; st < 2; ++st) {
+        const int ql = st * 7 + ps;                              // point inside the round
+        if (lane < 63 && ql < cnt) {
+          const double* rec = coef + ql * F2_REC;
+          // all LDS reads first (the out-tile writes below may alias them for the compiler)
+          double fi[9], sr[9];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int e = e0 + u;
-          const int q = e / 81;
-          const int m = e - q * 81;
-          const int row = m / 9, col = m - row * 9;
-          const int i = (FEFP_ROWS >> (2 * row)) & 3, Jx = (FEFP_COLS >> (2 * row)) & 3;
-          const int k = (FEFP_ROWS >> (2 * col)) & 3, L = (FEFP_COLS >> (2 * col)) & 3;
-          const double* c = coef + (q < FEFP_PPR ? q : 0) * FEFP_NCOEF;
-          double x = c[9 + k * 3 + L] * c[Jx * 3 + i] + c[18 + i * 3 + L] * c[Jx * 3 + k] +
-                     c[27 + k * 3 + L] * c[36 + i * 3 + Jx];
-          if (i == k) x += c[45 + L * 3 + Jx];
-          v[u] = x;
+          for (int t = 0; t < 9; ++t) { fi[t] = rec[t]; sr[t] = rec[36 + t]; }
+          const double Vc = rec[9 + cc], Wc = rec[27 + cc];
+          const double U0 = rec[18 + LL], U1 = rec[21 + LL], U2 = rec[24 + LL];
+          const double g0 = rec[45 + LL * 3 + 0], g1 = rec[45 + LL * 3 + 1], g2 = rec[45 + LL * 3 + 2];
+          const double F0k = kk == 0 ? fi[0] : (kk == 1 ? fi[1] : fi[2]);
+          const double F1k = kk == 0 ? fi[3] : (kk == 1 ? fi[4] : fi[5]);
+          const double F2k = kk == 0 ? fi[6] : (kk == 1 ? fi[7] : fi[8]);
+          double x[9];
+#pragma unroll
+          for (int r = 0; r < 9; ++r) {
+            const int i = TI[r], Jx = TJ[r];
+            const double Ui = i == 0 ? U0 : (i == 1 ? U1 : U2);
+            const double FJk = Jx == 0 ? F0k : (Jx == 1 ? F1k : F2k);
+            const double gJ = Jx == 0 ? g0 : (Jx == 1 ? g1 : g2);
+            const double mi = i == 0 ? mk0 : (i == 1 ? mk1 : mk2);
+            double t = Vc * fi[Jx * 3 + i];
+            t += Wc * sr[r];
+            t += Ui * FJk;
+            t += mi * gJ;
+            x[r] = t;
+          }
+          double* o = outt + ql * 81 + cc;
+#pragma unroll
+          for (int r = 0; r < 9; ++r) o[r * 9] = x[r];
         }
-        if (e0 + 1 < nent) {
-          *reinterpret_cast<double2_t*>(gct + e0) = double2_t{v[0], v[1]};
-        } else if (e0 < nent) {
-          gct[e0] = v[0];
+      }
+      wave_lds_sync();
+      {
+        int nv = npts - p0;                                      // valid points of this round
+        nv = nv < 0 ? 0 : (nv > cnt ? cnt : nv);
+        const int nent = nv * 81;                                // wave-uniform
+        double* gct = ct + (base + p0) * 81;                     // 16 B aligned: (base + p0) * 81 is even
+        const double2_t* o2 = reinterpret_cast<const double2_t*>(outt);
+        constexpr int NIT = (F2_PPR * 81 + 2 * WAVE - 1) / (2 * WAVE);
+        double2_t v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = o2[it * WAVE + lane];   // out-tile is padded to NIT KiB
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int e0 = (it * WAVE + lane) * 2;
+          if ((it + 1) * 2 * WAVE <= nent) {                     // scalar branch: whole KiB valid
+            *reinterpret_cast<double2_t*>(gct + e0) = v[it];
+          } else if (e0 + 1 < nent) {
+            *reinterpret_cast<double2_t*>(gct + e0) = v[it];
+          } else if (e0 < nent) {
+            gct[e0] = v[it].x;
+          }
         }
       }
       wave_lds_sync();
