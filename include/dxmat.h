@@ -25,7 +25,9 @@
  *   - int return codes: 0 = ok, > 0 = number of points whose local Newton did not converge,
  *     < 0 = hard error (message from dxm_last_error());
  *   - one handle per (material, device); a handle is not thread-safe (the reference calls the path
- *     from the PETSc SNES callback on one thread: dolfinx_materials/solvers.py:72);
+ *     from the PETSc SNES callback on one thread: dolfinx_materials/solvers.py:72); successive
+ *     device-pointer launches on one handle must be ordered on the same HIP stream (advance()
+ *     and revert() only swap pointers on the host);
  *   - there is NO CPU fallback: every entry point that computes fails with a negative code when no
  *     HIP device is usable.
  */
