@@ -116,7 +116,8 @@ struct dxm_material {
   bool s1_alias = false;  // after advance()/revert() s1 == s0 until the next integrate: no copy is made
   BlockStats* d_stats = nullptr;
   int stats_capacity = 0;
-  int last_grid = 0;
+  int last_grid = 0;                      // stats records written by the last integrate
+  hipStream_t pipe_stream = nullptr;      // second stream of the chunk-pipelined host path
   hipStream_t last_stream = nullptr;
   bool launched = false;
   hipStream_t own_stream = nullptr;
@@ -300,7 +301,7 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
     if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : m->blocks_per_cu;
     if (m->blocks_per_cu > 16) m->blocks_per_cu = 16;
   }
-  m->stats_capacity = m->num_cu * 16;
+  m->stats_capacity = m->num_cu * m->blocks_per_cu * 8;  // up to 8 chunk launches per integrate
   if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {
     fail(-3, "hipMalloc of stats failed"); return bail();
   }
@@ -320,6 +321,7 @@ int dxm_destroy(dxm_material* m) {
   if (m->d_isv) (void)hipFree(m->d_isv);
   if (m->d_ct) (void)hipFree(m->d_ct);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  if (m->pipe_stream) (void)hipStreamDestroy(m->pipe_stream);
   delete m;
   return 0;
 }
@@ -442,38 +444,51 @@ int dxm_revert(dxm_material* m) {
 }  // extern "C"
 
 // ---- launch -------------------------------------------------------------------------------
+// One launch over the point range [off, off + cnt) (off a multiple of 256): the chunk-pipelined host
+// path issues several of these on alternating streams; everything else launches the whole batch.
+// The block records of the launch go to m->d_stats[stats_off ...).
 template <int LAW>
-static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, const double* grad,
-                                double* flux, double* ct) {
+static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64_t off, int64_t cnt,
+                                const double* grad, double* flux, double* ct, int stats_off) {
+  const double* s0 = m->state[0] + off;
+  double* s1 = m->state[1] + off;
   if (m->sym_tangent)
-    hipLaunchKernelGGL((small_strain_kernel<LAW, true>), dim3(grid), dim3(BLOCK), 0, st, m->prm,
-                       m->n, grad, m->state[0], m->state[1], m->ld, flux, ct, m->d_stats);
+    hipLaunchKernelGGL((small_strain_kernel<LAW, true>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
+                       grad, s0, s1, m->ld, flux, ct, m->d_stats + stats_off);
   else
-    hipLaunchKernelGGL((small_strain_kernel<LAW, false>), dim3(grid), dim3(BLOCK), 0, st, m->prm,
-                       m->n, grad, m->state[0], m->state[1], m->ld, flux, ct, m->d_stats);
+    hipLaunchKernelGGL((small_strain_kernel<LAW, false>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
+                       grad, s0, s1, m->ld, flux, ct, m->d_stats + stats_off);
 }
 
-static int launch(dxm_material* m, const double* grad, double* flux, double* ct, hipStream_t st) {
-  if (m->n == 0) { m->last_grid = 0; return 0; }
+static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double* grad, double* flux,
+                        double* ct, hipStream_t st, int stats_off, int* grid_out) {
   if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
     return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
-  const int64_t ntiles = (m->n + WAVE - 1) / WAVE;
+  const int64_t ntiles = (cnt + WAVE - 1) / WAVE;
   int64_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int64_t cap = (int64_t)m->num_cu * m->blocks_per_cu;
   if (blocks > cap) blocks = cap;
-  if (blocks > m->stats_capacity) blocks = m->stats_capacity;
+  if (stats_off + blocks > m->stats_capacity) return fail(-1, "internal: stats buffer too small");
   const int grid = (int)blocks;
   switch (m->law) {
-    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, grad, flux, ct); break;
-    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, grad, flux, ct); break;
-    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, grad, flux, ct); break;
+    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
+    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
+    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
     case DXM_LAW_FEFP_J2_VOCE:
-      hipLaunchKernelGGL(fefp_kernel, dim3(grid), dim3(BLOCK), 0, st, m->prm, m->n, grad,
-                         m->state[0], m->state[1], m->ld, flux, ct, m->d_stats);
+      hipLaunchKernelGGL(fefp_kernel, dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad,
+                         m->state[0] + off, m->state[1] + off, m->ld, flux, ct, m->d_stats + stats_off);
       break;
     default: return fail(-1, "law %d not launchable", m->law);
   }
   HIP_TRY(hipGetLastError());
+  *grid_out = grid;
+  return 0;
+}
+
+static int launch(dxm_material* m, const double* grad, double* flux, double* ct, hipStream_t st) {
+  if (m->n == 0) { m->last_grid = 0; return 0; }
+  int grid = 0;
+  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid)) return rc;
   m->last_grid = grid;
   m->last_stream = st;
   m->launched = true;
@@ -515,6 +530,23 @@ int dxm_get_stats(dxm_material* m, dxm_stats* stats) {
   return 0;
 }
 
+static int pack_isv_range(dxm_material* m, int which, int64_t off, int64_t cnt, double* isv_aos_dev,
+                          hipStream_t st) {
+  const LawDesc& d = kLaws[m->law];
+  const int total = isv_total(d);
+  PackMap map{};
+  map.n = total;
+  int k = 0;
+  for (int f = 0; f < d.n_isv_fields; ++f)
+    for (int c = 0; c < d.isv_dim[f]; ++c) map.slot[k++] = d.isv_slot[f] + c;
+  const int64_t work = cnt * total;
+  const int blocks = (int)((work + 255) / 256);
+  hipLaunchKernelGGL(pack_isv_kernel, dim3(blocks), dim3(256), 0, st, state_of(m, which) + off, m->ld,
+                     cnt, isv_aos_dev, map);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_stream) {
   if (!m) return fail(-1, "null handle");
   if (which != DXM_S0 && which != DXM_S1) return fail(-1, "state selector must be DXM_S0 or DXM_S1");
@@ -523,17 +555,7 @@ int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_st
   if (total == 0 || m->n == 0) return 0;
   if (!isv_aos_dev) return fail(-1, "null device pointer");
   DEVICE_GUARD(m);
-  PackMap map{};
-  map.n = total;
-  int k = 0;
-  for (int f = 0; f < d.n_isv_fields; ++f)
-    for (int c = 0; c < d.isv_dim[f]; ++c) map.slot[k++] = d.isv_slot[f] + c;
-  const int64_t work = m->n * total;
-  const int blocks = (int)((work + 255) / 256);
-  hipLaunchKernelGGL(pack_isv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
-                     state_of(m, which), m->ld, m->n, isv_aos_dev, map);
-  HIP_TRY(hipGetLastError());
-  return 0;
+  return pack_isv_range(m, which, 0, m->n, isv_aos_dev, (hipStream_t)hip_stream);
 }
 
 static int ensure_host_path_buffers(dxm_material* m) {
@@ -549,25 +571,66 @@ static int ensure_host_path_buffers(dxm_material* m) {
   return 0;
 }
 
-// constitutive kernel on m->d_grad, then the requested downloads; synchronises own_stream
-static int run_and_download(dxm_material* m, double* flux_aos, double* isv_aos, double* ct_aos,
-                            dxm_stats* stats) {
+}  // extern "C"
+
+// Host-buffer form, shared by dxm_integrate and dxm_integrate_displacement.
+//   upload(off, cnt, stream) enqueues whatever produces m->d_grad[off .. off+cnt) on `stream`.
+// Large batches are cut into up to 8 chunks (multiples of 256 points) issued on two alternating
+// streams: the H2D of chunk c+1 and the kernel of chunk c+1 overlap the D2H of chunk c (PCIe is
+// full duplex and the 392 B/point coming back dominate).  Each chunk is one launch over a point
+// range; its block-stat records are appended after the previous chunk's.
+template <class Upload>
+static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
+                            double* ct_aos, dxm_stats* stats) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  hipStream_t st = m->own_stream;
-  if (int rc = launch(m, m->d_grad, m->d_flux, m->d_ct, st)) return rc;
-  if (flux_aos)
-    HIP_TRY(hipMemcpyAsync(flux_aos, m->d_flux, sizeof(double) * n * d.n_flux, hipMemcpyDeviceToHost, st));
-  if (isv_aos && total > 0) {
-    if (int rc = dxm_isv_device(m, DXM_S1, m->d_isv, st)) return rc;
-    HIP_TRY(hipMemcpyAsync(isv_aos, m->d_isv, sizeof(double) * n * total, hipMemcpyDeviceToHost, st));
+  const int nt = tangent_size(m);
+  if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
+  int nchunks = (int)(n / 262144);
+  if (nchunks < 1) nchunks = 1;
+  if (nchunks > 8) nchunks = 8;
+  if (getenv("DXM_NO_PIPELINE")) nchunks = 1;
+  int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
+  int stats_off = 0;
+  hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
+  for (int c = 0; c < nchunks; ++c) {
+    const int64_t off = (int64_t)c * csize;
+    if (off >= n) break;
+    const int64_t cnt = (n - off) < csize ? (n - off) : csize;
+    hipStream_t st = streams[c & 1];
+    if (int rc = upload(off, cnt, st)) return rc;
+    int grid = 0;
+    if (int rc = launch_range(m, off, cnt, m->d_grad + off * d.n_grad, m->d_flux + off * d.n_flux,
+                              m->d_ct + off * nt, st, stats_off, &grid))
+      return rc;
+    stats_off += grid;
+    if (flux_aos)
+      HIP_TRY(hipMemcpyAsync(flux_aos + off * d.n_flux, m->d_flux + off * d.n_flux,
+                             sizeof(double) * cnt * d.n_flux, hipMemcpyDeviceToHost, st));
+    if (isv_aos && total > 0) {
+      // the kernel wrote state[1]; s1_alias is cleared below, address it directly
+      const bool alias = m->s1_alias;
+      m->s1_alias = false;
+      int rc = pack_isv_range(m, DXM_S1, off, cnt, m->d_isv + off * total, st);
+      m->s1_alias = alias;
+      if (rc) return rc;
+      HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
+                             hipMemcpyDeviceToHost, st));
+    }
+    if (ct_aos)
+      HIP_TRY(hipMemcpyAsync(ct_aos + off * nt, m->d_ct + off * nt, sizeof(double) * cnt * nt,
+                             hipMemcpyDeviceToHost, st));
   }
-  if (ct_aos)
-    HIP_TRY(hipMemcpyAsync(ct_aos, m->d_ct, sizeof(double) * n * tangent_size(m),
-                           hipMemcpyDeviceToHost, st));
-  return dxm_get_stats(m, stats);  // synchronises st
+  m->last_grid = stats_off;
+  m->last_stream = m->own_stream;
+  m->launched = true;
+  m->s1_alias = false;  // every slot of s1 has been rewritten
+  HIP_TRY(hipStreamSynchronize(m->pipe_stream));
+  return dxm_get_stats(m, stats);  // synchronises own_stream
 }
+
+extern "C" {
 
 int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
                   double* isv_aos, double* ct_aos, dxm_stats* stats) {
@@ -582,10 +645,14 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   if (!grad_aos) return fail(-1, "null gradient pointer");
   DEVICE_GUARD(m);
   if (int rc = ensure_host_path_buffers(m)) return rc;
-  hipStream_t st = m->own_stream;
-  if (m->launched && m->last_stream != st) HIP_TRY(hipStreamSynchronize(m->last_stream));
-  HIP_TRY(hipMemcpyAsync(m->d_grad, grad_aos, sizeof(double) * n * d.n_grad, hipMemcpyHostToDevice, st));
-  return run_and_download(m, flux_aos, isv_aos, ct_aos, stats);
+  if (m->launched) HIP_TRY(hipStreamSynchronize(m->last_stream));
+  const int ng = d.n_grad;
+  auto upload = [&](int64_t off, int64_t cnt, hipStream_t st) -> int {
+    HIP_TRY(hipMemcpyAsync(m->d_grad + off * ng, grad_aos + off * ng, sizeof(double) * cnt * ng,
+                           hipMemcpyHostToDevice, st));
+    return 0;
+  };
+  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats);
 }
 
 void* dxm_host_alloc(uint64_t bytes) {
@@ -612,6 +679,7 @@ struct dxm_mesh {
   double* d_coords = nullptr;
   int32_t* d_conn = nullptr;
   double* d_u = nullptr;
+  hipEvent_t grad_done = nullptr;
 };
 
 dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int32_t* conn,
@@ -655,6 +723,7 @@ int dxm_mesh_destroy(dxm_mesh* mesh) {
   if (mesh->d_coords) (void)hipFree(mesh->d_coords);
   if (mesh->d_conn) (void)hipFree(mesh->d_conn);
   if (mesh->d_u) (void)hipFree(mesh->d_u);
+  if (mesh->grad_done) (void)hipEventDestroy(mesh->grad_done);
   delete mesh;
   return 0;
 }
@@ -688,11 +757,18 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
   DEVICE_GUARD(m);
   if (int rc = ensure_host_path_buffers(m)) return rc;
   hipStream_t st = m->own_stream;
-  if (m->launched && m->last_stream != st) HIP_TRY(hipStreamSynchronize(m->last_stream));
+  if (m->launched) HIP_TRY(hipStreamSynchronize(m->last_stream));
   HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * 3 * mesh->n_nodes, hipMemcpyHostToDevice, st));
   const int kind = kLaws[m->law].n_grad == 9 ? 1 : 0;
   if (int rc = dxm_mesh_gradient_device(mesh, mesh->d_u, kind, m->d_grad, st)) return rc;
-  return run_and_download(m, flux_aos, isv_aos, ct_aos, stats);
+  // the whole gradient array is produced on own_stream; chunks on the second stream wait for it
+  if (!mesh->grad_done) HIP_TRY(hipEventCreateWithFlags(&mesh->grad_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(mesh->grad_done, st));
+  auto upload = [&](int64_t, int64_t, hipStream_t s) -> int {
+    if (s != st) HIP_TRY(hipStreamWaitEvent(s, mesh->grad_done, 0));
+    return 0;
+  };
+  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats);
 }
 
 const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp) {
