@@ -208,3 +208,17 @@ def test_symmetric_layout_rejected_for_fefp():
     m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(500.0, 750.0, 1e3)), tangent_layout="sym")
     with pytest.raises(_lib.DxmError, match="not symmetric"):
         m.set_data_manager(8)
+
+
+def test_elastic_known_answer_nu_zero():
+    """tests/mfront/test_initialization.py:113-132: sigma[:3] = E * [1e-3, 0, 0] for nu = 0, also
+    after update_material_property (the reference test changes E through the QuadratureMap)."""
+    mat = LinearElasticIsotropic(70e3, 0.0)
+    mat.set_data_manager(4)
+    eps = np.tile(np.array([1e-3, 0, 0, 0, 0, 0.0]), (4, 1))
+    sig, _, Ct = mat.integrate(eps)
+    assert np.allclose(sig[:, :3], 70e3 * np.array([1e-3, 0, 0]), rtol=1e-14, atol=1e-12)
+    mat.update_material_property("elasticity.E", 210e3)
+    sig, _, Ct = mat.integrate(eps)
+    assert np.allclose(sig[:, :3], 210e3 * np.array([1e-3, 0, 0]), rtol=1e-14, atol=1e-12)
+    assert np.allclose(Ct[0], 210e3 * np.eye(6), rtol=1e-14)

@@ -287,3 +287,12 @@ def test_fefp_c_oracle_equals_numpy_oracle():
             assert np.abs(c[key][safe] - r[key][safe]).max() <= 1e-12 * max(np.abs(r[key]).max(), 1e-300), (k, key)
         assert c["n_not_converged"] == 0
         cp, p = r["cpinv"], r["p"]
+
+
+def test_elastic_known_answer_nu_zero():
+    """tests/mfront/test_initialization.py:113-132: sigma[:3] = E * [1e-3, 0, 0] for nu = 0."""
+    eps = np.array([[1e-3, 0, 0, 0, 0, 0.0]])
+    for fn in (onp.elastic_iso, oracle_c.elastic_iso):
+        sig, Ct = fn(eps, 70e3, 0.0)
+        assert np.allclose(sig[0, :3], 70e3 * np.array([1e-3, 0, 0]), rtol=1e-14, atol=1e-12)
+        assert np.allclose(Ct[0], 70e3 * np.eye(6), rtol=1e-14)

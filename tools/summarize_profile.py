@@ -87,7 +87,7 @@ def main():
     with open(a.prefix + "_summary.md", "w") as f:
         f.write(f"# rocprofv3 summary: `{a.kernel}` ({a.law}, {a.points} points per launch)\n\n")
         f.write("Command: `bash tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around\n")
-        f.write("`python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline`.\n\n## kernel-trace --stats\n\n")
+        f.write("`python3 bench.py --steps 30 --warmup 6 --no-cpu-baseline` (the default bench command without its CPU leg).\n\n## kernel-trace --stats\n\n")
         if rows:
             f.write("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
             for r in rows:
