@@ -95,3 +95,22 @@ def test_objectivity():
     assert np.abs(isv2[:, 0] - isv1[:, 0]).max() < 1e-14
     be1, be2 = onp.mandel_to_tensor(isv1[:, 1:]), onp.mandel_to_tensor(isv2[:, 1:])
     assert relerr(be2, Q @ be1 @ Q.transpose(0, 2, 1)) < 1e-11
+
+
+def test_large_deformation_single_step():
+    """Very large single increments (|F - I| ~ 0.25, dp up to ~2): the 2x2 local Newton still
+    converges everywhere and the kernel follows the oracle."""
+    rng = np.random.default_rng(0)
+    F = np.eye(3) + 0.25 * rng.standard_normal((4000, 3, 3))
+    F = F[np.linalg.det(F) > 0.2]
+    n = len(F)
+    m = make(n)
+    P, isv, Ct = m.integrate(onp.tensor_to_nsym(F))
+    ref = onp.fefp_update(onp.tensor_to_nsym(F), onp.fefp_initial_state(n)["cpinv"], np.zeros(n), E, NU, HARD)
+    assert m.last_stats["n_not_converged"] == 0 and m.last_stats["n_nan"] == 0 and not ref["notconv"].any()
+    safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_F
+    assert relerr(P[safe], ref["P"][safe]) < 1e-10
+    assert relerr(Ct[safe], ref["Ct"][safe]) < 1e-9
+    assert relerr(isv[safe, 0], ref["p"][safe]) < 1e-10
+    be = onp.mandel_to_tensor(isv[:, 1:])
+    assert np.abs(np.linalg.det(be) - 1).max() < 1e-12
