@@ -39,11 +39,14 @@ def _get_vals(fun: ArrayFunction):
 
 
 def _update_vals(fun: ArrayFunction, array, cells=None):
-    """``utils.py:136-143`` (block scatter by cell; identity when all cells are used)."""
-    if cells is None:
-        fun.x.array[:] = np.asarray(array).ravel()
+    """``utils.py:136-143`` (block scatter by cell).  A map over all cells in order is the identity
+    permutation; it is written with one contiguous copy instead of the reference's fancy-index
+    scatter (same result, and the only host-side cost that scales with the batch here)."""
+    arr = np.asarray(array).ravel()
+    if cells is None or (len(arr) == fun.x.array.size and len(cells) > 0 and cells[0] == 0
+                         and cells[-1] == len(cells) - 1 and np.all(np.diff(cells) == 1)):
+        fun.x.array[:] = arr
     else:
-        arr = np.asarray(array).ravel()
         bs = len(arr) // len(cells)
         dofs = np.add.outer(np.asarray(cells) * bs, np.arange(bs)).ravel()
         fun.x.array[dofs] = arr

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Stand-alone batch use of a material, without any FE code: the call sequence of the reference's
+``tests/test_FeFp_jax.py:6-33`` (``set_data_manager`` -> loop { ``integrate`` ->
+``data_manager.update()`` }) with the MI355X engine.  Only the two imports differ from the
+reference script (and the Voce law is a ``jm.VoceHardening`` object instead of a Python function).
+
+    python examples/standalone_batch.py [Nbatch]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import dolfinx_materials_amd.materials as jm  # reference: import jaxmat.materials as jm
+from dolfinx_materials_amd.jaxmat import JAXMaterial  # reference: from dolfinx_materials.jaxmat import JAXMaterial
+
+
+def main(Nbatch=10):
+    E, nu, sig0, b, sigu = 70e3, 0.3, 500.0, 1000, 750.0
+    elastic_model = jm.LinearElasticIsotropic(E=E, nu=nu)
+    behavior = jm.FeFpJ2Plasticity(elasticity=elastic_model, yield_stress=jm.VoceHardening(sig0=sig0, sigu=sigu, b=b))
+    material = JAXMaterial(behavior)
+    material.set_data_manager(Nbatch)
+
+    eps, Nsteps, dt = 2e-2, 20, 0
+    for t in np.linspace(0, 1.0, Nsteps)[1:]:
+        F = np.zeros((Nbatch, 9))
+        F[:, 0] = 1 + eps * t
+        F[:, [1, 2]] = 1 - eps / 2 * t
+        P, isv, Ct = material.integrate(F, dt)
+        material.data_manager.update()
+        print(f"t={t:.3f}  P11={P[0, 0]:9.4f}  p={isv[0, 0]:.6f}  plastic points={material.last_stats['n_plastic']}")
+    return P, isv, Ct
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 10)
