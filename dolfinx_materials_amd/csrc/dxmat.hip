@@ -105,7 +105,7 @@ struct dxm_material {
   int law = 0;
   int device = 0;
   int64_t n = 0;
-  int64_t ld = 0;  // SoA leading dimension (n rounded up to 256)
+  int64_t ld = 0;  // SoA leading dimension (n rounded up to 256, plus a 32-double stagger)
   LawParams prm{};
   std::vector<double> raw_params;
   int maxit = 25;
