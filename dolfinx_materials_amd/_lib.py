@@ -105,6 +105,26 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` / ``libhsa-runtime64.so``.  If
+    libdxmat (linked against ``/opt/rocm``) initialises HIP first and torch is imported later, the
+    process ends up with two HIP/HSA runtimes and torch reports "No HIP GPUs are available".
+    Importing torch first puts its runtime in the global symbol scope, libdxmat binds to it, and
+    device pointers, streams and events are shared (this is what ``bench.py`` relies on when it
+    passes ``torch.cuda.current_stream().cuda_stream``).  Skipped when torch is not installed or
+    ``DXM_NO_TORCH_PRELOAD=1``."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("DXM_NO_TORCH_PRELOAD") == "1":
+        return
+    if importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
 def load() -> C.CDLL:
     """Load the library and bind every ABI symbol; raises if it has not been built."""
     global _lib
@@ -116,6 +136,7 @@ def load() -> C.CDLL:
             "__graft_entry__ as g; g.build()'` or `make -C dolfinx_materials_amd/csrc`). "
             "dolfinx_materials_amd has no CPU fallback."
         )
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
