@@ -82,3 +82,27 @@ def test_unknown_property_and_callable_hardening():
         m.update_material_property("elasticity.G", 1.0)
     with pytest.raises(NotImplementedError):
         m.update_material_property("elasticity.E", np.ones(4))
+
+
+def test_device_path_on_a_non_default_torch_stream():
+    """The stream handle passed through the ABI is honoured: work enqueued on a side stream is
+    ordered with torch work on that stream and invisible to the others until synchronised."""
+    torch = pytest.importorskip("torch")
+    from oracle import constitutive_np as onp
+    from helpers import j2_history
+
+    n = 200_000
+    dev = torch.device("cuda:0")
+    m = _mat(n)
+    eps_h = j2_history(n)[2]
+    side = torch.cuda.Stream()
+    f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
+    with torch.cuda.stream(side):
+        g = torch.from_numpy(eps_h).to(dev, non_blocking=True) * 1.0   # produced on the side stream
+        m.integrate_device(g.data_ptr(), f.data_ptr(), c.data_ptr(), side.cuda_stream)
+        total = f.sum()                                                 # consumed on the side stream
+    side.synchronize()
+    ref = onp.j2_update(eps_h, np.zeros((n, 6)), np.zeros(n), 70e3, 0.3, onp.LinearHardening(250.0, 5e3))
+    assert abs(float(total) - ref["sig"].sum()) < 1e-6 * np.abs(ref["sig"]).sum()
+    assert np.abs(f.cpu().numpy() - ref["sig"]).max() < 1e-9 * np.abs(ref["sig"]).max()
