@@ -1,4 +1,4 @@
-"""GPU: error behaviour of the C ABI and of the protocol class (hard errors are negative return
+"""GPU: behaviour of the C ABI beyond numerics -- errors, stream semantics, graph capture (hard errors are negative return
 codes surfaced as DxmError; the reference raises Python exceptions at the same places)."""
 import ctypes as C
 
@@ -106,3 +106,33 @@ def test_device_path_on_a_non_default_torch_stream():
     ref = onp.j2_update(eps_h, np.zeros((n, 6)), np.zeros(n), 70e3, 0.3, onp.LinearHardening(250.0, 5e3))
     assert abs(float(total) - ref["sig"].sum()) < 1e-6 * np.abs(ref["sig"]).sum()
     assert np.abs(f.cpu().numpy() - ref["sig"]).max() < 1e-9 * np.abs(ref["sig"]).max()
+
+
+def test_device_path_is_graph_capturable():
+    """dxm_integrate_device makes no allocation and no synchronisation, so a caller can capture a
+    whole Newton-iteration cadence (several updates) in a HIP graph and replay it."""
+    torch = pytest.importorskip("torch")
+    from helpers import j2_history
+
+    n = 50_000
+    dev = torch.device("cuda:0")
+    m = _mat(n)
+    h = j2_history(n)
+    g = [torch.from_numpy(x).to(dev) for x in h[:3]]
+    f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
+    # eager reference: three updates from the same s0, last one wins
+    for x in g:
+        m.integrate_device(x.data_ptr(), f.data_ptr(), c.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    f_ref, c_ref = f.clone(), c.clone()
+    f.zero_()
+    c.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for x in g:
+            m.integrate_device(x.data_ptr(), f.data_ptr(), c.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert float(f.abs().max()) == 0.0  # nothing ran during capture
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(f, f_ref) and torch.equal(c, c_ref)
