@@ -91,6 +91,66 @@ def cpu_baseline(sample, seed, budget_s=14.0):
     }
 
 
+def other_laws(torch, jm, JAXMaterial, dev, n, reps=8):
+    """Kernel rates of the other laws of the path at the same batch size (device-resident,
+    HIP events), for context next to the headline: elastic, J2 Voce (cfg 3 parameters), FeFp J2
+    (cfg 4 parameters, F = I + t (eps diag(1,-1/2,-1/2) + 0.2 eps G) as in SURVEY.md 8(d))."""
+    out = {}
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    mu = E / 2 / (1 + NU)
+
+    def strain(sig0):
+        d = torch.randn((n, 6), generator=gen, device=dev, dtype=torch.float64)
+        d /= d.norm(dim=1, keepdim=True)
+        return d * (torch.rand((n, 1), generator=gen, device=dev, dtype=torch.float64) * 4.0 * sig0 / (2 * mu) * np.sqrt(2.0 / 3.0))
+
+    def fgrad(t):
+        F = torch.zeros((n, 9), dtype=torch.float64, device=dev)
+        G = torch.randn((n, 9), generator=torch.Generator(device=dev).manual_seed(99), device=dev, dtype=torch.float64)
+        F += t * 0.2 * 2e-2 * G
+        F[:, 0] += 1 + 2e-2 * t
+        F[:, 1] += 1 - 1e-2 * t
+        F[:, 2] += 1 - 1e-2 * t
+        return F
+
+    cases = [
+        ("elastic", jm.ElasticBehavior(el), lambda: (strain(SIG0) * 0.5, strain(SIG0))),
+        ("j2_voce", jm.vonMisesIsotropicHardening(el, jm.VoceHardening(350.0, 500.0, 1e3)), lambda: (lambda e: (e * 0.66, e))(strain(350.0))),
+        ("fefp_j2_voce", jm.FeFpJ2Plasticity(el, jm.VoceHardening(500.0, 750.0, 1000.0)), lambda: (fgrad(0.5), fgrad(1.0))),
+    ]
+    for name, beh, make_inputs in cases:
+        m = JAXMaterial(beh, device=dev.index or 0)
+        m.set_data_manager(n)
+        ng, nf = m._info.n_grad, m._info.n_flux
+        g0, g1 = make_inputs()
+        flux = torch.empty((n, nf), dtype=torch.float64, device=dev)
+        ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)
+        m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+        m.data_manager.update()
+        for _ in range(2):
+            m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+        rc, stats = m.stats()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        ab = m.algorithmic_bytes_per_point
+        out[name] = {
+            "Mpoints_per_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 4), "algorithmic_bytes_per_point": ab,
+            "GBs": round(ab * n / ms / 1e6, 1), "frac": round(ab * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+            "plastic_fraction": round(stats["n_plastic"] / n, 4), "not_converged": stats["n_not_converged"],
+        }
+        m.close()
+        del g0, g1, flux, ct
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +161,7 @@ def main():
                     help="j2_voce + --points 12500000 is cfg 3 (sig0=350, sigu=500, b=1e3); the default is cfg 2")
     ap.add_argument("--gather-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     args = ap.parse_args()
 
@@ -275,6 +336,15 @@ def main():
         }
         if gather is not None:
             out["gather_inclusive"] = gather
+        if world == 1 and not args.no_other_laws:
+            try:
+                del eps, flux, ct
+                for m in mats:
+                    m.close()
+                torch.cuda.empty_cache()
+                out["other_laws"] = other_laws(torch, jm, JAXMaterial, dev, n)
+            except Exception as exc:  # context only: never lose the headline line
+                out["other_laws"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline and args.law == "j2_linear":
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), seed)
         print(json.dumps(out), flush=True)
