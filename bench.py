@@ -251,6 +251,24 @@ def main():
     elapsed = t1 - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # device-copy bandwidth of THIS box (read + write bytes of a 2 GiB fp64 copy): the practical
+    # ceiling any streaming kernel sees here; boxes differ by more than 10 %
+    copy_gbs = None
+    if rank == 0:
+        a_ = torch.empty(1 << 28, dtype=torch.float64, device=dev).normal_()
+        b_ = torch.empty_like(a_)
+        for _ in range(3):
+            b_.copy_(a_)
+        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for x, y in cev:
+            x.record()
+            b_.copy_(a_)
+            y.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * a_.numel() * 8 / (float(np.median([x.elapsed_time(y) for x, y in cev])) * 1e-3) / 1e9
+        del a_, b_
+        torch.cuda.empty_cache()
+
     gather = None
     if world > 1:
         cdev = torch.device("cpu") if share else dev  # gloo debug mode keeps collectives on the host
@@ -332,6 +350,8 @@ def main():
                 "kernel": mats[0].kernel_name,
                 "kernel_ms": round(kern_ms, 4),
                 "algorithmic_bytes_per_point": ALG_BYTES,
+                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
+                "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
             },
         }
         if gather is not None:
