@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""J2 kernel vs. a no-arithmetic streaming kernel with the same bytes per point (104 B read, 392 B
-written), interleaved in one process on one box: how close is the constitutive kernel to the
-ceiling of its own traffic mix?"""
+"""Each constitutive kernel vs. a no-arithmetic streaming kernel that moves the same bytes per point
+(two perfectly linear 16 B-per-lane streams), interleaved in one process on one box: how close is
+the kernel to the ceiling of its own traffic mix?"""
 import ctypes as C
 import json
 import os
@@ -11,6 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
@@ -23,40 +24,56 @@ def main():
     n = 10_000_000 // 64 * 64
     dev = torch.device("cuda:0")
     lib = C.CDLL(os.path.join(ROOT, "tools", "libstreammix.so"))
-    lib.stream_mix_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
-    rbuf = torch.randn(n * 13, dtype=torch.float64, device=dev)
-    wbuf = torch.empty(n * 49, dtype=torch.float64, device=dev)
-    eps = [torch.from_numpy(h).to(dev) for h in bench.history(n, 1234)]
-    flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
-    ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+    lib.stream_mix_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     st = torch.cuda.current_stream().cuda_stream
-    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=bench.E, nu=bench.NU), jm.LinearHardening(bench.SIG0, bench.H)))
-    m.set_data_manager(n)
-    for i in range(2):
-        m.integrate_device(eps[i].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+    el = jm.LinearElasticIsotropic(E=bench.E, nu=bench.NU)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    hist = [torch.from_numpy(h).to(dev) for h in bench.history(n, 1234)]
+    Fg = torch.randn((n, 9), generator=gen, device=dev, dtype=torch.float64) * (0.2 * 2e-2)
+    Fg[:, 0] += 1 + 2e-2
+    Fg[:, 1] += 1 - 1e-2
+    Fg[:, 2] += 1 - 1e-2
+    F0 = 0.5 * (Fg + torch.tensor([1.0, 1, 1, 0, 0, 0, 0, 0, 0], device=dev, dtype=torch.float64))
+    cases = [
+        # name, behaviour, (first increment, timed increment), bytes read / written per point
+        ("elastic", jm.ElasticBehavior(el), (hist[1], hist[2]), 48, 336),
+        ("j2_linear", jm.vonMisesIsotropicHardening(el, jm.LinearHardening(bench.SIG0, bench.H)), (hist[1], hist[2]), 104, 392),
+        ("fefp_j2_voce", jm.FeFpJ2Plasticity(el, jm.VoceHardening(500.0, 750.0, 1000.0)), (F0, Fg), 128, 824),
+    ]
+    for name, beh, (g0, g1), rb, wb in cases:
+        m = JAXMaterial(beh)
+        m.set_data_manager(n)
+        ng, nf = m._info.n_grad, m._info.n_flux
+        flux = torch.empty((n, nf), dtype=torch.float64, device=dev)
+        ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)
+        rbuf = torch.randn(n * rb // 8, dtype=torch.float64, device=dev)
+        wbuf = torch.empty(n * wb // 8, dtype=torch.float64, device=dev)
+        m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
-    variants = {"j2_linear": lambda: m.integrate_device(eps[2].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)}
-    for blocks in (1024, 2048, 4096):
-        variants[f"stream_mix_{blocks}"] = (lambda b: (lambda: lib.stream_mix_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, b, st or None)))(blocks)
-    times = {k: [] for k in variants}
-    for r in range(14):
-        for k, fn in variants.items():
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            torch.cuda.synchronize()
-            if r >= 2:
-                times[k].append(e0.elapsed_time(e1))
-    base = None
-    for k, t in times.items():
-        med = float(np.median(t))
-        gbs = 496 * n / med / 1e6
-        if k == "j2_linear":
-            base = gbs
-        print(json.dumps({"kernel": k, "median_ms": round(med, 4), "GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / 8000, 4)}))
-    best = max(496 * n / float(np.median(t)) / 1e6 for k, t in times.items() if k != "j2_linear")
-    print(json.dumps({"j2_over_best_stream_mix": round(base / best, 4)}))
+        variants = {name: lambda: m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)}
+        for blocks in (1024, 2048, 4096):
+            variants[f"probe_{blocks}"] = (lambda b: (lambda: lib.stream_mix_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, rb, wb, b, st or None)))(blocks)
+        times = {k: [] for k in variants}
+        for r in range(12):
+            for k, fn in variants.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                if r >= 2:
+                    times[k].append(e0.elapsed_time(e1))
+        med = {k: float(np.median(t)) for k, t in times.items()}
+        probe = min(v for k, v in med.items() if k != name)
+        moved = (rb + wb) * n
+        print(json.dumps({
+            "law": name, "bytes_moved_per_point": rb + wb, "kernel_ms": round(med[name], 4), "probe_ms": round(probe, 4),
+            "kernel_GBs_moved": round(moved / med[name] / 1e6, 1), "probe_GBs": round(moved / probe / 1e6, 1),
+            "kernel_over_probe": round(probe / med[name], 4),
+        }), flush=True)
+        m.close()
+        del flux, ct, rbuf, wbuf
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
