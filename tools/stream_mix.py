@@ -25,6 +25,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = C.CDLL(os.path.join(ROOT, "tools", "libstreammix.so"))
     lib.stream_mix_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.stream_mix_pipelined_launch.argtypes = lib.stream_mix_launch.argtypes
     st = torch.cuda.current_stream().cuda_stream
     el = jm.LinearElasticIsotropic(E=bench.E, nu=bench.NU)
     gen = torch.Generator(device=dev).manual_seed(7)
@@ -51,8 +52,16 @@ def main():
         m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
         variants = {name: lambda: m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)}
+        if name == "j2_linear":
+            lib.stream_mix_j2_shape_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+            ld = n + 32
+            sa = torch.randn(7 * ld, dtype=torch.float64, device=dev)
+            sb = torch.empty(7 * ld, dtype=torch.float64, device=dev)
+            for blocks in (1024, 2048):
+                variants[f"shape17_{blocks}"] = (lambda b: (lambda: lib.stream_mix_j2_shape_launch(g1.data_ptr(), sa.data_ptr(), sb.data_ptr(), ld, flux.data_ptr(), ct.data_ptr(), n, b, st or None)))(blocks)
         for blocks in (1024, 2048, 4096):
             variants[f"probe_{blocks}"] = (lambda b: (lambda: lib.stream_mix_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, rb, wb, b, st or None)))(blocks)
+            variants[f"probe_pipelined_{blocks}"] = (lambda b: (lambda: lib.stream_mix_pipelined_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, rb, wb, b, st or None)))(blocks)
         times = {k: [] for k in variants}
         for r in range(12):
             for k, fn in variants.items():
@@ -64,12 +73,17 @@ def main():
                 if r >= 2:
                     times[k].append(e0.elapsed_time(e1))
         med = {k: float(np.median(t)) for k, t in times.items()}
-        probe = min(v for k, v in med.items() if k != name)
+        probe = min(v for k, v in med.items() if k.startswith("probe_"))
+        plain = min(v for k, v in med.items() if k.startswith("probe_") and "pipelined" not in k)
+        shape = [v for k, v in med.items() if k.startswith("shape17_")]
+        piped = min(v for k, v in med.items() if "pipelined" in k)
         moved = (rb + wb) * n
         print(json.dumps({
             "law": name, "bytes_moved_per_point": rb + wb, "kernel_ms": round(med[name], 4), "probe_ms": round(probe, 4),
             "kernel_GBs_moved": round(moved / med[name] / 1e6, 1), "probe_GBs": round(moved / probe / 1e6, 1),
             "kernel_over_probe": round(probe / med[name], 4),
+            "probe_plain_ms": round(plain, 4), "probe_pipelined_ms": round(piped, 4),
+            "probe_17_streams_ms": round(min(shape), 4) if shape else None,
         }), flush=True)
         m.close()
         del flux, ct, rbuf, wbuf
