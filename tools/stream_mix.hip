@@ -97,6 +97,16 @@ extern "C" int stream_mix_pipelined_launch(const void* rbuf, void* wbuf, int64_t
   return (int)hipGetLastError();
 }
 
+// Same probe with `lds_bytes` of dynamic LDS per workgroup, only to cap residency (e.g. 70 KiB ->
+// 2 workgroups = 8 waves per CU, the FeFp kernel's occupancy).
+extern "C" int stream_mix_capped_launch(const void* rbuf, void* wbuf, int64_t npoints, int read_bytes_per_point,
+                                        int write_bytes_per_point, int blocks, int lds_bytes, void* stream) {
+  hipLaunchKernelGGL(stream_mix_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream,
+                     (const double2_t*)rbuf, (double2_t*)wbuf, npoints / 64, read_bytes_per_point * 4,
+                     write_bytes_per_point * 4);
+  return (int)hipGetLastError();
+}
+
 extern "C" int stream_mix_launch(const void* rbuf, void* wbuf, int64_t npoints, int read_bytes_per_point,
                                  int write_bytes_per_point, int blocks, void* stream) {
   hipLaunchKernelGGL(stream_mix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,

@@ -52,6 +52,10 @@ def main():
         m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
         variants = {name: lambda: m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)}
+        if name == "fefp_j2_voce":  # probe at the FeFp kernel's occupancy (2 workgroups per CU)
+            lib.stream_mix_capped_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            for blocks in (512, 1024):
+                variants[f"capped8waves_{blocks}"] = (lambda b: (lambda: lib.stream_mix_capped_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, rb, wb, b, 70 * 1024, st or None)))(blocks)
         if name == "j2_linear":
             lib.stream_mix_j2_shape_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
             ld = n + 32
@@ -84,6 +88,7 @@ def main():
             "kernel_over_probe": round(probe / med[name], 4),
             "probe_plain_ms": round(plain, 4), "probe_pipelined_ms": round(piped, 4),
             "probe_17_streams_ms": round(min(shape), 4) if shape else None,
+            "probe_at_8_waves_per_cu_ms": round(min([v for k, v in med.items() if k.startswith("capped8waves_")]), 4) if any(k.startswith("capped8waves_") for k in med) else None,
         }), flush=True)
         m.close()
         del flux, ct, rbuf, wbuf
