@@ -232,6 +232,13 @@ class HIPMaterial:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def _require(self):
         if not self._handle:
             raise DxmError("set_data_manager(ngauss) must be called first")

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--law", default="j2_linear")
     ap.add_argument("--stagger", type=int, default=0, help="extra byte offset k*stagger of the k-th boundary array")
-    ap.add_argument("--env", nargs="+", default=["DXM_BLOCKS_PER_CU=5", "DXM_BLOCKS_PER_CU=4", "DXM_BLOCKS_PER_CU=3", "DXM_BLOCKS_PER_CU=8", "DXM_BLOCKS_PER_CU=5,DXM_NT_STORE=1"])
+    ap.add_argument("--env", nargs="+", default=["DXM_BLOCKS_PER_CU=4", "DXM_BLOCKS_PER_CU=3", "DXM_BLOCKS_PER_CU=5", "DXM_LD_PAD=0", "DXM_LD_PAD=32"])
     a = ap.parse_args()
     import torch
 
