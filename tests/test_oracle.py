@@ -296,3 +296,62 @@ def test_elastic_known_answer_nu_zero():
         sig, Ct = fn(eps, 70e3, 0.0)
         assert np.allclose(sig[0, :3], 70e3 * np.array([1e-3, 0, 0]), rtol=1e-14, atol=1e-12)
         assert np.allclose(Ct[0], 70e3 * np.eye(6), rtol=1e-14)
+
+
+def test_voce_return_mapping_against_an_independent_root_finder():
+    """The scalar return-mapping equation solved by scipy's bracketing root finder (no Newton, no
+    shared code) gives the same plastic multiplier as the oracle's Newton."""
+    from scipy.optimize import brentq
+
+    hard = HARDS["voce"][0]
+    n = 300
+    eps = j2_history(n, seed=13, sig0=hard.sig0)[2]
+    epsp_n, p_n = random_j2_state(n, sig0=hard.sig0)
+    r = onp.j2_update(eps, epsp_n, p_n, E, NU, hard)
+    _, mu = onp.lame(E, NU)
+    e = eps - epsp_n
+    e[:, :3] -= e[:, :3].mean(axis=1)[:, None]
+    seq = np.sqrt(1.5) * 2 * mu * np.sqrt((e * e).sum(axis=1))
+    for i in np.nonzero(r["plastic"])[0][:100]:
+        f = lambda dp: seq[i] - 3 * mu * dp - hard.R(p_n[i] + dp)  # noqa: E731
+        dp = brentq(f, 0.0, seq[i] / (3 * mu), xtol=1e-18, rtol=1e-15)
+        assert abs(dp - (r["p"][i] - p_n[i])) < 1e-12 * max(dp, 1e-12)
+
+
+def test_fefp_solution_satisfies_the_full_tensorial_system():
+    """The oracle solves a reduced 2x2 system in (dp, Ie).  Its result must satisfy the original
+    seven equations of the formulation (plastic consistency, flow rule for dev(be_bar), and
+    det(be_bar) = 1) that the reduction was derived from."""
+    n = 400
+    rng = np.random.default_rng(11)
+    F = np.eye(3) + 0.06 * rng.standard_normal((n, 3, 3))
+    st = onp.fefp_initial_state(n)
+    r0 = onp.fefp_update(onp.tensor_to_nsym(np.eye(3) + 0.03 * rng.standard_normal((n, 3, 3))), st["cpinv"], st["p"], E, NU, HARD_F, tangent=False)
+    r = onp.fefp_update(onp.tensor_to_nsym(F), r0["cpinv"], r0["p"], E, NU, HARD_F, tangent=False)
+    assert r["plastic"].mean() > 0.8
+    _, mu = onp.lame(E, NU)
+    G = onp.mandel_to_tensor(r0["cpinv"])
+    J = onp._det3(F)
+    btr = (J ** (-2 / 3))[:, None, None] * (F @ G @ F.transpose(0, 2, 1))
+    be = onp.mandel_to_tensor(r["be_bar"])
+    dp = r["p"] - r0["p"]
+    I3 = np.eye(3)
+    dev = lambda A: A - (np.trace(A, axis1=1, axis2=2) / 3)[:, None, None] * I3  # noqa: E731
+    s = mu * dev(be)
+    seq = np.sqrt(1.5 * (s * s).sum((1, 2)))
+    pl = r["plastic"]
+    # (1) consistency f = 0 on plastic points, f <= 0 and dp = 0 on elastic ones
+    assert np.abs(seq[pl] - HARD_F.R(r["p"][pl])).max() < 1e-9 * SIG0_F
+    assert (seq[~pl] <= HARD_F.R(r["p"][~pl]) + 1e-9).all() and np.all(dp[~pl] == 0)
+    # (2) flow rule: dev(be - be_trial) + 2 dp tr(be)/3 n = 0 with n = 3 s / (2 seq)
+    nrm = 1.5 * s / seq[:, None, None]
+    res = dev(be - btr) + (2 * dp * np.trace(be, axis1=1, axis2=2) / 3)[:, None, None] * nrm
+    assert np.abs(res[pl]).max() < 1e-13
+    # (3) isochoric elastic left Cauchy-Green tensor
+    assert np.abs(onp._det3(be) - 1).max() < 1e-13
+    # (4) stress: tau = kappa/2 (J^2 - 1) 1 + s,  P = tau F^-T
+    lm, _ = onp.lame(E, NU)
+    kappa = lm + 2 * mu / 3
+    tau = 0.5 * kappa * (J * J - 1)[:, None, None] * I3 + s
+    P = tau @ np.linalg.inv(F).transpose(0, 2, 1)
+    assert np.abs(onp.nsym_to_tensor(r["P"]) - P).max() < 1e-9
