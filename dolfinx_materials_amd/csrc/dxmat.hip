@@ -129,6 +129,7 @@ struct dxm_material {
   double* d_flux = nullptr;
   double* d_isv = nullptr;
   double* d_ct = nullptr;
+  double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
 };
 
 static int build_params(dxm_material* m, const double* p, int np) {
@@ -178,6 +179,17 @@ __global__ void pack_isv_kernel(const double* __restrict__ soa, int64_t ld, int6
   const int64_t i = t / map.n;
   const int k = (int)(t - i * map.n);
   aos[t] = soa[(int64_t)map.slot[k] * ld + i];
+}
+
+// AoS (n, map.n) -> SoA state slots (set_initial_state_dict upload).
+__global__ void unpack_isv_kernel(double* __restrict__ soa, int64_t ld, int64_t n,
+                                  const double* __restrict__ aos, PackMap map) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = n * map.n;
+  if (t >= total) return;
+  const int64_t i = t / map.n;
+  const int k = (int)(t - i * map.n);
+  soa[(int64_t)map.slot[k] * ld + i] = aos[t];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -320,6 +332,7 @@ int dxm_destroy(dxm_material* m) {
   if (m->d_flux) (void)hipFree(m->d_flux);
   if (m->d_isv) (void)hipFree(m->d_isv);
   if (m->d_ct) (void)hipFree(m->d_ct);
+  if (m->d_field) (void)hipFree(m->d_field);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->pipe_stream) (void)hipStreamDestroy(m->pipe_stream);
   delete m;
@@ -393,13 +406,20 @@ int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos)
   const int dim = d.isv_dim[field];
   const int64_t n = m->n;
   if (n == 0) return 0;
-  std::vector<double> tmp((size_t)dim * n);
-  for (int64_t i = 0; i < n; ++i)
-    for (int c = 0; c < dim; ++c) tmp[(size_t)c * n + i] = host_aos[i * dim + c];
   if (which == DXM_S1) if (int rc = materialize_s1(m)) return rc;
-  double* dst = state_of(m, which) + (size_t)d.isv_slot[field] * m->ld;
-  HIP_TRY(hipMemcpy2D(dst, m->ld * sizeof(double), tmp.data(), n * sizeof(double),
-                      n * sizeof(double), dim, hipMemcpyHostToDevice));
+  // upload the AoS block and transpose on the device (a host-side transposition of 6 x 1e7
+  // doubles costs more than the PCIe transfer)
+  if (!m->d_field) HIP_TRY(hipMalloc(&m->d_field, sizeof(double) * n * 6));
+  PackMap map{};
+  map.n = dim;
+  for (int c = 0; c < dim; ++c) map.slot[c] = d.isv_slot[field] + c;
+  hipStream_t st = m->own_stream;
+  HIP_TRY(hipMemcpyAsync(m->d_field, host_aos, sizeof(double) * n * dim, hipMemcpyHostToDevice, st));
+  const int blocks = (int)((n * dim + 255) / 256);
+  hipLaunchKernelGGL(unpack_isv_kernel, dim3(blocks), dim3(256), 0, st, state_of(m, which), m->ld, n,
+                     m->d_field, map);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -412,12 +432,17 @@ int dxm_get_state(dxm_material* m, int which, int field, double* host_aos) {
   const int dim = d.isv_dim[field];
   const int64_t n = m->n;
   if (n == 0) return 0;
-  std::vector<double> tmp((size_t)dim * n);
-  const double* src = state_of(m, which) + (size_t)d.isv_slot[field] * m->ld;
-  HIP_TRY(hipMemcpy2D(tmp.data(), n * sizeof(double), src, m->ld * sizeof(double),
-                      n * sizeof(double), dim, hipMemcpyDeviceToHost));
-  for (int64_t i = 0; i < n; ++i)
-    for (int c = 0; c < dim; ++c) host_aos[i * dim + c] = tmp[(size_t)c * n + i];
+  if (!m->d_field) HIP_TRY(hipMalloc(&m->d_field, sizeof(double) * n * 6));
+  PackMap map{};
+  map.n = dim;
+  for (int c = 0; c < dim; ++c) map.slot[c] = d.isv_slot[field] + c;
+  hipStream_t st = m->own_stream;
+  const int blocks = (int)((n * dim + 255) / 256);
+  hipLaunchKernelGGL(pack_isv_kernel, dim3(blocks), dim3(256), 0, st, state_of(m, which), m->ld, n,
+                     m->d_field, map);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(host_aos, m->d_field, sizeof(double) * n * dim, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return 0;
 }
 
