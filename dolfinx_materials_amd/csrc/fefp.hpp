@@ -66,6 +66,16 @@ __device__ __forceinline__ void mmt(const double* A, const double* B, double* C)
     for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
 }
 
+// 1/x from the hardware approximation plus two Newton-Raphson steps (<= 1 ulp for normal x):
+// 5 instructions instead of the ~14 of the IEEE division sequence; used where the operand is a
+// well-scaled positive quantity (J, |dev be|, Jacobian determinants).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 __device__ __forceinline__ double voce_R(const LawParams& prm, double p) {
   return prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exp(-prm.h2 * p));
 }
@@ -161,14 +171,14 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     {
       double cf[9];
       cof3(F, cf);
-      const double iJ = 1.0 / J;
+      const double iJ = fast_rcp(J);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Fi[r * 3 + c] = cf[c * 3 + r] * iJ;
     }
     const double J23 = cbrt(J * J);
-    const double Jm23 = 1.0 / J23;
+    const double Jm23 = fast_rcp(J23);
     double h[9];  // h[L][m] = J^(-2/3) G[L][N] F[m][N]
     mmt(G, F, h);
 #pragma unroll
@@ -190,7 +200,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     const bool plastic = f_tr > 0.0;
     if (plastic) {
       double sh[9];
-      const double iatr = 1.0 / atr;
+      const double iatr = fast_rcp(atr);
 #pragma unroll
       for (int k = 0; k < 9; ++k) sh[k] = d[k] * iatr;
       const double delta = det3(sh);
@@ -208,7 +218,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         const double j12 = -SQ6 * dp;
         const double j21 = (-aa * Ie + 3.0 * aa * aa * delta) * ap;
         const double j22 = 3.0 * Ie * Ie - 0.5 * aa * aa;
-        const double idet = 1.0 / (j11 * j22 - j12 * j21);
+        const double idet = fast_rcp(j11 * j22 - j12 * j21);
         dp += (-r1 * j22 + r2 * j12) * idet;
         Ie += (-j11 * r2 + j21 * r1) * idet;
         ++iters;
@@ -221,7 +231,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
 #pragma unroll
       for (int k = 0; k < 9; ++k) sdev[k] = a * sh[k];
       // implicit differentiation of (r1, r2) = 0 with respect to (atr, delta)
-      const double igI = 1.0 / (3.0 * Ie * Ie - 0.5 * a * a);
+      const double igI = fast_rcp(3.0 * Ie * Ie - 0.5 * a * a);
       const double dIe_da = (a * Ie - 3.0 * a * a * delta) * igI;
       const double dIe_dd = -(a * a * a) * igI;
       const double r_dp = -ap - SQ6 * Ie - SQ6 * dp * dIe_da * ap;
@@ -231,7 +241,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       mm(h, sh, hs);  // (h s)[L][k]
       mm(h, cs, hc);  // (h cof)[L][k]
       const double trc = cs[0] + cs[4] + cs[8];
-      const double ir_dp = 1.0 / r_dp;
+      const double ir_dp = fast_rcp(r_dp);
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
