@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--law", choices=["j2_linear", "j2_voce"], default="j2_linear",
                     help="j2_voce + --points 12500000 is cfg 3 (sig0=350, sigu=500, b=1e3); the default is cfg 2")
     ap.add_argument("--gather-steps", type=int, default=3)
+    ap.add_argument("--p2p-gather", action="store_true",
+                    help="also time the point-to-point all-gather schedule (sharding.allgather_rows_p2p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -170,7 +172,7 @@ def main():
 
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
-    from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows
+    from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -302,6 +304,23 @@ def main():
             "collective": "RCCL all_gather_into_tensor of stress (N,6) and tangent (N,36), fp64",
             "bytes_received_per_rank": int((world - 1) * n * 42 * 8),
         }
+
+    if world > 1 and args.p2p_gather:
+        def pstep(i):
+            step(i)
+            allgather_rows_p2p(flux.to(cdev), plan, out=g_flux)
+            allgather_rows_p2p(ct.to(cdev), plan, out=g_ct)
+
+        pstep(0)
+        barrier()
+        g0 = time.perf_counter()
+        for i in range(G):
+            pstep(i)
+        barrier()
+        pt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        gather["p2p_schedule"] = {"value": round(n * world * G / float(pt.item()) / 1e6, 3), "unit": "Mpoints/s",
+                                  "ms_per_step": round(float(pt.item()) / G * 1e3, 4)}
 
     if rank == 0:
         value = n * world * K / elapsed / 1e6

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows
+from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p
 from oracle import constitutive_np as onp
 
 from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
@@ -45,6 +45,10 @@ def _worker(rank, world, port, n, q):
         r = onp.j2_update(eps[lo:hi], np.zeros((hi - lo, 6)), np.zeros(hi - lo), E, NU, hard)
         sig = allgather_rows(torch.from_numpy(r["sig"]), plan)
         ct = allgather_rows(torch.from_numpy(r["Ct"].reshape(-1, 36)), plan)
+        # the point-to-point schedule must reassemble the very same arrays
+        sig2 = allgather_rows_p2p(torch.from_numpy(r["sig"]), plan)
+        ct2 = allgather_rows_p2p(torch.from_numpy(r["Ct"].reshape(-1, 36)), plan)
+        assert torch.equal(sig, sig2) and torch.equal(ct, ct2)
         if rank == 0:
             q.put((sig.numpy(), ct.numpy()))
     finally:
