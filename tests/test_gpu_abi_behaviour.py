@@ -136,3 +136,37 @@ def test_device_path_is_graph_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(f, f_ref) and torch.equal(c, c_ref)
+
+
+def test_create_destroy_cycles_do_not_leak_device_memory():
+    torch = pytest.importorskip("torch")
+    from helpers import j2_history
+
+    torch.cuda.synchronize()
+    n = 200_000
+    eps = j2_history(n)[2]
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(30):
+        m = _mat(n)
+        m.integrate(eps)
+        m.data_manager.update()
+        m.get_final_state_dict()
+        m.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 30 create/destroy cycles"
+
+
+def test_several_handles_side_by_side():
+    """Independent handles (e.g. one QuadratureMap per material region) do not interfere."""
+    from oracle import constitutive_np as onp
+    from helpers import j2_history
+
+    n = 5000
+    hs = j2_history(n, seed=3)
+    mats = [_mat(n) for _ in range(4)]
+    outs = [m.integrate(hs[k % 3 + 0] * (1 + 0.1 * k))[0].copy() for k, m in enumerate(mats)]
+    for k, (m, got) in enumerate(zip(mats, outs)):
+        ref = onp.j2_update(hs[k % 3] * (1 + 0.1 * k), np.zeros((n, 6)), np.zeros(n), 70e3, 0.3, onp.LinearHardening(250.0, 5e3))
+        assert np.abs(got - ref["sig"]).max() < 1e-9 * np.abs(ref["sig"]).max()
+        m.close()
