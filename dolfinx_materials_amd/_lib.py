@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdxmat.so")
+LIB_PATH = os.environ.get("DXM_LIB_PATH") or os.path.join(_HERE, "libdxmat.so")  # override: A/B of two builds
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DXM_MAX_STATE_FIELDS = 4

@@ -217,16 +217,13 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
     }
     // ---- 7. coalesced tangent store: entry pair (i, j..j+1) of point q ---------------------------
     if constexpr (!SYM) {
-      // full 6x6, row-major (quadrature_map.py:83-105): 18 x 1 KiB per tile, 18 pairs per point
+      // full 6x6, row-major (quadrature_map.py:83-105): 18 x 1 KiB per tile, 18 pairs per point.
+      // The (q, i, j) of a lane's pair advance by a fixed pattern from one iteration to the next
+      // (64 pairs = 3 points + 10 pairs), so they are carried instead of re-divided; for a full tile
+      // (wave-uniform) the stores are unpredicated and the LDS reads of 3 iterations are issued
+      // together, ahead of the arithmetic (groups of 3: larger groups spill at 128 VGPRs).
       double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 36);
-      const int lim = npts * 18;
-#pragma unroll 6
-      for (int it = 0; it < 18; ++it) {
-        const int k = it * WAVE + lane;   // pair index inside the tile
-        const int q = k / 18;
-        const int r = k - q * 18;
-        const int i = r / 3;
-        const int j = (r - i * 3) * 2;
+      auto entry = [&](int q, int i, int j) -> double2_t {
         double2_t v;
         if constexpr (LAW == LAW_ELASTIC) {
           v.x = ((i < 3 && j < 3) ? lambda : 0.0) + ((i == j) ? 2.0 * mu : 0.0);
@@ -240,7 +237,34 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           v.x = t0 + (k3 * ni) * nj0;
           v.y = t1 + (k3 * ni) * nj1;
         }
-        if (k < lim) gct[k] = v;
+        return v;
+      };
+      if (npts == WAVE) {
+#pragma unroll 1  // a fully unrolled loop gets its (loop-invariant) index arithmetic hoisted out of the
+                  // tile loop: 18 x (q, i, j) live across tiles, which spills at 128 VGPRs
+        for (int g = 0; g < 6; ++g) {
+          double2_t v[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int k = (g * 3 + u) * WAVE + lane;
+            const int q = k / 18;
+            const int r = k - q * 18;
+            const int i = r / 3;
+            v[u] = entry(q, i, (r - i * 3) * 2);
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) gct[(g * 3 + u) * WAVE + lane] = v[u];
+        }
+      } else {
+        const int lim = npts * 18;
+#pragma unroll 1
+        for (int it = 0; it < 18; ++it) {
+          const int k = it * WAVE + lane;
+          const int q = k / 18;
+          const int r = k - q * 18;
+          const int i = r / 3;
+          if (k < lim) gct[k] = entry(q, i, (r - i * 3) * 2);
+        }
       }
     } else {
       // symmetric-packed: the 21 entries (i <= j) of the upper triangle, row-major, per point
