@@ -698,6 +698,7 @@ int dxm_host_free(void* p) {
 
 // ---- gradient evaluation on device ----------------------------------------------------------
 struct dxm_mesh {
+  int nodes_per_cell = 8;   // 8: trilinear hexahedron, 4: linear tetrahedron
   int device = 0;
   int64_t n_nodes = 0, n_cells = 0;
   QuadPoints qp{};
@@ -707,9 +708,9 @@ struct dxm_mesh {
   hipEvent_t grad_done = nullptr;
 };
 
-dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int32_t* conn,
-                               int64_t n_cells, const double* qpoints, int nqp, int device) {
-  if (!coords || !conn || !qpoints || n_nodes <= 0 || n_cells <= 0 || nqp <= 0 || nqp > 27) {
+static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, const int32_t* conn,
+                             int64_t n_cells, const double* qpoints, int nqp, int device) {
+  if (!coords || !conn || n_nodes <= 0 || n_cells <= 0 || nqp <= 0 || nqp > 27 || (npc == 8 && !qpoints)) {
     fail(-1, "invalid mesh arguments");
     return nullptr;
   }
@@ -718,28 +719,40 @@ dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int3
     fail(-2, "no usable HIP device %d (libdxmat has no CPU fallback)", device);
     return nullptr;
   }
-  for (int64_t k = 0; k < n_cells * 8; ++k)
+  for (int64_t k = 0; k < n_cells * npc; ++k)
     if (conn[k] < 0 || conn[k] >= n_nodes) { fail(-1, "connectivity entry %lld out of range", (long long)k); return nullptr; }
   dxm_mesh* mesh = new dxm_mesh();
+  mesh->nodes_per_cell = npc;
   mesh->device = device;
   mesh->n_nodes = n_nodes;
   mesh->n_cells = n_cells;
   mesh->qp.nqp = nqp;
-  for (int q = 0; q < nqp; ++q)
-    for (int d = 0; d < 3; ++d) mesh->qp.xi[q][d] = qpoints[3 * q + d];
+  if (qpoints)
+    for (int q = 0; q < nqp; ++q)
+      for (int d = 0; d < 3; ++d) mesh->qp.xi[q][d] = qpoints[3 * q + d];
   DeviceGuard guard(device);
   bool ok = guard.ok;
   ok = ok && hipMalloc(&mesh->d_coords, sizeof(double) * 3 * n_nodes) == hipSuccess;
-  ok = ok && hipMalloc(&mesh->d_conn, sizeof(int32_t) * 8 * n_cells) == hipSuccess;
+  ok = ok && hipMalloc(&mesh->d_conn, sizeof(int32_t) * npc * n_cells) == hipSuccess;
   ok = ok && hipMalloc(&mesh->d_u, sizeof(double) * 3 * n_nodes) == hipSuccess;
   ok = ok && hipMemcpy(mesh->d_coords, coords, sizeof(double) * 3 * n_nodes, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(mesh->d_conn, conn, sizeof(int32_t) * 8 * n_cells, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(mesh->d_conn, conn, sizeof(int32_t) * npc * n_cells, hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
     fail(-3, "device allocation / upload of the mesh failed");
     dxm_mesh_destroy(mesh);
     return nullptr;
   }
   return mesh;
+}
+
+dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int32_t* conn,
+                               int64_t n_cells, const double* qpoints, int nqp, int device) {
+  return mesh_create(8, coords, n_nodes, conn, n_cells, qpoints, nqp, device);
+}
+
+dxm_mesh* dxm_mesh_create_tet4(const double* coords, int64_t n_nodes, const int32_t* conn,
+                               int64_t n_cells, int nqp, int device) {
+  return mesh_create(4, coords, n_nodes, conn, n_cells, nullptr, nqp, device);
 }
 
 int dxm_mesh_destroy(dxm_mesh* mesh) {
@@ -762,12 +775,21 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
   DEVICE_GUARD(mesh);
   const int64_t npts = mesh->n_cells * mesh->qp.nqp;
   const int blocks = (int)((npts + 255) / 256);
-  if (kind == 0)
-    hipLaunchKernelGGL(hex8_gradient_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
-                       mesh->d_coords, mesh->d_conn, u_dev, mesh->n_cells, mesh->qp, grad_dev);
-  else
-    hipLaunchKernelGGL(hex8_gradient_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
-                       mesh->d_coords, mesh->d_conn, u_dev, mesh->n_cells, mesh->qp, grad_dev);
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (mesh->nodes_per_cell == 4) {
+    if (kind == 0)
+      hipLaunchKernelGGL(tet4_gradient_kernel<0>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
+                         u_dev, mesh->n_cells, mesh->qp.nqp, grad_dev);
+    else
+      hipLaunchKernelGGL(tet4_gradient_kernel<1>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
+                         u_dev, mesh->n_cells, mesh->qp.nqp, grad_dev);
+  } else if (kind == 0) {
+    hipLaunchKernelGGL(hex8_gradient_kernel<0>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
+                       u_dev, mesh->n_cells, mesh->qp, grad_dev);
+  } else {
+    hipLaunchKernelGGL(hex8_gradient_kernel<1>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
+                       u_dev, mesh->n_cells, mesh->qp, grad_dev);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

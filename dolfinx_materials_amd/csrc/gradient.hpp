@@ -1,4 +1,4 @@
-// Gradient evaluation at the Gauss points on the device, for first-order hexahedra: the step
+// Gradient evaluation at the Gauss points on the device, for first-order hexahedra and tetrahedra: the step
 // immediately BEFORE the hot path (reference: QuadratureExpression.eval -> fem.Expression.eval,
 // dolfinx_materials/quadrature_function.py:45-51, called from quadrature_map.py:247-253), so that
 // only the displacement vector (24 B/node) crosses PCIe instead of the strain array (48 B/point).
@@ -79,6 +79,63 @@ hex8_gradient_kernel(const double* __restrict__ coords, const int32_t* __restric
   }
   if constexpr (KIND == 0) {
     const double r = 0.70710678118654752440;  // sqrt(2) * (1/2)
+    double* o = grad + gid * 6;
+    o[0] = H[0]; o[1] = H[4]; o[2] = H[8];
+    o[3] = r * (H[1] + H[3]); o[4] = r * (H[2] + H[6]); o[5] = r * (H[5] + H[7]);
+  } else {
+    double* o = grad + gid * 9;
+    o[0] = 1.0 + H[0]; o[1] = 1.0 + H[4]; o[2] = 1.0 + H[8];
+    o[3] = H[1]; o[4] = H[3]; o[5] = H[2]; o[6] = H[6]; o[7] = H[5]; o[8] = H[7];
+  }
+}
+
+// First-order tetrahedra (affine): the displacement gradient is constant per cell,
+//   H = sum_m u_m (x) grad N_m,  grad N from the inverse of the edge matrix [X1-X0, X2-X0, X3-X0].
+// One thread per Gauss point (the nqp points of a cell repeat the cell value, as a dolfinx
+// quadrature Function of degree > 1 would hold it).
+template <int KIND>
+__global__ void __launch_bounds__(256)
+tet4_gradient_kernel(const double* __restrict__ coords, const int32_t* __restrict__ conn,
+                     const double* __restrict__ u, const int64_t ncells, const int nqp,
+                     double* __restrict__ grad) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncells * nqp) return;
+  const int64_t cell = gid / nqp;
+  int64_t nd[4];
+  double X[4][3], U[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    nd[m] = conn[cell * 4 + m];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { X[m][a] = coords[3 * nd[m] + a]; U[m][a] = u[3 * nd[m] + a]; }
+  }
+  // A[a][d] = X_{d+1}[a] - X_0[a]  (dX_a / dxi_d for the reference tetrahedron)
+  double A[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) A[a * 3 + d] = X[d + 1][a] - X[0][a];
+  double Ai[9];  // Ai[d][a] = dxi_d / dX_a
+  {
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double idet = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    Ai[0] = c00 * idet; Ai[3] = c01 * idet; Ai[6] = c02 * idet;
+    Ai[1] = (A[2] * A[7] - A[1] * A[8]) * idet;
+    Ai[4] = (A[0] * A[8] - A[2] * A[6]) * idet;
+    Ai[7] = (A[1] * A[6] - A[0] * A[7]) * idet;
+    Ai[2] = (A[1] * A[5] - A[2] * A[4]) * idet;
+    Ai[5] = (A[2] * A[3] - A[0] * A[5]) * idet;
+    Ai[8] = (A[0] * A[4] - A[1] * A[3]) * idet;
+  }
+  // H[i][a] = sum_d (U_{d+1}[i] - U_0[i]) Ai[d][a]
+  double H[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      H[i * 3 + a] = (U[1][i] - U[0][i]) * Ai[0 + a] + (U[2][i] - U[0][i]) * Ai[3 + a] + (U[3][i] - U[0][i]) * Ai[6 + a];
+  if constexpr (KIND == 0) {
+    const double r = 0.70710678118654752440;
     double* o = grad + gid * 6;
     o[0] = H[0]; o[1] = H[4]; o[2] = H[8];
     o[3] = r * (H[1] + H[3]); o[4] = r * (H[2] + H[6]); o[5] = r * (H[5] + H[7]);

@@ -21,7 +21,44 @@ def gauss_points_hex(degree=2):
     return np.array([[a, b, c] for a in x for b in x for c in x])
 
 
-class Hex8Mesh:
+class _DeviceMesh:
+    def gradient_device(self, u_ptr, kind, grad_ptr, stream=0):
+        """kind 0: Mandel strain (6); 1: F (9).  Device pointers, asynchronous on ``stream``."""
+        _lib.check(self._lib.dxm_mesh_gradient_device(self._handle, int(u_ptr), int(kind), int(grad_ptr), int(stream) or None))
+
+    @property
+    def npoints(self):
+        return self.n_cells * self.nqp
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.dxm_mesh_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Tet4Mesh(_DeviceMesh):
+    """Linear tetrahedra: coords ``(n_nodes, 3)``, conn ``(n_cells, 4)``; the (constant) cell
+    gradient is repeated at the cell's ``nqp`` Gauss points."""
+
+    def __init__(self, coords, conn, nqp=1, device=0):
+        self._lib = _lib.load()
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.n_nodes, self.n_cells, self.nqp = coords.shape[0], conn.shape[0], int(nqp)
+        self.device = int(device)
+        h = self._lib.dxm_mesh_create_tet4(coords.ctypes.data, self.n_nodes, conn.ctypes.data, self.n_cells, self.nqp, self.device)
+        if not h:
+            raise _lib.DxmError(f"dxm_mesh_create_tet4 failed: {_lib.last_error()}")
+        self._handle = h
+
+
+class Hex8Mesh(_DeviceMesh):
     """coords ``(n_nodes, 3)``; conn ``(n_cells, 8)`` with the corner order
     ``(-,-,-)(+,-,-)(+,+,-)(-,+,-)(-,-,+)(+,-,+)(+,+,+)(-,+,+)``; Gauss point ``q`` of cell ``c``
     is point ``c * nqp + q``."""
@@ -39,22 +76,3 @@ class Hex8Mesh:
         if not h:
             raise _lib.DxmError(f"dxm_mesh_create_hex8 failed: {_lib.last_error()}")
         self._handle = h
-
-    @property
-    def npoints(self):
-        return self.n_cells * self.nqp
-
-    def gradient_device(self, u_ptr, kind, grad_ptr, stream=0):
-        """kind 0: Mandel strain (6); 1: F (9).  Device pointers, asynchronous on ``stream``."""
-        _lib.check(self._lib.dxm_mesh_gradient_device(self._handle, int(u_ptr), int(kind), int(grad_ptr), int(stream) or None))
-
-    def close(self):
-        if getattr(self, "_handle", None):
-            self._lib.dxm_mesh_destroy(self._handle)
-            self._handle = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass

@@ -163,7 +163,7 @@ const char* dxm_kernel_name(const dxm_material* m);
 void* dxm_host_alloc(uint64_t bytes);
 int dxm_host_free(void* p);
 
-/* ---- gradient evaluation on device (the step before the path; first-order hexahedra) ---------
+/* ---- gradient evaluation on device (the step before the path; first-order hexahedra and tetrahedra) --
  * Replaces, for the device-resident flow, QuadratureExpression.eval -> fem.Expression.eval
  * (quadrature_function.py:45-51; consumer quadrature_map.py:247-253): only the displacement
  * vector crosses PCIe, the (npoints, n_grad) gradient array is produced in HBM in the layout
@@ -173,6 +173,10 @@ typedef struct dxm_mesh dxm_mesh; /* opaque: device copies of coordinates and co
  * (-,-,-)(+,-,-)(+,+,-)(-,+,-)(-,-,+)(+,-,+)(+,+,+)(-,+,+); qpoints (nqp,3) in [-1,1]^3, nqp <= 27. */
 dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int32_t* conn,
                                int64_t n_cells, const double* qpoints, int nqp, int device);
+/* First-order tetrahedra: conn (n_cells,4); the gradient is constant per cell and repeated at the
+ * cell's nqp Gauss points (point = cell * nqp + q). */
+dxm_mesh* dxm_mesh_create_tet4(const double* coords, int64_t n_nodes, const int32_t* conn,
+                               int64_t n_cells, int nqp, int device);
 int dxm_mesh_destroy(dxm_mesh* mesh);
 int64_t dxm_mesh_npoints(const dxm_mesh* mesh);
 /* kind 0: Mandel strain (6); kind 1: deformation gradient F = I + grad u (9).  u_dev: device

@@ -110,3 +110,39 @@ def test_integrate_displacement_equals_integrate_of_host_gradient(law):
     scale = np.abs(fb).max()
     assert np.abs(fa - fb).max() < 1e-9 * scale and np.abs(ca - cb).max() < 1e-9 * np.abs(cb).max()
     assert np.abs(ia - ib).max() < 1e-12
+
+
+def test_tet4_gradient_matches_host_and_drives_the_update():
+    """Linear tetrahedra (each cube of the hex mesh split into 6): device gradient == host affine
+    gradient, repeated at the cell's 4 Gauss points; integrate_displacement == integrate."""
+    torch = pytest.importorskip("torch")
+    from dolfinx_materials_amd.gradient import Tet4Mesh
+
+    m, coords = make_mesh(3, distort=0.2, seed=4)
+    # Kuhn split of every hexahedron (corner order of HexMesh.conn) into 6 tetrahedra along 0-6
+    kuhn = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]
+    conn = np.concatenate([m.conn[:, list(k)] for k in kuhn], axis=0).astype(np.int32)
+    rng = np.random.default_rng(8)
+    u = 2e-2 * m.h * rng.standard_normal(m.ndof)
+    X, U = coords[conn], u.reshape(-1, 3)[conn]
+    A = (X[:, 1:] - X[:, :1]).transpose(0, 2, 1)           # dX_a/dxi_d
+    dU = (U[:, 1:] - U[:, :1]).transpose(0, 2, 1)          # du_i/dxi_d
+    H = dU @ np.linalg.inv(A)
+    nqp = 4
+    Hq = np.repeat(H, nqp, axis=0)
+    e = 0.5 * (Hq + Hq.transpose(0, 2, 1))
+    eps_ref = np.stack([e[:, 0, 0], e[:, 1, 1], e[:, 2, 2], SQ2 * e[:, 0, 1], SQ2 * e[:, 0, 2], SQ2 * e[:, 1, 2]], axis=1)
+    mesh = Tet4Mesh(coords, conn, nqp=nqp)
+    dev = torch.device("cuda:0")
+    eps = torch.empty((mesh.npoints, 6), dtype=torch.float64, device=dev)
+    mesh.gradient_device(torch.from_numpy(u).to(dev).data_ptr(), 0, eps.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.abs(eps.cpu().numpy() - eps_ref).max() < 1e-13
+    beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=70e3, nu=0.3), jm.LinearHardening(250.0, 5e3))
+    a, b = JAXMaterial(beh), JAXMaterial(beh)
+    a.set_data_manager(mesh.npoints)
+    b.set_data_manager(mesh.npoints)
+    fa, _, ca = a.integrate_displacement(mesh, u)
+    fb, _, cb = b.integrate(eps_ref)
+    assert a.last_stats["n_plastic"] > 0
+    assert np.abs(fa - fb).max() < 1e-9 * np.abs(fb).max() and np.abs(ca - cb).max() < 1e-9 * np.abs(cb).max()
