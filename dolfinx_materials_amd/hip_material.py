@@ -302,9 +302,13 @@ class HIPMaterial:
     def integrate(self, gradients, dt=0):
         """``(N, ng)`` host gradients -> ``(flux (N,nf), isv (N,sum isv), Ct (N,nf,ng))``.
 
-        Same contract as ``JAXMaterial.integrate`` (``jaxmat.py:208-234``); the returned arrays
-        are fresh for flux (it becomes the s1 mirror) and reused buffers for isv / Ct, valid
-        until the next call (the reference returns views too: ``generic.py:185-189``).
+        Same contract as ``JAXMaterial.integrate`` (``jaxmat.py:208-234``).  The returned arrays
+        are page-locked buffers owned by the material and reused from call to call (the flux
+        alternates between two so that the s0 mirror survives): they are valid until the next
+        ``integrate``, which is how ``QuadratureMap.update`` consumes them -- it copies into the
+        quadrature Functions right away (``utils.py:140-143``); the reference returns views of its
+        state manager too (``generic.py:185-189``).  The gradient array is kept by reference as
+        the s1 gradient mirror.
         """
         h = self._require()
         ng, nf = self._info.n_grad, self._info.n_flux
