@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("DXM_LIB_PATH") or os.path.join(_HERE, "libdxmat.so") 
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DXM_MAX_STATE_FIELDS = 4
-LAW_ELASTIC_ISO, LAW_J2_LINEAR, LAW_J2_VOCE, LAW_FEFP_J2_VOCE = 0, 1, 2, 3
+LAW_ELASTIC_ISO, LAW_J2_LINEAR, LAW_J2_VOCE, LAW_FEFP_J2_VOCE, LAW_FEFP_J2_LINEAR = 0, 1, 2, 3, 4
 S0, S1 = 0, 1
 
 

@@ -87,7 +87,9 @@ static const LawDesc kLaws[DXM_LAW_COUNT] = {
      "small_strain_kernel<2"},
     // field 2 is hidden state: the isochoric inverse plastic right Cauchy-Green tensor
     {9, 9, 5, 2, 3, {1, 6, 6, 0}, {"p", "be_bar", "cp_bar_inv", nullptr}, {FEFP_SLOT_P, FEFP_SLOT_BE, FEFP_SLOT_CPI, 0}, FEFP_NSLOTS, 976,
-     "fefp_kernel"},
+     "fefp_kernel<1"},
+    {9, 9, 4, 2, 3, {1, 6, 6, 0}, {"p", "be_bar", "cp_bar_inv", nullptr}, {FEFP_SLOT_P, FEFP_SLOT_BE, FEFP_SLOT_CPI, 0}, FEFP_NSLOTS, 976,
+     "fefp_kernel<0"},
 };
 
 static int tangent_size(const dxm_material* m);
@@ -144,7 +146,8 @@ static int build_params(dxm_material* m, const double* p, int np) {
   q.sig0 = 1.0;
   switch (m->law) {
     case DXM_LAW_ELASTIC_ISO: break;
-    case DXM_LAW_J2_LINEAR: q.sig0 = p[2]; q.h1 = p[3]; break;
+    case DXM_LAW_J2_LINEAR:
+    case DXM_LAW_FEFP_J2_LINEAR: q.sig0 = p[2]; q.h1 = p[3]; break;
     case DXM_LAW_J2_VOCE:
     case DXM_LAW_FEFP_J2_VOCE: q.sig0 = p[2]; q.h1 = p[3]; q.h2 = p[4]; break;
   }
@@ -231,7 +234,7 @@ static int init_state(dxm_material* m) {
   const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
   for (int w = 0; w < 2; ++w) {
     HIP_TRY(hipMemsetAsync(m->state[w], 0, bytes, m->own_stream));
-    if (m->law == DXM_LAW_FEFP_J2_VOCE) {
+    if (kLaws[m->law].n_grad == 9) {
       // be_bar = Cp^-1 = identity: unstressed natural configuration
       // (demos/jax/finite_strain_elastoplasticity/finite_strain_elastoplasticity.py:181)
       const int ones[6] = {FEFP_SLOT_BE + 0, FEFP_SLOT_BE + 1, FEFP_SLOT_BE + 2,
@@ -295,7 +298,8 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
       case DXM_LAW_ELASTIC_ISO: fn = (const void*)small_strain_kernel<LAW_ELASTIC, false>; break;
       case DXM_LAW_J2_LINEAR: fn = (const void*)small_strain_kernel<LAW_J2_LINEAR, false>; break;
       case DXM_LAW_J2_VOCE: fn = (const void*)small_strain_kernel<LAW_J2_VOCE, false>; break;
-      default: fn = (const void*)fefp_kernel; break;
+      case DXM_LAW_FEFP_J2_LINEAR: fn = (const void*)fefp_kernel<0>; break;
+      default: fn = (const void*)fefp_kernel<1>; break;
     }
     // residency from the kernel's own resources (the occupancy API over-reports on ROCm 7.2):
     // waves/SIMD by allocated VGPRs (512-entry file, granule 8), workgroups by LDS (160 KiB/CU)
@@ -350,7 +354,7 @@ int dxm_set_params(dxm_material* m, const double* params, int n_params) {
 int dxm_set_tangent_layout(dxm_material* m, int layout) {
   if (!m) return fail(-1, "null handle");
   if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_SYM) return fail(-1, "unknown tangent layout %d", layout);
-  if (layout == DXM_TANGENT_SYM && m->law == DXM_LAW_FEFP_J2_VOCE)
+  if (layout == DXM_TANGENT_SYM && kLaws[m->law].n_grad == 9)
     return fail(-1, "the FeFp tangent dP/dF is not symmetric: only DXM_TANGENT_FULL is available");
   m->sym_tangent = (layout == DXM_TANGENT_SYM);
   return 0;
@@ -500,7 +504,11 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
     case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
     case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
     case DXM_LAW_FEFP_J2_VOCE:
-      hipLaunchKernelGGL(fefp_kernel, dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad,
+      hipLaunchKernelGGL(fefp_kernel<1>, dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad,
+                         m->state[0] + off, m->state[1] + off, m->ld, flux, ct, m->d_stats + stats_off);
+      break;
+    case DXM_LAW_FEFP_J2_LINEAR:
+      hipLaunchKernelGGL(fefp_kernel<0>, dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad,
                          m->state[0] + off, m->state[1] + off, m->ld, flux, ct, m->d_stats + stats_off);
       break;
     default: return fail(-1, "law %d not launchable", m->law);

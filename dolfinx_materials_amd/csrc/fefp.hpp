@@ -76,13 +76,21 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
-__device__ __forceinline__ double voce_R(const LawParams& prm, double p) {
-  return prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exp(-prm.h2 * p));
-}
-__device__ __forceinline__ double voce_dR(const LawParams& prm, double p) {
-  return (prm.h1 - prm.sig0) * prm.h2 * exp(-prm.h2 * p);
+// hardening law and its slope, sharing the exponential
+template <int HARD>
+__device__ __forceinline__ void hardening(const LawParams& prm, double p, double& R, double& dR) {
+  if constexpr (HARD == 0) {
+    R = prm.sig0 + prm.h1 * p;
+    dR = prm.h1;
+  } else {
+    const double ex = exp(-prm.h2 * p);
+    R = prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - ex);
+    dR = (prm.h1 - prm.sig0) * prm.h2 * ex;
+  }
 }
 
+// HARD: 0 = linear hardening R = sig0 + H p (prm.h1 = H), 1 = Voce (prm.h1 = sigu, prm.h2 = b)
+template <int HARD>
 __global__ void __launch_bounds__(BLOCK, 2)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
             const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
@@ -191,7 +199,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
 #pragma unroll
     for (int k = 0; k < 9; ++k) atr2 += d[k] * d[k];
     const double atr = sqrt(atr2);
-    const double f_tr = SQ32 * mu * atr - voce_R(prm, p_n);
+    double R_n, dR_n;
+    hardening<HARD>(prm, p_n, R_n, dR_n);
+    const double f_tr = SQ32 * mu * atr - R_n;
 
     // ---- 3. return mapping ---------------------------------------------------------------------
     double dp = 0.0, Ie = Itr, a = atr, theta = 1.0;
@@ -207,13 +217,14 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       const double tol1 = (prm.tol / fabs(prm.sig0)) * fmax(fabs(prm.sig0), SQ32 * mu * atr);
       unsigned iters = 0;
       for (int it = 0;; ++it) {
-        const double ex = exp(-prm.h2 * (p_n + dp));
-        const double aa = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - ex)) * imu;
+        double R_k, dR_k;
+        hardening<HARD>(prm, p_n + dp, R_k, dR_k);
+        const double aa = SQ23 * R_k * imu;
         const double r1 = atr - aa - SQ6 * dp * Ie;
         const double r2 = Ie * Ie * Ie - 0.5 * aa * aa * Ie + aa * aa * aa * delta - 1.0;
         if (fabs(SQ32 * mu * r1) <= tol1 && fabs(r2) <= 1e-14) break;
         if (it >= prm.maxit) { if (valid) ++c_notconv; break; }
-        const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * ex) * imu;
+        const double ap = SQ23 * dR_k * imu;
         const double j11 = -ap - SQ6 * Ie;
         const double j12 = -SQ6 * dp;
         const double j21 = (-aa * Ie + 3.0 * aa * aa * delta) * ap;
@@ -224,9 +235,10 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         ++iters;
       }
       const double p_new = p_n + dp;
-      const double exn = exp(-prm.h2 * p_new);
-      a = SQ23 * (prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exn)) * imu;
-      const double ap = SQ23 * ((prm.h1 - prm.sig0) * prm.h2 * exn) * imu;
+      double R_1, dR_1;
+      hardening<HARD>(prm, p_new, R_1, dR_1);
+      a = SQ23 * R_1 * imu;
+      const double ap = SQ23 * dR_1 * imu;
       theta = a * iatr;
 #pragma unroll
       for (int k = 0; k < 9; ++k) sdev[k] = a * sh[k];

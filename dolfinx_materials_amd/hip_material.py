@@ -275,11 +275,11 @@ class HIPMaterial:
                 self._grad[0] = a.copy()
             elif key == self._fname:
                 self._flux[0] = a.copy()
-            elif key == "be_bar" and self.behavior.law == _lib.LAW_FEFP_J2_VOCE:
+            elif key == "be_bar" and self._info.n_grad == 9:
                 continue  # handled below together with F
             else:
                 _lib.check(self._lib.dxm_set_state(h, S0, isv_names.index(key), _ptr(a)))
-        if self.behavior.law == _lib.LAW_FEFP_J2_VOCE and ("be_bar" in state or self._gname in state):
+        if self._info.n_grad == 9 and ("be_bar" in state or self._gname in state):
             # the kernel's state is the isochoric Cp^-1 (hidden field 2), rebuilt from (F_n, be_bar_n)
             from .conventions import cp_bar_inv_from_be_bar
 

@@ -132,17 +132,15 @@ class vonMisesIsotropicHardening(SmallStrainBehavior):
 class FeFpJ2Plasticity(FiniteStrainBehavior):
     """Finite-strain FeFp J2 plasticity (``tests/test_FeFp_jax.py:17-19``); Voce hardening."""
 
-    law = _lib.LAW_FEFP_J2_VOCE
-
     def __init__(self, elasticity: LinearElasticIsotropic, yield_stress):
         self.elasticity = elasticity
-        y = _check_hardening(yield_stress)
-        if isinstance(y, LinearHardening):
-            raise NotImplementedError("FeFpJ2Plasticity is built for VoceHardening")
-        self.yield_stress = y
+        self.yield_stress = _check_hardening(yield_stress)
+        self.law = _lib.LAW_FEFP_J2_LINEAR if isinstance(yield_stress, LinearHardening) else _lib.LAW_FEFP_J2_VOCE
 
     def params(self):
         e, y = self.elasticity, self.yield_stress
+        if isinstance(y, LinearHardening):
+            return [e.E, e.nu, y.sig0, y.H]
         return [e.E, e.nu, y.sig0, y.sigu, y.b]
 
     def flat_properties(self):

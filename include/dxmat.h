@@ -60,7 +60,10 @@ enum {
    * (jaxmat FeFpJ2Plasticity as constructed in tests/test_FeFp_jax.py:7-20).
    * params = [E, nu, sig0, sigu, b] */
   DXM_LAW_FEFP_J2_VOCE = 3,
-  DXM_LAW_COUNT = 4
+  /* the same finite-strain law with linear hardening R(p) = sig0 + H p.
+   * params = [E, nu, sig0, H] */
+  DXM_LAW_FEFP_J2_LINEAR = 4,
+  DXM_LAW_COUNT = 5
 };
 
 /* Which state: s0 = beginning of the increment, s1 = end (generic.py:204-216, jaxmat.py:30-43). */

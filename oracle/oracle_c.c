@@ -121,7 +121,7 @@ int orc_max_threads(void) {
 }
 
 /* ------------------------------------------------------------------------------------------
- * law 3: finite-strain FeFp J2 plasticity with Voce hardening (PARITY UNPINNED: the reference
+ * laws 3/4: finite-strain FeFp J2 plasticity, Voce (kind 1: su, b) or linear (kind 0: su = H) hardening (PARITY UNPINNED: the reference
  * only fixes the interface, jaxmat.py:170-186 / tests/test_FeFp_jax.py:7-31; the algorithm is the
  * build's own choice, restated from oracle/constitutive_np.py::fefp_update -- same 2x2 Newton in
  * (dp, Ie), tangent by nine hand-written JVPs through the algorithm).
@@ -162,7 +162,7 @@ static void t_to_mandel(const double T[3][3], double* v) {
 }
 
 int64_t orc_fefp(int64_t n, const double* F9, const double* cpinv_n, const double* p_n, double E, double nu,
-                 double s0, double su, double b, double rtol, double* P9, double* be_bar, double* cpinv,
+                 int kind, double s0, double su, double b, double rtol, double* P9, double* be_bar, double* cpinv,
                  double* p_out, double* ct, int64_t* n_plastic, int nthreads) {
   double lambda, mu;
   lame(E, nu, &lambda, &mu);
@@ -191,7 +191,7 @@ int64_t orc_fefp(int64_t n, const double* F9, const double* cpinv_n, const doubl
       for (int j = 0; j < 3; ++j) { d[i][j] = btr[i][j] - (i == j ? Itr : 0.0); atr2 += d[i][j] * d[i][j]; }
     const double atr = sqrt(atr2);
     const double pn = p_n[q];
-    const int plastic = SQ32 * mu * atr - hard_R(1, s0, su, b, pn) > 0.0;
+    const int plastic = SQ32 * mu * atr - hard_R(kind, s0, su, b, pn) > 0.0;
     double dp = 0, Ie = Itr, a = atr, delta = 0;
     if (plastic) {
       ++nplast;
@@ -200,12 +200,12 @@ int64_t orc_fefp(int64_t n, const double* F9, const double* cpinv_n, const doubl
       delta = det3(sh);
       const double tol1 = rtol * fmax(s0, SQ32 * mu * atr);
       for (int it = 0;; ++it) {
-        const double aa = SQ23 * hard_R(1, s0, su, b, pn + dp) / mu;
+        const double aa = SQ23 * hard_R(kind, s0, su, b, pn + dp) / mu;
         const double r1 = atr - aa - SQ6 * dp * Ie;
         const double r2 = Ie * Ie * Ie - 0.5 * aa * aa * Ie + aa * aa * aa * delta - 1.0;
         if (fabs(SQ32 * mu * r1) <= tol1 && fabs(r2) <= 1e-14) break;
         if (it >= ORC_MAXIT) { ++notconv; break; }
-        const double ap = SQ23 * hard_dR(1, s0, su, b, pn + dp) / mu;
+        const double ap = SQ23 * hard_dR(kind, s0, su, b, pn + dp) / mu;
         const double j11 = -ap - SQ6 * Ie, j12 = -SQ6 * dp;
         const double j21 = (-aa * Ie + 3 * aa * aa * delta) * ap, j22 = 3 * Ie * Ie - 0.5 * aa * aa;
         const double det = j11 * j22 - j12 * j21;
@@ -213,7 +213,7 @@ int64_t orc_fefp(int64_t n, const double* F9, const double* cpinv_n, const doubl
         dp += ddp;
         Ie += dIe;
       }
-      a = SQ23 * hard_R(1, s0, su, b, pn + dp) / mu;
+      a = SQ23 * hard_R(kind, s0, su, b, pn + dp) / mu;
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) be[i][j] = (i == j ? Ie : 0.0) + a * sh[i][j];
     } else {
@@ -236,7 +236,7 @@ int64_t orc_fefp(int64_t n, const double* F9, const double* cpinv_n, const doubl
     if (!ct) continue;
     /* tangent: column (k,l) = derivative of the algorithm in the direction dF = e_k (x) e_l */
     const double p1 = pn + dp;
-    const double ap = SQ23 * hard_dR(1, s0, su, b, p1) / mu;
+    const double ap = SQ23 * hard_dR(kind, s0, su, b, p1) / mu;
     double cs[3][3];
     cof3(sh, cs);
     const double gI = 3 * Ie * Ie - 0.5 * a * a;

@@ -29,7 +29,7 @@ def load():
         lib.orc_j2.restype = i64
         lib.orc_j2.argtypes = [i64, vp, vp, vp, dbl, dbl, ci, dbl, dbl, dbl, dbl, vp, vp, vp, vp, C.POINTER(i64), ci]
         lib.orc_fefp.restype = i64
-        lib.orc_fefp.argtypes = [i64, vp, vp, vp, dbl, dbl, dbl, dbl, dbl, dbl, vp, vp, vp, vp, vp, C.POINTER(i64), ci]
+        lib.orc_fefp.argtypes = [i64, vp, vp, vp, dbl, dbl, ci, dbl, dbl, dbl, dbl, vp, vp, vp, vp, vp, C.POINTER(i64), ci]
         lib.orc_max_threads.restype = ci
         _lib = lib
     return _lib
@@ -65,14 +65,15 @@ def j2(eps, epsp_n, p_n, E, nu, kind, sig0, h1, h2=0.0, rtol=1e-14, nthreads=1, 
     return out
 
 
-def fefp(F9, cpinv_n, p_n, E, nu, sig0, sigu, b, rtol=1e-14, nthreads=1, out=None, tangent=True):
+def fefp(F9, cpinv_n, p_n, E, nu, sig0, sigu, b=0.0, rtol=1e-14, nthreads=1, out=None, tangent=True, kind=1):
+    """kind 1: Voce (sigu, b); kind 0: linear hardening (sigu holds H)."""
     F9, cpinv_n, p_n = _c(F9), _c(cpinv_n), _c(p_n).reshape(-1)
     n = F9.shape[0]
     if out is None:
         out = dict(P=np.empty((n, 9)), be_bar=np.empty((n, 6)), cpinv=np.empty((n, 6)), p=np.empty(n), Ct=np.empty((n, 9, 9)))
     npl = C.c_int64(0)
     notconv = load().orc_fefp(
-        n, F9.ctypes.data, cpinv_n.ctypes.data, p_n.ctypes.data, E, nu, sig0, sigu, b, rtol,
+        n, F9.ctypes.data, cpinv_n.ctypes.data, p_n.ctypes.data, E, nu, kind, sig0, sigu, b, rtol,
         out["P"].ctypes.data, out["be_bar"].ctypes.data, out["cpinv"].ctypes.data, out["p"].ctypes.data,
         out["Ct"].ctypes.data if tangent else None, C.byref(npl), nthreads,
     )

@@ -37,6 +37,7 @@ def test_law_table():
         _lib.LAW_J2_LINEAR: (6, 6, 4, {"p": 1, "epsp": 6}, 496),
         _lib.LAW_J2_VOCE: (6, 6, 5, {"p": 1, "epsp": 6}, 496),
         _lib.LAW_FEFP_J2_VOCE: (9, 9, 5, {"p": 1, "be_bar": 6}, 976),
+        _lib.LAW_FEFP_J2_LINEAR: (9, 9, 4, {"p": 1, "be_bar": 6}, 976),
     }
     for law, (ng, nf, npar, isv, alg) in expect.items():
         i = _lib.law_info(law)

@@ -114,3 +114,25 @@ def test_large_deformation_single_step():
     assert relerr(isv[safe, 0], ref["p"][safe]) < 1e-10
     be = onp.mandel_to_tensor(isv[:, 1:])
     assert np.abs(np.linalg.det(be) - 1).max() < 1e-12
+
+
+def test_fefp_with_linear_hardening_matches_oracle():
+    """FeFpJ2Plasticity accepts either hardening law (law id 4: R = sig0 + H p)."""
+    n = 700
+    hard = onp.LinearHardening(400.0, 2e3)
+    m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(400.0, 2e3)))
+    m.set_data_manager(n)
+    st = onp.fefp_initial_state(n)
+    cp, p = st["cpinv"], st["p"]
+    for k, F in enumerate(fefp_path(n)):
+        if k % 3:
+            continue
+        P, isv, Ct = m.integrate(F)
+        ref = onp.fefp_update(F, cp, p, E, NU, hard)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * 400.0
+        assert relerr(P[safe], ref["P"][safe]) < TIGHT and relerr(Ct[safe], ref["Ct"][safe]) < TIGHT
+        assert np.abs(isv[safe, 0] - ref["p"][safe]).max() < 1e-16 + TIGHT * max(ref["p"].max(), 1e-300)
+        assert m.last_stats["n_not_converged"] == 0
+        m.data_manager.update()
+        cp, p = ref["cpinv"], ref["p"]
+    assert ref["plastic"].all()

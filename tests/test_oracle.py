@@ -355,3 +355,17 @@ def test_fefp_solution_satisfies_the_full_tensorial_system():
     tau = 0.5 * kappa * (J * J - 1)[:, None, None] * I3 + s
     P = tau @ np.linalg.inv(F).transpose(0, 2, 1)
     assert np.abs(onp.nsym_to_tensor(r["P"]) - P).max() < 1e-9
+
+
+def test_fefp_c_oracle_linear_hardening():
+    n = 129
+    hard = onp.LinearHardening(400.0, 2e3)
+    st = onp.fefp_initial_state(n)
+    cp, p = st["cpinv"], st["p"]
+    for F in fefp_path(n)[::4]:
+        r = onp.fefp_update(F, cp, p, E, NU, hard)
+        c = oracle_c.fefp(F, cp, p, E, NU, 400.0, 2e3, kind=0)
+        safe = np.abs(r["f_trial"]) > 1e-9 * 400.0
+        for key in ("P", "Ct", "p"):
+            assert np.abs(c[key][safe] - r[key][safe]).max() <= 1e-12 * max(np.abs(r[key]).max(), 1e-300), key
+        cp, p = r["cpinv"], r["p"]
