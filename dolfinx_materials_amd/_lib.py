@@ -55,6 +55,7 @@ _h = C.c_void_p
 #: every symbol include/dxmat.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "dxm_abi_version": (C.c_int, []),
+    "dxm_has_custom_hardening": (C.c_int, []),
     "dxm_last_error": (C.c_char_p, []),
     "dxm_device_count": (C.c_int, []),
     "dxm_law_info_get": (C.c_int, [C.c_int, C.POINTER(LawInfo)]),
@@ -138,23 +139,68 @@ def load() -> C.CDLL:
             "dolfinx_materials_amd has no CPU fallback."
         )
     _share_hip_runtime_with_torch()
-    lib = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
 
 
-def last_error() -> str:
-    return (load().dxm_last_error() or b"").decode()
+_custom_libs = {}
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def check(rc: int) -> int:
+def load_custom(expr_R: str, expr_dR: str) -> C.CDLL:
+    """Build (once, cached under ``dolfinx_materials_amd/_jit/``) and load a copy of libdxmat whose
+    "voce" kernels integrate a user-supplied isotropic hardening law: ``expr_R`` / ``expr_dR`` are C
+    expressions for R(p) and dR/dp in the variables ``p``, ``sig0`` and ``c[0..5]``.  This is the
+    counterpart of handing a Python ``yield_stress(p)`` callable to jaxmat and letting ``jax.jit``
+    compile it on the first pass (``tests/test_FeFp_jax.py:14-19``, ``jaxmat.py:214-216``): here
+    hipcc compiles the fused gfx950 kernels with the law inlined (a few seconds)."""
+    import hashlib
+
+    key = (expr_R, expr_dR)
+    if key in _custom_libs:
+        return _custom_libs[key]
+    srcs = [os.path.join(CSRC_DIR, f) for f in sorted(os.listdir(CSRC_DIR)) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "dxmat.h"))
+    h = hashlib.sha1()
+    h.update(expr_R.encode() + b"\0" + expr_dR.encode())
+    for f in srcs:
+        h.update(open(f, "rb").read())
+    out_dir = os.path.join(_HERE, "_jit", h.hexdigest()[:16])
+    out = os.path.join(out_dir, "libdxmat_custom.so")
+    if not os.path.exists(out):
+        os.makedirs(out_dir, exist_ok=True)
+        cmd = [
+            HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-shared",
+            "-DDXM_CUSTOM_HARDENING", f"-DDXM_CUSTOM_R={expr_R}", f"-DDXM_CUSTOM_DR={expr_dR}",
+            "-o", out + ".tmp", os.path.join(CSRC_DIR, "dxmat.hip"),
+        ]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise DxmError(f"compiling the custom hardening law failed:\n{r.stderr[-2000:]}")
+        os.replace(out + ".tmp", out)
+    _share_hip_runtime_with_torch()
+    lib = _bind(C.CDLL(out))
+    assert lib.dxm_has_custom_hardening() == 1
+    _custom_libs[key] = lib
+    return lib
+
+
+def last_error(lib=None) -> str:
+    return ((lib or load()).dxm_last_error() or b"").decode()
+
+
+def check(rc: int, lib=None) -> int:
     """Raise on hard errors (<0); pass soft codes (>=0) through."""
     if rc < 0:
-        raise DxmError(f"libdxmat error {rc}: {last_error()}")
+        raise DxmError(f"libdxmat error {rc}: {last_error(lib)}")
     return rc
 
 
@@ -192,7 +238,8 @@ class PinnedArray:
             pass
 
 
-def law_info(law: int) -> LawInfo:
+def law_info(law: int, lib=None) -> LawInfo:
     info = LawInfo()
-    check(load().dxm_law_info_get(law, C.byref(info)))
+    lib = lib or load()
+    check(lib.dxm_law_info_get(law, C.byref(info)), lib)
     return info

@@ -20,7 +20,28 @@ struct LawParams {
   double tol;      // absolute residual tolerance of the local Newton (= rtol * sig0)
   int32_t maxit;   // local Newton iteration cap
   int32_t pad;
+  double c[6];     // parameters of a user-supplied hardening law (JIT builds only, see below)
 };
+
+// A library built with -DDXM_CUSTOM_HARDENING replaces the Voce law of the "voce" kernels by two
+// user-supplied C expressions DXM_CUSTOM_R and DXM_CUSTOM_DR in the variables `p` (cumulated
+// plastic strain), `sig0` and `c[0..5]`: R(p) and dR/dp of an arbitrary isotropic hardening law
+// (what a Python `yield_stress(p)` callable is to jaxmat: tests/test_FeFp_jax.py:14-15).  The
+// Python layer compiles such a library on demand (dolfinx_materials_amd/_lib.py::load_custom).
+#ifdef DXM_CUSTOM_HARDENING
+__device__ __forceinline__ double custom_R(const LawParams& prm, double p) {
+  const double sig0 = prm.sig0;
+  const double* c = prm.c;
+  (void)sig0; (void)c;
+  return (DXM_CUSTOM_R);
+}
+__device__ __forceinline__ double custom_dR(const LawParams& prm, double p) {
+  const double sig0 = prm.sig0;
+  const double* c = prm.c;
+  (void)sig0; (void)c;
+  return (DXM_CUSTOM_DR);
+}
+#endif
 
 // One record per workgroup, summed on the host on demand (no atomics on the hot path: a
 // same-address atomic fan-in of a few thousand workgroups costs ~10 ns each at kernel end).

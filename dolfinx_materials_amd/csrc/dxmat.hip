@@ -134,9 +134,18 @@ struct dxm_material {
   double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
 };
 
+// number of parameters a law takes in THIS build: a JIT build with a user-supplied hardening law
+// (DXM_CUSTOM_HARDENING) takes [E, nu, sig0, c0..c5] for the two "voce" slots
+static int n_params_of(int law) {
+#ifdef DXM_CUSTOM_HARDENING
+  if (law == DXM_LAW_J2_VOCE || law == DXM_LAW_FEFP_J2_VOCE) return 9;
+#endif
+  return kLaws[law].n_params;
+}
+
 static int build_params(dxm_material* m, const double* p, int np) {
-  const LawDesc& d = kLaws[m->law];
-  if (np != d.n_params) return fail(-1, "law %d expects %d parameters, got %d", m->law, d.n_params, np);
+  const int expect = n_params_of(m->law);
+  if (np != expect) return fail(-1, "law %d expects %d parameters, got %d", m->law, expect, np);
   const double E = p[0], nu = p[1];
   if (!(E > 0.0) || !(nu > -1.0 && nu < 0.5)) return fail(-1, "invalid elastic constants E=%g nu=%g", E, nu);
   LawParams q{};
@@ -149,7 +158,14 @@ static int build_params(dxm_material* m, const double* p, int np) {
     case DXM_LAW_J2_LINEAR:
     case DXM_LAW_FEFP_J2_LINEAR: q.sig0 = p[2]; q.h1 = p[3]; break;
     case DXM_LAW_J2_VOCE:
-    case DXM_LAW_FEFP_J2_VOCE: q.sig0 = p[2]; q.h1 = p[3]; q.h2 = p[4]; break;
+    case DXM_LAW_FEFP_J2_VOCE:
+#ifdef DXM_CUSTOM_HARDENING
+      q.sig0 = p[2];
+      for (int k = 0; k < 6; ++k) q.c[k] = p[3 + k];
+#else
+      q.sig0 = p[2]; q.h1 = p[3]; q.h2 = p[4];
+#endif
+      break;
   }
   q.maxit = m->maxit;
   q.tol = m->rtol * fabs(q.sig0);
@@ -202,6 +218,14 @@ extern "C" {
 
 int dxm_abi_version(void) { return DXM_ABI_VERSION; }
 
+int dxm_has_custom_hardening(void) {
+#ifdef DXM_CUSTOM_HARDENING
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 const char* dxm_last_error(void) { return g_last_error.c_str(); }
 
 int dxm_device_count(void) {
@@ -217,7 +241,7 @@ int dxm_law_info_get(int law, dxm_law_info* out) {
   memset(out, 0, sizeof(*out));
   out->n_grad = d.n_grad;
   out->n_flux = d.n_flux;
-  out->n_params = d.n_params;
+  out->n_params = n_params_of(law);
   out->n_isv_fields = d.n_isv_fields;
   for (int f = 0; f < DXM_MAX_STATE_FIELDS; ++f) {
     out->isv_dim[f] = d.isv_dim[f];

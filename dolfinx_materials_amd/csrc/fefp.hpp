@@ -83,9 +83,14 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
     R = prm.sig0 + prm.h1 * p;
     dR = prm.h1;
   } else {
+#ifdef DXM_CUSTOM_HARDENING
+    R = custom_R(prm, p);
+    dR = custom_dR(prm, p);
+#else
     const double ex = exp(-prm.h2 * p);
     R = prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - ex);
     dR = (prm.h1 - prm.sig0) * prm.h2 * ex;
+#endif
   }
 }
 

@@ -38,7 +38,11 @@ __device__ __forceinline__ double hardening_R(const LawParams& prm, double p) {
   if constexpr (LAW == LAW_J2_LINEAR) {
     return prm.sig0 + prm.h1 * p;
   } else {
+#ifdef DXM_CUSTOM_HARDENING
+    return custom_R(prm, p);
+#else
     return prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exp(-prm.h2 * p));
+#endif
   }
 }
 template <int LAW>
@@ -46,7 +50,11 @@ __device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
   if constexpr (LAW == LAW_J2_LINEAR) {
     return prm.h1;
   } else {
+#ifdef DXM_CUSTOM_HARDENING
+    return custom_dR(prm, p);
+#else
     return (prm.h1 - prm.sig0) * prm.h2 * exp(-prm.h2 * p);
+#endif
   }
 }
 

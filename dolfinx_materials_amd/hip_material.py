@@ -81,8 +81,10 @@ class HIPMaterial:
         self.tangent_layout = tangent_layout
         self.behavior = behavior
         self.device = int(device)
-        self._lib = _lib.load()
-        self._info = _lib.law_info(behavior.law)
+        custom = getattr(behavior, "custom_hardening", None)
+        # a user-supplied hardening law lives in its own JIT-compiled copy of the library
+        self._lib = _lib.load_custom(custom.expr_R, custom.expr_dR) if custom is not None else _lib.load()
+        self._info = _lib.law_info(behavior.law, self._lib)
         self._gname = gradient_name or behavior.gradient_name
         self._fname = flux_name or behavior.flux_name
         self.material_properties = dict(behavior.flat_properties())  # jaxmat.py:146
@@ -92,6 +94,9 @@ class HIPMaterial:
         self.last_stats = None
         self.dt = 0.0
         self._warm = False
+
+    def _chk(self, rc):
+        return _lib.check(rc, self._lib)
 
     # ---- protocol: names and sizes ---------------------------------------------------------
     @property
@@ -165,14 +170,14 @@ class HIPMaterial:
         self.material_properties[key] = value
         if self._handle:
             prm = np.asarray(self.behavior.params(), dtype=np.float64)
-            _lib.check(
+            self._chk(
                 self._lib.dxm_set_params(
                     self._handle, prm.ctypes.data_as(C.POINTER(C.c_double)), prm.size
                 )
             )
 
     def set_newton(self, maxit=25, rtol=1e-14):
-        _lib.check(self._lib.dxm_set_newton(self._require(), int(maxit), float(rtol)))
+        self._chk(self._lib.dxm_set_newton(self._require(), int(maxit), float(rtol)))
 
     # ---- protocol: life cycle ------------------------------------------------------------------
     def set_data_manager(self, ngauss):
@@ -187,12 +192,12 @@ class HIPMaterial:
             self.device,
         )
         if not h:
-            raise DxmError(f"dxm_create failed: {_lib.last_error()}")
+            raise DxmError(f"dxm_create failed: {_lib.last_error(self._lib)}")
         self._handle = h
         self._n = int(ngauss)
         if self.tangent_layout == "sym":
             try:
-                _lib.check(self._lib.dxm_set_tangent_layout(h, 1))
+                self._chk(self._lib.dxm_set_tangent_layout(h, 1))
             except Exception:
                 self.close()
                 raise
@@ -250,7 +255,7 @@ class HIPMaterial:
         out = {}
         for f, (name, dim) in enumerate(self.internal_state_variables.items()):
             a = np.empty((self._n, dim))
-            _lib.check(self._lib.dxm_get_state(h, which, f, _ptr(a)))
+            self._chk(self._lib.dxm_get_state(h, which, f, _ptr(a)))
             out[name] = a
         return out
 
@@ -278,23 +283,23 @@ class HIPMaterial:
             elif key == "be_bar" and self._info.n_grad == 9:
                 continue  # handled below together with F
             else:
-                _lib.check(self._lib.dxm_set_state(h, S0, isv_names.index(key), _ptr(a)))
+                self._chk(self._lib.dxm_set_state(h, S0, isv_names.index(key), _ptr(a)))
         if self._info.n_grad == 9 and ("be_bar" in state or self._gname in state):
             # the kernel's state is the isochoric Cp^-1 (hidden field 2), rebuilt from (F_n, be_bar_n)
             from .conventions import cp_bar_inv_from_be_bar
 
             be = _as_c(state["be_bar"], (self._n, 6)) if "be_bar" in state else self._isv_dict(S0)["be_bar"]
             cpi, be = cp_bar_inv_from_be_bar(self._grad[0], be)
-            _lib.check(self._lib.dxm_set_state(h, S0, 1, _ptr(_as_c(be))))
-            _lib.check(self._lib.dxm_set_state(h, S0, 2, _ptr(_as_c(cpi))))
+            self._chk(self._lib.dxm_set_state(h, S0, 1, _ptr(_as_c(be))))
+            self._chk(self._lib.dxm_set_state(h, S0, 2, _ptr(_as_c(cpi))))
 
     def _advance(self):
-        _lib.check(self._lib.dxm_advance(self._require()))
+        self._chk(self._lib.dxm_advance(self._require()))
         self._grad[0] = self._grad[1]
         self._flux[0] = self._flux[1]
 
     def _revert(self):
-        _lib.check(self._lib.dxm_revert(self._require()))
+        self._chk(self._lib.dxm_revert(self._require()))
         self._grad[1] = self._grad[0]
         self._flux[1] = self._flux[0]
 
@@ -325,7 +330,7 @@ class HIPMaterial:
             rc = self._lib.dxm_integrate(
                 h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)
             )
-        _lib.check(rc)
+        self._chk(rc)
         self.last_stats = st.as_dict()
         if rc > 0:
             warnings.warn(
@@ -360,7 +365,7 @@ class HIPMaterial:
         rc = self._lib.dxm_integrate_displacement(
             h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)
         )
-        _lib.check(rc)
+        self._chk(rc)
         self.last_stats = st.as_dict()
         if rc > 0:
             warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
@@ -371,18 +376,18 @@ class HIPMaterial:
         """Device-pointer form: asynchronous launch on ``stream`` (a ``hipStream_t`` value, e.g.
         ``torch.cuda.current_stream().cuda_stream``); the three arguments are device addresses
         of ``(N,ng)``, ``(N,nf)`` and ``(N,nf*ng)`` fp64 arrays on this material's device."""
-        _lib.check(
+        self._chk(
             self._lib.dxm_integrate_device(
                 self._require(), int(grad_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None
             )
         )
 
     def isv_device(self, which, isv_ptr, stream=0):
-        _lib.check(self._lib.dxm_isv_device(self._require(), which, int(isv_ptr), int(stream) or None))
+        self._chk(self._lib.dxm_isv_device(self._require(), which, int(isv_ptr), int(stream) or None))
 
     def stats(self):
         """Wait for the last integrate and return its per-batch status."""
         st = Stats()
-        rc = _lib.check(self._lib.dxm_get_stats(self._require(), C.byref(st)))
+        rc = self._chk(self._lib.dxm_get_stats(self._require(), C.byref(st)))
         self.last_stats = st.as_dict()
         return rc, self.last_stats

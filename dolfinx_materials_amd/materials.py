@@ -51,6 +51,58 @@ class VoceHardening:
     b: float
 
 
+class CustomHardening:
+    """An arbitrary isotropic hardening law given as C expressions, compiled into the fused kernels
+    on first use (the role a Python ``yield_stress(p)`` callable plays for jaxmat,
+    ``tests/test_FeFp_jax.py:14-19``)::
+
+        jm.CustomHardening("sig0 + K * pow(p + 1e-12, n)", "K * n * pow(p + 1e-12, n - 1)",
+                           sig0=250.0, K=600.0, n=0.3)
+
+    ``R`` is R(p), ``dR`` its derivative, both in the variable ``p``, ``sig0`` and up to six named
+    parameters; R(0) must equal ``sig0`` and R must be non-decreasing (the local Newton relies on
+    it, as with the built-in laws)."""
+
+    _RESERVED = {"p", "sig0", "c"}
+
+    def __init__(self, R: str, dR: str, sig0: float, **params):
+        import re
+
+        if len(params) > 6:
+            raise ValueError("at most 6 named parameters")
+        bad = self._RESERVED & set(params)
+        if bad:
+            raise ValueError(f"parameter names {sorted(bad)} are reserved")
+        self.sig0 = float(sig0)
+        self.names = list(params)
+        self.values = [float(v) for v in params.values()]
+        self.R_source, self.dR_source = R, dR
+
+        def sub(expr):
+            for i, name in enumerate(self.names):
+                expr = re.sub(rf"\b{re.escape(name)}\b", f"c[{i}]", expr)
+            return "(" + expr + ")"
+
+        self.expr_R, self.expr_dR = sub(R), sub(dR)
+
+    def coefficients(self):
+        return self.values + [0.0] * (6 - len(self.values))
+
+    # named parameters read and written like attributes (update_material_property("yield_stress.K", ...))
+    def __getattr__(self, name):
+        names = self.__dict__.get("names", [])
+        if name in names:
+            return self.__dict__["values"][names.index(name)]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        names = self.__dict__.get("names", [])
+        if name in names:
+            self.__dict__["values"][names.index(name)] = float(value)
+        else:
+            object.__setattr__(self, name, value)
+
+
 class Behavior:
     """Common part: law id, parameter vector, field names and sizes."""
 
@@ -84,12 +136,27 @@ class FiniteStrainBehavior(Behavior):
 
 
 def _check_hardening(yield_stress):
-    if isinstance(yield_stress, (LinearHardening, VoceHardening)):
+    if isinstance(yield_stress, (LinearHardening, VoceHardening, CustomHardening)):
         return yield_stress
     raise NotImplementedError(
-        "yield_stress must be a materials.LinearHardening or materials.VoceHardening instance: "
-        "an arbitrary Python callable cannot be fused into the HIP return-mapping kernel."
+        "yield_stress must be a materials.LinearHardening, materials.VoceHardening or "
+        "materials.CustomHardening (C expressions for R(p) and dR/dp) instance: an arbitrary Python "
+        "callable cannot be fused into the HIP return-mapping kernel."
     )
+
+
+def _hardening_params(e, y):
+    if isinstance(y, LinearHardening):
+        return [e.E, e.nu, y.sig0, y.H]
+    if isinstance(y, CustomHardening):
+        return [e.E, e.nu, y.sig0] + y.coefficients()
+    return [e.E, e.nu, y.sig0, y.sigu, y.b]
+
+
+def _hardening_properties(y):
+    if isinstance(y, CustomHardening):
+        return {"yield_stress.sig0": y.sig0, **{f"yield_stress.{n}": v for n, v in zip(y.names, y.values)}}
+    return {f"yield_stress.{k}": v for k, v in vars(y).items()}
 
 
 class ElasticBehavior(SmallStrainBehavior):
@@ -116,16 +183,14 @@ class vonMisesIsotropicHardening(SmallStrainBehavior):
         self.law = (
             _lib.LAW_J2_LINEAR if isinstance(yield_stress, LinearHardening) else _lib.LAW_J2_VOCE
         )
+        self.custom_hardening = yield_stress if isinstance(yield_stress, CustomHardening) else None
 
     def params(self):
-        e, y = self.elasticity, self.yield_stress
-        if isinstance(y, LinearHardening):
-            return [e.E, e.nu, y.sig0, y.H]
-        return [e.E, e.nu, y.sig0, y.sigu, y.b]
+        return _hardening_params(self.elasticity, self.yield_stress)
 
     def flat_properties(self):
         out = {"elasticity.E": self.elasticity.E, "elasticity.nu": self.elasticity.nu}
-        out.update({f"yield_stress.{k}": v for k, v in vars(self.yield_stress).items()})
+        out.update(_hardening_properties(self.yield_stress))
         return out
 
 
@@ -136,14 +201,12 @@ class FeFpJ2Plasticity(FiniteStrainBehavior):
         self.elasticity = elasticity
         self.yield_stress = _check_hardening(yield_stress)
         self.law = _lib.LAW_FEFP_J2_LINEAR if isinstance(yield_stress, LinearHardening) else _lib.LAW_FEFP_J2_VOCE
+        self.custom_hardening = yield_stress if isinstance(yield_stress, CustomHardening) else None
 
     def params(self):
-        e, y = self.elasticity, self.yield_stress
-        if isinstance(y, LinearHardening):
-            return [e.E, e.nu, y.sig0, y.H]
-        return [e.E, e.nu, y.sig0, y.sigu, y.b]
+        return _hardening_params(self.elasticity, self.yield_stress)
 
     def flat_properties(self):
         out = {"elasticity.E": self.elasticity.E, "elasticity.nu": self.elasticity.nu}
-        out.update({f"yield_stress.{k}": v for k, v in vars(self.yield_stress).items()})
+        out.update(_hardening_properties(self.yield_stress))
         return out

@@ -20,7 +20,12 @@ from dolfinx_materials_amd.jaxmat import JAXMaterial  # reference: from dolfinx_
 def main(Nbatch=10):
     E, nu, sig0, b, sigu = 70e3, 0.3, 500.0, 1000, 750.0
     elastic_model = jm.LinearElasticIsotropic(E=E, nu=nu)
-    behavior = jm.FeFpJ2Plasticity(elasticity=elastic_model, yield_stress=jm.VoceHardening(sig0=sig0, sigu=sigu, b=b))
+    # the reference passes a Python function `yield_stress(p)` (tests/test_FeFp_jax.py:14-15); here the same law
+    # is either the built-in jm.VoceHardening(sig0, sigu, b) or, as below, C expressions compiled on first use
+    yield_stress = jm.CustomHardening(
+        "sig0 + (sigu - sig0) * (1.0 - exp(-b * p))", "(sigu - sig0) * b * exp(-b * p)", sig0=sig0, sigu=sigu, b=b
+    )
+    behavior = jm.FeFpJ2Plasticity(elasticity=elastic_model, yield_stress=yield_stress)
     material = JAXMaterial(behavior)
     material.set_data_manager(Nbatch)
 

@@ -97,6 +97,10 @@ typedef struct dxm_material dxm_material; /* opaque handle */
 
 /* ---- library / device ------------------------------------------------------------------- */
 int dxm_abi_version(void);
+/* 1 if this library was built with -DDXM_CUSTOM_HARDENING (a user-supplied isotropic hardening law
+ * R(p), dR/dp compiled into the DXM_LAW_J2_VOCE / DXM_LAW_FEFP_J2_VOCE kernels; those laws then
+ * take params = [E, nu, sig0, c0..c5]), 0 for the stock library. */
+int dxm_has_custom_hardening(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* dxm_last_error(void);
 /* Number of HIP devices, or < 0 if the HIP runtime cannot be initialised. */

@@ -1,0 +1,112 @@
+"""User-supplied hardening laws: JIT-compiled kernel variants (the counterpart of handing a Python
+``yield_stress(p)`` callable to jaxmat, tests/test_FeFp_jax.py:14-19)."""
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from dolfinx_materials_amd import _lib
+from oracle import constitutive_np as onp
+
+from helpers import E, NU, SIG0_V, SIGU_V, B_V, SIG0_F, SIGU_F, B_F, j2_history, random_j2_state, fefp_path
+
+
+class PowerLaw:
+    """numpy counterpart of the C expressions below (the oracle accepts any object with R / dR)."""
+
+    def __init__(self, sig0, K, n, p0=1e-3):
+        self.sig0, self.K, self.n, self.p0 = sig0, K, n, p0
+
+    def R(self, p):
+        return self.sig0 + self.K * ((p + self.p0) ** self.n - self.p0**self.n)
+
+    def dR(self, p):
+        return self.K * self.n * (np.asarray(p, dtype=np.float64) + self.p0) ** (self.n - 1)
+
+
+POWER_R = "sig0 + K * (pow(p + p0, n) - pow(p0, n))"
+POWER_DR = "K * n * pow(p + p0, n - 1.0)"
+
+
+def test_expression_substitution_and_parameters():
+    h = jm.CustomHardening(POWER_R, POWER_DR, sig0=250.0, K=600.0, n=0.3, p0=1e-3)
+    assert h.expr_R == "(sig0 + c[0] * (pow(p + c[2], c[1]) - pow(c[2], c[1])))"
+    assert h.coefficients() == [600.0, 0.3, 1e-3, 0.0, 0.0, 0.0]
+    h.K = 700.0
+    assert h.K == 700.0 and h.coefficients()[0] == 700.0
+    b = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), h)
+    assert b.law == _lib.LAW_J2_VOCE and b.params() == [E, NU, 250.0, 700.0, 0.3, 1e-3, 0.0, 0.0, 0.0]
+    assert b.flat_properties()["yield_stress.n"] == 0.3
+    with pytest.raises(ValueError):
+        jm.CustomHardening("p", "1", sig0=1.0, p=2.0)
+    with pytest.raises(NotImplementedError):
+        jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), lambda p: 250.0)
+
+
+def test_custom_library_builds_and_reports_its_parameter_count():
+    """hipcc cross-compiles without a GPU: the JIT build must succeed in the build container too."""
+    h = jm.CustomHardening(POWER_R, POWER_DR, sig0=250.0, K=600.0, n=0.3, p0=1e-3)
+    lib = _lib.load_custom(h.expr_R, h.expr_dR)
+    assert lib.dxm_has_custom_hardening() == 1 and _lib.load().dxm_has_custom_hardening() == 0
+    assert _lib.law_info(_lib.LAW_J2_VOCE, lib).n_params == 9 and _lib.law_info(_lib.LAW_J2_LINEAR, lib).n_params == 4
+    assert _lib.load_custom(h.expr_R, h.expr_dR) is lib  # cached
+    with pytest.raises(_lib.DxmError, match="compiling the custom hardening law failed"):
+        _lib.load_custom("(this is not C", "(1.0)")
+
+
+@pytest.mark.gpu
+def test_custom_voce_expression_reproduces_the_builtin_voce_kernel():
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+
+    n = 5000
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    custom = jm.CustomHardening("sig0 + (sigu - sig0) * (1.0 - exp(-b * p))", "(sigu - sig0) * b * exp(-b * p)",
+                                sig0=SIG0_V, sigu=SIGU_V, b=B_V)
+    a = JAXMaterial(jm.vonMisesIsotropicHardening(el, custom))
+    b = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.VoceHardening(SIG0_V, SIGU_V, B_V)))
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    for eps in j2_history(n, sig0=SIG0_V):
+        sa, ia, ca = a.integrate(eps)
+        sb, ib, cb = b.integrate(eps)
+        assert np.abs(sa - sb).max() < 1e-12 * np.abs(sb).max() and np.abs(ca - cb).max() < 1e-12 * np.abs(cb).max()
+        assert np.abs(ia - ib).max() < 1e-15
+        a.data_manager.update()
+        b.data_manager.update()
+
+
+@pytest.mark.gpu
+def test_power_law_hardening_small_strain_and_fefp_match_the_oracle():
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    # small strain
+    n = 4000
+    hard = PowerLaw(250.0, 600.0, 0.3)
+    mat = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.CustomHardening(POWER_R, POWER_DR, sig0=250.0, K=600.0, n=0.3, p0=1e-3)))
+    mat.set_data_manager(n)
+    epsp_n, p_n = random_j2_state(n, sig0=250.0)
+    mat.set_initial_state_dict({"p": p_n, "epsp": epsp_n})
+    eps = j2_history(n, seed=17, sig0=250.0)[2]
+    sig, isv, Ct = mat.integrate(eps)
+    ref = onp.j2_update(eps, epsp_n, p_n, E, NU, hard)
+    safe = np.abs(ref["f_trial"]) > 1e-9 * 250.0
+    assert ref["plastic"].mean() > 0.3 and mat.last_stats["n_not_converged"] == 0
+    assert np.abs(sig[safe] - ref["sig"][safe]).max() < 1e-11 * np.abs(ref["sig"]).max()
+    assert np.abs(Ct[safe] - ref["Ct"][safe]).max() < 1e-10 * np.abs(ref["Ct"]).max()
+    assert np.abs(isv[safe, 0] - ref["p"][safe]).max() < 1e-13
+    # finite strain
+    n = 600
+    hardf = PowerLaw(500.0, 900.0, 0.25)
+    matf = JAXMaterial(jm.FeFpJ2Plasticity(el, jm.CustomHardening(POWER_R, POWER_DR, sig0=500.0, K=900.0, n=0.25, p0=1e-3)))
+    matf.set_data_manager(n)
+    st = onp.fefp_initial_state(n)
+    cp, p = st["cpinv"], st["p"]
+    for F in fefp_path(n)[4::5]:
+        P, isvf, Ctf = matf.integrate(F)
+        reff = onp.fefp_update(F, cp, p, E, NU, hardf)
+        safe = np.abs(reff["f_trial"]) > 1e-9 * 500.0
+        assert np.abs(P[safe] - reff["P"][safe]).max() < 1e-10 * np.abs(reff["P"]).max()
+        assert np.abs(Ctf[safe] - reff["Ct"][safe]).max() < 1e-10 * np.abs(reff["Ct"]).max()
+        matf.data_manager.update()
+        cp, p = reff["cpinv"], reff["p"]
+    assert reff["plastic"].mean() > 0.9
