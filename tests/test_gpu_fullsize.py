@@ -69,3 +69,46 @@ def test_j2_full_size_device_path(kind):
         sig_prev, eps_prev = sig.clone(), eps
         mat.data_manager.update()
         epsp, p = ref["epsp"], ref["p"]
+
+
+def test_fefp_full_size_device_path():
+    """cfg 4 at full size: 1e7 points of the perturbed uniaxial F path, two
+    increments; strided sample against the oracle, whole batch through properties."""
+    torch = pytest.importorskip("torch")
+    from helpers import SIG0_F, SIGU_F, B_F
+
+    dev = torch.device("cuda:0")
+    hard_o = onp.VoceHardening(SIG0_F, SIGU_F, B_F)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    G = torch.randn((N, 9), generator=g, device=dev, dtype=torch.float64) * (0.2 * 2e-2)
+    base = torch.tensor([2e-2, -1e-2, -1e-2, 0, 0, 0, 0, 0, 0], device=dev, dtype=torch.float64)
+    eye = torch.tensor([1.0, 1, 1, 0, 0, 0, 0, 0, 0], device=dev, dtype=torch.float64)
+    mat = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_F, SIGU_F, B_F)))
+    mat.set_data_manager(N)
+    P = torch.empty((N, 9), dtype=torch.float64, device=dev)
+    ct = torch.empty((N, 81), dtype=torch.float64, device=dev)
+    isv = torch.empty((N, 7), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    idx = torch.cat([torch.arange(0, N, 19997, device=dev), torch.tensor([N - 1, N - 63, N - 64, N - 65], device=dev)])
+    s0 = onp.fefp_initial_state(len(idx))
+    cp, p = s0["cpinv"], s0["p"]
+    for t in (0.5, 1.0):
+        F = eye + t * (base + G)
+        mat.integrate_device(F.data_ptr(), P.data_ptr(), ct.data_ptr(), st)
+        mat.isv_device(1, isv.data_ptr(), st)
+        rc, stats = mat.stats()
+        assert rc == 0 and stats["n_nan"] == 0 and stats["n_not_converged"] == 0
+        ref = onp.fefp_update(F[idx].cpu().numpy(), cp, p, E, NU, hard_o)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_F
+        for got, exp in ((P[idx].cpu().numpy(), ref["P"]), (ct[idx].cpu().numpy().reshape(-1, 9, 9), ref["Ct"]),
+                         (isv[idx, 0].cpu().numpy(), ref["p"]), (isv[idx, 1:].cpu().numpy(), ref["be_bar"])):
+            assert np.abs(got[safe] - exp[safe]).max() <= 1e-11 * max(np.abs(exp).max(), 1e-300)
+        # det(be_bar) = 1 over the whole batch (Mandel -> tensor on the device)
+        b = isv[:, 1:]
+        r2 = 0.5 ** 0.5
+        b01, b02, b12 = b[:, 3] * r2, b[:, 4] * r2, b[:, 5] * r2
+        det = (b[:, 0] * (b[:, 1] * b[:, 2] - b12 * b12) - b01 * (b01 * b[:, 2] - b12 * b02) + b02 * (b01 * b12 - b[:, 1] * b02))
+        assert float((det - 1).abs().max()) < 1e-12
+        assert abs(stats["n_plastic"] / N - ref["plastic"].mean()) < 0.05
+        mat.data_manager.update()
+        cp, p = ref["cpinv"], ref["p"]
