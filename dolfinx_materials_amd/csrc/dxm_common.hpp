@@ -107,4 +107,27 @@ __device__ __forceinline__ void store_block_stats(BlockStats* out, unsigned long
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// Cache policy of the streaming accesses, fixed at build time by the bits of DXM_NT:
+//   bit 0 = non-temporal stores of flux and tangent      bit 1 = of the new state
+//   bit 2 = non-temporal loads of the gradient            bit 3 = of the old state
+// Shipped: 1.  Flux and tangent (336 of the 496 B/point of J2) are not read again on the GPU, so
+// their lines need not displace the gradient and the state in L2 / Infinity Cache: same-process A/B
+// (tools/ab_inproc.py, profiles/r01_nt_ab.jsonl) -26 % kernel time at 1e6 points, -9 % at 1e5,
+// -2 % at 1e7, never slower.  The new state IS read back by the next update (advance), and a
+// non-temporal state store costs +18 % at 3e5 points; non-temporal loads only lose where the
+// gradient was just written by the displacement-gradient kernel.  So bits 1-3 stay off.
+#ifndef DXM_NT
+#define DXM_NT 1
+#endif
+template <int BIT, class T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+  if constexpr ((DXM_NT >> BIT) & 1) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int BIT, class T>
+__device__ __forceinline__ T stream_load(const T* p) {
+  if constexpr ((DXM_NT >> BIT) & 1) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 }  // namespace dxm

@@ -144,7 +144,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const int idx = k * WAVE + lane;
-        v[k] = (idx < 288) ? gsrc[idx] : double2_t{0.0, 0.0};
+        v[k] = (idx < 288) ? stream_load<2>(gsrc + idx) : double2_t{0.0, 0.0};
       }
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
@@ -162,9 +162,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     }
     double p_n = 0.0, g6[6] = {1, 1, 1, 0, 0, 0};
     if (valid) {
-      p_n = s0[(int64_t)FEFP_SLOT_P * ld + gi];
+      p_n = stream_load<3>(s0 + (int64_t)FEFP_SLOT_P * ld + gi);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) g6[c] = s0[(int64_t)(FEFP_SLOT_CPI + c) * ld + gi];
+      for (int c = 0; c < 6; ++c) g6[c] = stream_load<3>(s0 + (int64_t)(FEFP_SLOT_CPI + c) * ld + gi);
     }
     wave_lds_sync();
     double F[9];
@@ -302,19 +302,19 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       double t[9], gn[9];
       mmt(be, Fi, t);   // be F^-T
       mm(Fi, t, gn);    // F^-1 be F^-T
-      s1[(int64_t)FEFP_SLOT_P * ld + gi] = p_new;
-      s1[(int64_t)(FEFP_SLOT_BE + 0) * ld + gi] = be[0];
-      s1[(int64_t)(FEFP_SLOT_BE + 1) * ld + gi] = be[4];
-      s1[(int64_t)(FEFP_SLOT_BE + 2) * ld + gi] = be[8];
-      s1[(int64_t)(FEFP_SLOT_BE + 3) * ld + gi] = SQ2 * be[1];
-      s1[(int64_t)(FEFP_SLOT_BE + 4) * ld + gi] = SQ2 * be[2];
-      s1[(int64_t)(FEFP_SLOT_BE + 5) * ld + gi] = SQ2 * be[5];
-      s1[(int64_t)(FEFP_SLOT_CPI + 0) * ld + gi] = J23 * gn[0];
-      s1[(int64_t)(FEFP_SLOT_CPI + 1) * ld + gi] = J23 * gn[4];
-      s1[(int64_t)(FEFP_SLOT_CPI + 2) * ld + gi] = J23 * gn[8];
-      s1[(int64_t)(FEFP_SLOT_CPI + 3) * ld + gi] = SQ2 * J23 * 0.5 * (gn[1] + gn[3]);
-      s1[(int64_t)(FEFP_SLOT_CPI + 4) * ld + gi] = SQ2 * J23 * 0.5 * (gn[2] + gn[6]);
-      s1[(int64_t)(FEFP_SLOT_CPI + 5) * ld + gi] = SQ2 * J23 * 0.5 * (gn[5] + gn[7]);
+      stream_store<1>(s1 + (int64_t)FEFP_SLOT_P * ld + gi, p_new);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 0) * ld + gi, be[0]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 1) * ld + gi, be[4]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 2) * ld + gi, be[8]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 3) * ld + gi, SQ2 * be[1]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 4) * ld + gi, SQ2 * be[2]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 5) * ld + gi, SQ2 * be[5]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 0) * ld + gi, J23 * gn[0]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 1) * ld + gi, J23 * gn[4]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 2) * ld + gi, J23 * gn[8]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 3) * ld + gi, SQ2 * J23 * 0.5 * (gn[1] + gn[3]));
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 4) * ld + gi, SQ2 * J23 * 0.5 * (gn[2] + gn[6]));
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 5) * ld + gi, SQ2 * J23 * 0.5 * (gn[5] + gn[7]));
     }
 
     // ---- 5. PK1 through LDS, coalesced store -------------------------------------------------------
@@ -329,7 +329,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const int idx = k * WAVE + lane;
-        if (idx < 288) gdst[idx] = stage2[idx];
+        if (idx < 288) stream_store<0>(gdst + idx, stage2[idx]);
       }
     } else {
       double* gdst = Pout + base * 9;
@@ -427,11 +427,11 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         for (int it = 0; it < NIT; ++it) {
           const int e0 = (it * WAVE + lane) * 2;
           if ((it + 1) * 2 * WAVE <= nent) {                     // scalar branch: whole KiB valid
-            *reinterpret_cast<double2_t*>(gct + e0) = v[it];
+            stream_store<0>(reinterpret_cast<double2_t*>(gct + e0), v[it]);
           } else if (e0 + 1 < nent) {
-            *reinterpret_cast<double2_t*>(gct + e0) = v[it];
+            stream_store<0>(reinterpret_cast<double2_t*>(gct + e0), v[it]);
           } else if (e0 < nent) {
-            gct[e0] = v[it].x;
+            stream_store<0>(gct + e0, v[it].x);
           }
         }
       }

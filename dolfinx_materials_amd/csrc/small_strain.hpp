@@ -94,7 +94,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int idx = k * WAVE + lane;
-        v[k] = (idx < npts * 3) ? gsrc[idx] : double2_t{0.0, 0.0};
+        v[k] = (idx < npts * 3) ? stream_load<2>(gsrc + idx) : double2_t{0.0, 0.0};
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k) stage2[k * WAVE + lane] = v[k];
@@ -103,9 +103,9 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
     double p_n = 0.0, ep[6] = {0, 0, 0, 0, 0, 0};
     if constexpr (LAW != LAW_ELASTIC) {
       if (valid) {
-        p_n = s0[gi];
+        p_n = stream_load<3>(s0 + gi);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) ep[c] = s0[(int64_t)(1 + c) * ld + gi];
+        for (int c = 0; c < 6; ++c) ep[c] = stream_load<3>(s0 + (int64_t)(1 + c) * ld + gi);
       }
     }
     wave_lds_sync();
@@ -194,9 +194,9 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
     // ---- 4. new state, SoA -------------------------------------------------------------------
     if constexpr (LAW != LAW_ELASTIC) {
       if (valid) {
-        s1[gi] = p_new;
+        stream_store<1>(s1 + gi, p_new);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s1[(int64_t)(1 + c) * ld + gi] = ep[c];
+        for (int c = 0; c < 6; ++c) stream_store<1>(s1 + (int64_t)(1 + c) * ld + gi, ep[c]);
       }
     }
 
@@ -219,7 +219,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
       for (int k = 0; k < 3; ++k) {
         const int idx = k * WAVE + lane;
         if (idx < npts * 3) {
-          gdst[idx] = stage2[idx];
+          stream_store<0>(gdst + idx, stage2[idx]);
         }
       }
     }
@@ -261,7 +261,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
             v[u] = entry(q, i, (r - i * 3) * 2);
           }
 #pragma unroll
-          for (int u = 0; u < 3; ++u) gct[(g * 3 + u) * WAVE + lane] = v[u];
+          for (int u = 0; u < 3; ++u) stream_store<0>(gct + (g * 3 + u) * WAVE + lane, v[u]);
         }
       } else {
         const int lim = npts * 18;
@@ -271,7 +271,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           const int q = k / 18;
           const int r = k - q * 18;
           const int i = r / 3;
-          if (k < lim) gct[k] = entry(q, i, (r - i * 3) * 2);
+          if (k < lim) stream_store<0>(gct + k, entry(q, i, (r - i * 3) * 2));
         }
       }
     } else {
@@ -305,8 +305,8 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           }
           v[u] = x;
         }
-        if (e0 + 1 < lim) *reinterpret_cast<double2_t*>(gct + e0) = double2_t{v[0], v[1]};
-        else if (e0 < lim) gct[e0] = v[0];
+        if (e0 + 1 < lim) stream_store<0>(reinterpret_cast<double2_t*>(gct + e0), double2_t{v[0], v[1]});
+        else if (e0 < lim) stream_store<0>(gct + e0, v[0]);
       }
     }
     wave_lds_sync();  // LDS regions are rewritten by the next tile
