@@ -96,7 +96,9 @@ def main():
         ms = float(np.median(times[k]))
         print(json.dumps({"lib": os.path.basename(a.libs[k]), "law": a.law, "advance": a.advance, "points": n, "median_ms": round(ms, 4),
                           "min_ms": round(float(np.min(times[k])), 4), "frac_of_8TBs": round(ab * n / ms / 1e6 / 8000, 4),
-                          "same_result": checks[k] == checks[0]}), flush=True)
+                          "same_result": checks[k] == checks[0],
+                          "s0": hex(m._lib.dxm_state_ptr(m._handle, 0, 0, 0) or 0), "s1": hex(m._lib.dxm_state_ptr(m._handle, 1, 0, 0) or 0),
+                          "grad": hex(g[1].data_ptr()), "flux": hex(flux.data_ptr()), "ct": hex(ct.data_ptr())}), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Device-side cost of the step before the hot path: displacement vector -> gradient at the Gauss
+points (gradient.hpp), alone and followed by the constitutive kernel, on a structured hex8 mesh.
+
+    python tools/bench_gradient.py [--cells 108] [--law j2_linear|fefp]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def box_mesh(nc):
+    x = np.linspace(0.0, 1.0, nc + 1)
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    nid = np.arange((nc + 1) ** 3).reshape(nc + 1, nc + 1, nc + 1)
+    i, j, k = np.meshgrid(np.arange(nc), np.arange(nc), np.arange(nc), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()
+    conn = np.stack([nid[i, j, k], nid[i + 1, j, k], nid[i + 1, j + 1, k], nid[i, j + 1, k],
+                     nid[i, j, k + 1], nid[i + 1, j, k + 1], nid[i + 1, j + 1, k + 1], nid[i, j + 1, k + 1]], axis=1)
+    return coords, conn.astype(np.int32)
+
+
+def timeit(torch, fn, reps):
+    for _ in range(3):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    return float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=108)
+    ap.add_argument("--law", default="j2_linear", choices=["j2_linear", "fefp"])
+    ap.add_argument("--reps", type=int, default=30)
+    a = ap.parse_args()
+    import torch
+
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.gradient import Hex8Mesh
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+    from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_F, SIGU_F, B_F
+
+    dev = torch.device("cuda:0")
+    coords, conn = box_mesh(a.cells)
+    rng = np.random.default_rng(0)
+    coords[:, :] += rng.uniform(-0.2, 0.2, coords.shape) / a.cells  # distorted cells: nothing special-cased
+    mesh = Hex8Mesh(coords, conn)
+    n = mesh.npoints
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if a.law == "j2_linear":
+        beh, kind, scale = jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN)), 0, 6e-3
+    else:
+        beh, kind, scale = jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F)), 1, 2e-2
+    m = JAXMaterial(beh)
+    m.set_data_manager(n)
+    ng, nf = m._info.n_grad, m._info.n_flux
+    u = coords * np.array([scale, -0.4 * scale, -0.4 * scale]) + rng.standard_normal(coords.shape) * 0.1 * scale / a.cells
+    ud = torch.from_numpy(u.ravel().copy()).to(dev)
+    grad = torch.empty((n, ng), dtype=torch.float64, device=dev)
+    flux = torch.empty((n, nf), dtype=torch.float64, device=dev)
+    ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    t_grad = timeit(torch, lambda: mesh.gradient_device(ud.data_ptr(), kind, grad.data_ptr(), st), a.reps)
+    t_law = timeit(torch, lambda: m.integrate_device(grad.data_ptr(), flux.data_ptr(), ct.data_ptr(), st), a.reps)
+
+    def both():
+        mesh.gradient_device(ud.data_ptr(), kind, grad.data_ptr(), st)
+        m.integrate_device(grad.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+
+    t_both = timeit(torch, both, a.reps)
+    rc, stats = m.stats()
+    print(json.dumps({"cells": a.cells ** 3, "points": n, "nodes": len(coords), "law": a.law,
+                      "gradient_ms": round(t_grad, 4), "law_ms": round(t_law, 4), "both_ms": round(t_both, 4),
+                      "gradient_write_GBs": round(n * ng * 8 / t_grad / 1e6, 1),
+                      "plastic_fraction": round(stats["n_plastic"] / n, 3), "rc": rc}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

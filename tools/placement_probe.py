@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--jitter-mib", type=int, default=0, help="allocate a dummy buffer of k * this many MiB before handle k")
+    ap.add_argument("--variants", nargs="*", default=[""],
+                    help="environment settings applied round-robin at handle creation, e.g. '' DXM_LD_PAD=64 DXM_S1_SKEW=256")
     a = ap.parse_args()
     import torch
 
@@ -47,8 +49,14 @@ def main():
     for k in range(a.handles):
         if a.jitter_mib and k:
             dummies.append(torch.empty(k * a.jitter_mib << 20, dtype=torch.uint8, device=dev))
+        var = a.variants[k % len(a.variants)]
+        kv = dict(x.split("=") for x in var.split(",") if x)
+        os.environ.update(kv)
         m = JAXMaterial(mk())
         m.set_data_manager(n)
+        for key in kv:
+            del os.environ[key]
+        m._variant = var
         m.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
         for _ in range(3):
@@ -64,13 +72,34 @@ def main():
                 e1.record()
             torch.cuda.synchronize()
             times[k] += [e0.elapsed_time(e1) for e0, e1 in ev]
+    # the J2-shaped streaming probe (tools/stream_mix.hip) on the SAME state memory, afterwards
+    import ctypes as C
+    sm = C.CDLL(os.path.join(ROOT, "tools", "libstreammix.so"))
+    sm.stream_mix_j2_shape_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    probe = []
+    n64 = n // 64 * 64
+    for m in mats:
+        s0 = m._lib.dxm_state_ptr(m._handle, 0, 0, 0)
+        s1 = m._lib.dxm_state_ptr(m._handle, 1, 0, 0)
+        ldm = (m._lib.dxm_state_ptr(m._handle, 0, 1, 0) - s0) // 8
+        fn = lambda: sm.stream_mix_j2_shape_launch(g[1].data_ptr(), s0, s1, ldm, flux.data_ptr(), ct.data_ptr(), n64, 1024, st or None)  # noqa: E731
+        for _ in range(3):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for e0, e1 in ev:
+            e0.record()
+            fn()
+            e1.record()
+        torch.cuda.synchronize()
+        probe.append(round(float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])), 4))
     print(json.dumps({"eps": hex(g[1].data_ptr()), "flux": hex(flux.data_ptr()), "ct": hex(ct.data_ptr())}))
     for k, m in enumerate(mats):
         s0 = m._lib.dxm_state_ptr(m._handle, 0, 0, 0)
         s1 = m._lib.dxm_state_ptr(m._handle, 1, 0, 0)
         s0b = m._lib.dxm_state_ptr(m._handle, 0, 1, 0)
-        print(json.dumps({"handle": k, "s0": hex(s0), "s1": hex(s1), "slot_stride": s0b - s0,
-                          "median_ms": round(float(np.median(times[k])), 4), "min_ms": round(float(np.min(times[k])), 4)}), flush=True)
+        print(json.dumps({"handle": k, "variant": m._variant, "s0": hex(s0), "s1": hex(s1), "slot_stride": s0b - s0,
+                          "median_ms": round(float(np.median(times[k])), 4), "min_ms": round(float(np.min(times[k])), 4),
+                          "probe_on_same_state_ms": probe[k]}), flush=True)
 
 
 if __name__ == "__main__":

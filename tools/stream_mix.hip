@@ -10,6 +10,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // rpairs / wpairs: 16-byte pairs read / written per 64-point tile (J2: 416 / 1568; elastic: 192 / 1344;
 // FeFp: 512 / 3296)
+template <bool NT>
 __global__ void __launch_bounds__(256) stream_mix_kernel(const double2_t* __restrict__ rbuf,
                                                          double2_t* __restrict__ wbuf, int64_t ntiles,
                                                          int rpairs, int wpairs) {
@@ -23,7 +24,10 @@ __global__ void __launch_bounds__(256) stream_mix_kernel(const double2_t* __rest
     for (int idx = lane; idx < rpairs; idx += 64) acc += r[idx];
     double2_t* w = wbuf + t * wpairs;
 #pragma unroll 8
-    for (int idx = lane; idx < wpairs; idx += 64) w[idx] = acc;
+    for (int idx = lane; idx < wpairs; idx += 64) {
+      if constexpr (NT) __builtin_nontemporal_store(acc, w + idx);   // the cache policy libdxmat ships for flux / tangent
+      else w[idx] = acc;
+    }
   }
 }
 
@@ -101,7 +105,7 @@ extern "C" int stream_mix_pipelined_launch(const void* rbuf, void* wbuf, int64_t
 // 2 workgroups = 8 waves per CU, the FeFp kernel's occupancy).
 extern "C" int stream_mix_capped_launch(const void* rbuf, void* wbuf, int64_t npoints, int read_bytes_per_point,
                                         int write_bytes_per_point, int blocks, int lds_bytes, void* stream) {
-  hipLaunchKernelGGL(stream_mix_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream,
+  hipLaunchKernelGGL(stream_mix_kernel<false>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream,
                      (const double2_t*)rbuf, (double2_t*)wbuf, npoints / 64, read_bytes_per_point * 4,
                      write_bytes_per_point * 4);
   return (int)hipGetLastError();
@@ -109,7 +113,15 @@ extern "C" int stream_mix_capped_launch(const void* rbuf, void* wbuf, int64_t np
 
 extern "C" int stream_mix_launch(const void* rbuf, void* wbuf, int64_t npoints, int read_bytes_per_point,
                                  int write_bytes_per_point, int blocks, void* stream) {
-  hipLaunchKernelGGL(stream_mix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(stream_mix_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const double2_t*)rbuf, (double2_t*)wbuf, npoints / 64, read_bytes_per_point * 4,
+                     write_bytes_per_point * 4);
+  return (int)hipGetLastError();
+}
+
+extern "C" int stream_mix_nt_launch(const void* rbuf, void* wbuf, int64_t npoints, int read_bytes_per_point,
+                                    int write_bytes_per_point, int blocks, void* stream) {
+  hipLaunchKernelGGL(stream_mix_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      (const double2_t*)rbuf, (double2_t*)wbuf, npoints / 64, read_bytes_per_point * 4,
                      write_bytes_per_point * 4);
   return (int)hipGetLastError();

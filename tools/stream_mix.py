@@ -26,6 +26,7 @@ def main():
     lib = C.CDLL(os.path.join(ROOT, "tools", "libstreammix.so"))
     lib.stream_mix_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.stream_mix_pipelined_launch.argtypes = lib.stream_mix_launch.argtypes
+    lib.stream_mix_nt_launch.argtypes = lib.stream_mix_launch.argtypes
     st = torch.cuda.current_stream().cuda_stream
     el = jm.LinearElasticIsotropic(E=bench.E, nu=bench.NU)
     gen = torch.Generator(device=dev).manual_seed(7)
@@ -65,6 +66,7 @@ def main():
                 variants[f"shape17_{blocks}"] = (lambda b: (lambda: lib.stream_mix_j2_shape_launch(g1.data_ptr(), sa.data_ptr(), sb.data_ptr(), ld, flux.data_ptr(), ct.data_ptr(), n, b, st or None)))(blocks)
         for blocks in (1024, 2048, 4096):
             variants[f"probe_{blocks}"] = (lambda b: (lambda: lib.stream_mix_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, rb, wb, b, st or None)))(blocks)
+            variants[f"probe_nt_{blocks}"] = (lambda b: (lambda: lib.stream_mix_nt_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, rb, wb, b, st or None)))(blocks)
             variants[f"probe_pipelined_{blocks}"] = (lambda b: (lambda: lib.stream_mix_pipelined_launch(rbuf.data_ptr(), wbuf.data_ptr(), n, rb, wb, b, st or None)))(blocks)
         times = {k: [] for k in variants}
         for r in range(12):
@@ -78,7 +80,8 @@ def main():
                     times[k].append(e0.elapsed_time(e1))
         med = {k: float(np.median(t)) for k, t in times.items()}
         probe = min(v for k, v in med.items() if k.startswith("probe_"))
-        plain = min(v for k, v in med.items() if k.startswith("probe_") and "pipelined" not in k)
+        plain = min(v for k, v in med.items() if k.startswith("probe_") and "pipelined" not in k and "_nt_" not in k)
+        nts = min(v for k, v in med.items() if k.startswith("probe_nt_"))
         shape = [v for k, v in med.items() if k.startswith("shape17_")]
         piped = min(v for k, v in med.items() if "pipelined" in k)
         moved = (rb + wb) * n
@@ -86,7 +89,7 @@ def main():
             "law": name, "bytes_moved_per_point": rb + wb, "kernel_ms": round(med[name], 4), "probe_ms": round(probe, 4),
             "kernel_GBs_moved": round(moved / med[name] / 1e6, 1), "probe_GBs": round(moved / probe / 1e6, 1),
             "kernel_over_probe": round(probe / med[name], 4),
-            "probe_plain_ms": round(plain, 4), "probe_pipelined_ms": round(piped, 4),
+            "probe_plain_ms": round(plain, 4), "probe_pipelined_ms": round(piped, 4), "probe_nt_stores_ms": round(nts, 4),
             "probe_17_streams_ms": round(min(shape), 4) if shape else None,
             "probe_at_8_waves_per_cu_ms": round(min([v for k, v in med.items() if k.startswith("capped8waves_")]), 4) if any(k.startswith("capped8waves_") for k in med) else None,
         }), flush=True)
