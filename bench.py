@@ -91,7 +91,7 @@ def cpu_baseline(sample, seed, budget_s=14.0):
     }
 
 
-def other_laws(torch, jm, JAXMaterial, dev, n, reps=8):
+def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True):
     """Kernel rates of the other laws of the path at the same batch size (device-resident,
     HIP events), for context next to the headline: elastic, J2 Voce (cfg 3 parameters), FeFp J2
     (cfg 4 parameters, F = I + t (eps diag(1,-1/2,-1/2) + 0.2 eps G) as in SURVEY.md 8(d))."""
@@ -129,6 +129,8 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8):
         ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)
         m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
+        if tune:
+            m.tune_placement(g1.data_ptr(), flux.data_ptr(), ct.data_ptr())
         for _ in range(2):
             m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         rc, stats = m.stats()
@@ -163,6 +165,8 @@ def main():
     ap.add_argument("--p2p-gather", action="store_true",
                     help="also time the point-to-point all-gather schedule (sharding.allgather_rows_p2p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true",
+                    help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
     ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     args = ap.parse_args()
@@ -222,6 +226,16 @@ def main():
             assert rc == 0 and st["n_nan"] == 0
             m.data_manager.update()
         mats.append(m)
+
+    # setup, outside the timed region: where the resident state sits relative to the boundary arrays
+    # decides between a fast and a slow mode of the kernel (+14 %); let every
+    # handle measure a few allocations with the real buffers and keep the fastest
+    tuning = []
+    if not args.no_tune:
+        for j, m in enumerate(mats):
+            info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr())
+            tuning.append({"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4),
+                           "candidates_tried": info["candidates_tried"]})
 
     def step(i):
         j = i % 3
@@ -363,6 +377,7 @@ def main():
                 "plastic_fraction_inc2_3_4": [round(x, 4) for x in plastic_frac],
                 "layout": "AoS (N,6)/(N,36) boundary arrays in HBM, SoA resident state",
                 "sharding": "independent contiguous point blocks, no data-path collective",
+                "placement_tuning": tuning if tuning else None,
             },
             "roofline": {
                 "bound": "hbm",
@@ -386,7 +401,7 @@ def main():
                 for m in mats:
                     m.close()
                 torch.cuda.empty_cache()
-                out["other_laws"] = other_laws(torch, jm, JAXMaterial, dev, n)
+                out["other_laws"] = other_laws(torch, jm, JAXMaterial, dev, n, tune=not args.no_tune)
             except Exception as exc:  # context only: never lose the headline line
                 out["other_laws"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline and args.law == "j2_linear":

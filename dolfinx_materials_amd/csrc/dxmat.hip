@@ -7,6 +7,7 @@
 // There is deliberately no CPU implementation behind this ABI.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -308,11 +309,22 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   const LawDesc& d = kLaws[law];
   if (d.n_slots > 0) {
     const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
-    if (hipMalloc(&m->state_base, 2 * bytes + m->s1_skew) != hipSuccess) {
-      fail(-3, "hipMalloc of %zu state bytes failed", 2 * bytes + m->s1_skew); return bail();
+#ifdef DXM_EXPERIMENT_EXTERNAL_STATE
+    // Placement experiments only (tools/placement_*.py build their own copy of the library with this
+    // flag): the state lives at caller-chosen device addresses and is not owned by the handle.
+    if (const char* e0 = getenv("DXM_STATE_EXTERNAL")) {
+      m->state[0] = reinterpret_cast<double*>(strtoull(e0, nullptr, 16));
+      m->state[1] = reinterpret_cast<double*>(reinterpret_cast<char*>(m->state[0]) + bytes + m->s1_skew);
+      if (const char* e1 = getenv("DXM_STATE_EXTERNAL_S1")) m->state[1] = reinterpret_cast<double*>(strtoull(e1, nullptr, 16));
+    } else
+#endif
+    {
+      if (hipMalloc(&m->state_base, 2 * bytes + m->s1_skew) != hipSuccess) {
+        fail(-3, "hipMalloc of %zu state bytes failed", 2 * bytes + m->s1_skew); return bail();
+      }
+      m->state[0] = m->state_base;
+      m->state[1] = reinterpret_cast<double*>(reinterpret_cast<char*>(m->state_base) + bytes + m->s1_skew);
     }
-    m->state[0] = m->state_base;
-    m->state[1] = reinterpret_cast<double*>(reinterpret_cast<char*>(m->state_base) + bytes + m->s1_skew);
   }
   // persistent grid = workgroups that are resident at once (occupancy query per kernel)
   {
@@ -562,6 +574,100 @@ int dxm_integrate_device(dxm_material* m, const double* grad_dev, double dt, dou
   if (m->n > 0 && (!grad_dev || !flux_dev || !ct_dev)) return fail(-1, "null device pointer");
   DEVICE_GUARD(m);
   return launch(m, grad_dev, flux_dev, ct_dev, (hipStream_t)hip_stream);
+}
+
+// ---- placement tuning ----------------------------------------------------------------------
+// The kernel time is bimodal (+13 % at 1e7 J2 points) in WHERE the resident state sits relative to
+// the caller's gradient / flux / tangent arrays: physical placement, invisible to and not steerable
+// from user space (profiles/r01_placement_*.jsonl).  What can be done is to
+// measure: try a few fresh state allocations with the caller's real buffers and keep the fastest.
+struct StateBlock { double* base; double* s[2]; };
+
+static int time_launches(dxm_material* m, const double* grad, double* flux, double* ct, int reps,
+                         hipEvent_t e0, hipEvent_t e1, float* best_ms) {
+  float best = 1e30f;
+  for (int r = 0; r < reps; ++r) {
+    HIP_TRY(hipEventRecord(e0, m->own_stream));
+    if (int rc = launch(m, grad, flux, ct, m->own_stream)) return rc;
+    HIP_TRY(hipEventRecord(e1, m->own_stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  *best_ms = best;
+  return 0;
+}
+
+int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
+                       int max_candidates, double* ms_before, double* ms_after, int* n_tried) {
+  if (!m) return fail(-1, "null handle");
+  if (ms_before) *ms_before = 0.0;
+  if (ms_after) *ms_after = 0.0;
+  if (n_tried) *n_tried = 0;
+  const LawDesc& d = kLaws[m->law];
+  if (m->n == 0 || d.n_slots == 0 || max_candidates <= 0) return 0;   // nothing resident to place
+  if (!grad_dev || !flux_dev || !ct_dev) return fail(-1, "null device pointer");
+  DEVICE_GUARD(m);
+  if (int rc = sync_last(m)) return rc;
+  const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
+  const size_t block = 2 * bytes + m->s1_skew;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  std::vector<void*> held;   // losers stay allocated until the end, so that the allocator keeps
+                             // handing out NEW physical ranges
+  auto cleanup = [&]() {
+    for (void* p : held) (void)hipFree(p);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  };
+  float t = 0.f;
+  if (int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 2, e0, e1, &t)) { cleanup(); return rc; }   // warm
+  const int reps = t > 0.f ? std::min(50, std::max(3, (int)(2.0f / t))) : 3;
+  if (int rc = time_launches(m, grad_dev, flux_dev, ct_dev, reps, e0, e1, &t)) { cleanup(); return rc; }
+  if (ms_before) *ms_before = t;
+  StateBlock best{m->state_base, {m->state[0], m->state[1]}};
+  float t_best = t, t_max = t;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  size_t budget = free_b / 2;
+  int tried = 0;
+  for (int c = 0; c < max_candidates; ++c) {
+    if (budget < block) break;
+    double* nb = nullptr;
+    if (hipMalloc(&nb, block) != hipSuccess) { (void)hipGetLastError(); break; }
+    budget -= block;
+    StateBlock cand{nb, {nb, reinterpret_cast<double*>(reinterpret_cast<char*>(nb) + bytes + m->s1_skew)}};
+    hipError_t ce = hipMemcpyAsync(cand.s[0], m->state[0], bytes, hipMemcpyDeviceToDevice, m->own_stream);
+    if (ce != hipSuccess) { held.push_back(nb); cleanup(); return fail(-2, "state copy failed: %s", hipGetErrorString(ce)); }
+    const StateBlock cur{m->state_base, {m->state[0], m->state[1]}};
+    m->state_base = cand.base; m->state[0] = cand.s[0]; m->state[1] = cand.s[1];
+    int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 1, e0, e1, &t);
+    if (!rc) rc = time_launches(m, grad_dev, flux_dev, ct_dev, reps, e0, e1, &t);
+    if (rc) {   // keep the handle usable: back to the previous block
+      m->state_base = cur.base; m->state[0] = cur.s[0]; m->state[1] = cur.s[1];
+      held.push_back(nb); cleanup(); return rc;
+    }
+    ++tried;
+    if (t > t_max) t_max = t;
+    if (t < t_best) {
+      held.push_back(best.base);   // the former best becomes a loser
+      best = cand; t_best = t;
+    } else {
+      held.push_back(cand.base);
+    }
+    // state[0] of `best` always holds s0: every candidate received a copy and the kernel never writes it
+    m->state_base = best.base; m->state[0] = best.s[0]; m->state[1] = best.s[1];
+    if (t_best <= 0.95f * t_max) break;   // both modes seen: the best is a fast placement
+  }
+  // one more launch on the chosen block so that s1, flux, tangent and the stats are those of `best`
+  int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 1, e0, e1, &t);
+  cleanup();
+  if (rc) return rc;
+  if (ms_after) *ms_after = t_best;
+  if (n_tried) *n_tried = tried;
+  return 0;
 }
 
 int dxm_get_stats(dxm_material* m, dxm_stats* stats) {

@@ -382,6 +382,17 @@ class HIPMaterial:
             )
         )
 
+    def tune_placement(self, grad_ptr, flux_ptr, ct_ptr, max_candidates=16):
+        """Optional, synchronous: measure the update on up to ``max_candidates`` fresh allocations of
+        the resident state with the caller's real device arrays and keep the fastest (the kernel time
+        is bimodal, up to 13 %, in where the state sits relative to those arrays: DESIGN.md section 3).
+        Acts like ``integrate_device(grad_ptr, flux_ptr, ct_ptr)``: the initial state is preserved,
+        the final state / flux / tangent are those of that update.  Returns the kernel times."""
+        before, after, tried = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        self._chk(self._lib.dxm_tune_placement(self._require(), int(grad_ptr), int(flux_ptr), int(ct_ptr),
+                                               int(max_candidates), C.byref(before), C.byref(after), C.byref(tried)))
+        return {"ms_before": before.value, "ms_after": after.value, "candidates_tried": tried.value}
+
     def isv_device(self, which, isv_ptr, stream=0):
         self._chk(self._lib.dxm_isv_device(self._require(), which, int(isv_ptr), int(stream) or None))
 

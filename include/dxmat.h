@@ -160,6 +160,18 @@ int dxm_get_stats(dxm_material* m, dxm_stats* stats);
 int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_stream);
 /* Device address of component `comp` of SoA state field `field` (npoints contiguous doubles). */
 const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp);
+/* Placement tuning (optional, synchronous; not capturable).  The update kernel's time depends on
+ * where the handle's resident state sits relative to the caller's gradient / flux / tangent arrays
+ * (bimodal, up to +13 % at 1e7 J2 points; physical placement, not steerable: DESIGN.md section 3).
+ * This call measures instead: it runs the update (exactly as dxm_integrate_device would, on the
+ * handle's own stream) with the caller's real device arrays on up to max_candidates fresh state
+ * allocations and keeps the fastest; s0 is preserved, s1 / flux_dev / ct_dev / the stats end up as
+ * after one dxm_integrate_device(grad_dev, ...).  Stops early once both modes have been seen.
+ * Temporarily holds up to half of the free device memory.  No-op for laws without state.
+ * ms_before / ms_after: kernel time (ms) on the initial / chosen placement; n_tried: candidates
+ * measured (any may be NULL).  No counterpart in the reference (its state lives in jax arrays). */
+int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
+                       int max_candidates, double* ms_before, double* ms_after, int* n_tried);
 /* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
 const char* dxm_kernel_name(const dxm_material* m);
 

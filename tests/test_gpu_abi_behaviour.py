@@ -170,3 +170,57 @@ def test_several_handles_side_by_side():
         ref = onp.j2_update(hs[k % 3] * (1 + 0.1 * k), np.zeros((n, 6)), np.zeros(n), 70e3, 0.3, onp.LinearHardening(250.0, 5e3))
         assert np.abs(got - ref["sig"]).max() < 1e-9 * np.abs(ref["sig"]).max()
         m.close()
+
+
+def test_tune_placement_preserves_state_and_results():
+    """dxm_tune_placement moves the resident state to another allocation: results before and after
+    must be bit-identical, s0 preserved, and it acts like one integrate_device."""
+    torch = pytest.importorskip("torch")
+    from helpers import E, NU, SIG0_V, SIGU_V, B_V, j2_history
+
+    dev = torch.device("cuda:0")
+    n = 200_003
+    h = j2_history(n, sig0=SIG0_V)
+    mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V)))
+    mat.set_data_manager(n)
+    st = torch.cuda.current_stream().cuda_stream
+    g = [torch.from_numpy(x).to(dev) for x in h[:3]]
+    flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+    mat.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+    mat.data_manager.update()
+    mat.integrate_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+    torch.cuda.synchronize()
+    ref_flux, ref_ct = flux.clone(), ct.clone()
+    s0_before = mat.get_initial_state_dict()
+    s1_before = mat.get_final_state_dict()
+    flux.zero_()
+    ct.zero_()
+    info = mat.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=3)
+    assert info["candidates_tried"] >= 1 and info["ms_after"] <= info["ms_before"] * 1.0001
+    torch.cuda.synchronize()
+    assert torch.equal(flux, ref_flux) and torch.equal(ct, ref_ct)       # acts like integrate_device
+    s0_after, s1_after = mat.get_initial_state_dict(), mat.get_final_state_dict()
+    for k in s0_before:
+        assert np.array_equal(s0_before[k], s0_after[k])
+    for k in s1_before:
+        assert np.array_equal(s1_before[k], s1_after[k])
+    rc, stats = mat.stats()
+    assert rc == 0 and stats["n_plastic"] > 0
+    # the handle keeps working on the new block: advance + next increment against the oracle-free identity
+    mat.data_manager.update()
+    mat.integrate_device(g[2].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+    torch.cuda.synchronize()
+    other = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V)))
+    other.set_data_manager(n)
+    f2, c2 = torch.empty_like(flux), torch.empty_like(ct)
+    for k in range(3):
+        other.integrate_device(g[k].data_ptr(), f2.data_ptr(), c2.data_ptr(), st)
+        if k < 2:
+            other.data_manager.update()
+    torch.cuda.synchronize()
+    assert torch.equal(flux, f2) and torch.equal(ct, c2)
+    # no state, nothing to place
+    el = JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU)))
+    el.set_data_manager(1000)
+    assert el.tune_placement(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr())["candidates_tried"] == 0

@@ -126,3 +126,25 @@ extern "C" int stream_mix_nt_launch(const void* rbuf, void* wbuf, int64_t npoint
                      write_bytes_per_point * 4);
   return (int)hipGetLastError();
 }
+
+// State-only variant: the 7 SoA slots in and 7 out of the J2 kernel, nothing else (placement studies).
+__global__ void __launch_bounds__(256) stream_mix_state_only_kernel(const double* __restrict__ s0, double* __restrict__ s1,
+                                                                    int64_t ld, int64_t ntiles) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t base = t * 64;
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a += s0[c * ld + base + lane];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) s1[c * ld + base + lane] = a;
+  }
+}
+
+extern "C" int stream_mix_state_only_launch(const void* s0, void* s1, int64_t ld, int64_t npoints, int blocks, void* stream) {
+  hipLaunchKernelGGL(stream_mix_state_only_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)s0,
+                     (double*)s1, ld, npoints / 64);
+  return (int)hipGetLastError();
+}
