@@ -326,7 +326,11 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
       m->state[1] = reinterpret_cast<double*>(reinterpret_cast<char*>(m->state_base) + bytes + m->s1_skew);
     }
   }
-  // persistent grid = workgroups that are resident at once (occupancy query per kernel)
+  // grid size, in workgroups per CU.  FeFp: the workgroups that are resident at once (persistent
+  // grid).  Small strain: 32 = 8 x the resident 4: a grid of exactly-resident workgroups starts all
+  // waves together and keeps them in lockstep (everybody loads, then everybody stores); workgroups
+  // that are dispatched as others retire spread those phases, 3-6 % faster at 1e7 points in the fast
+  // placement mode and 10 % in the slow one (tools/grid_sweep.py, profiles/r01_grid_sweep.jsonl).
   {
     int occ = 0;
     const void* fn = nullptr;
@@ -350,8 +354,9 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
       if (occ < 1) occ = 1;
       m->blocks_per_cu = occ;
     }
+    if (law == DXM_LAW_ELASTIC_ISO || law == DXM_LAW_J2_LINEAR || law == DXM_LAW_J2_VOCE) m->blocks_per_cu = 32;
     if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : m->blocks_per_cu;
-    if (m->blocks_per_cu > 16) m->blocks_per_cu = 16;
+    if (m->blocks_per_cu > 256) m->blocks_per_cu = 256;
   }
   m->stats_capacity = m->num_cu * m->blocks_per_cu * 8;  // up to 8 chunk launches per integrate
   if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {
@@ -633,8 +638,19 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
   (void)hipMemGetInfo(&free_b, &total_b);
   size_t budget = free_b / 2;
   int tried = 0;
+  const bool verbose = getenv("DXM_TUNE_VERBOSE") != nullptr;
+  if (verbose) fprintf(stderr, "[dxm_tune_placement] initial %p: %.4f ms\n", (void*)m->state_base, t);
   for (int c = 0; c < max_candidates; ++c) {
     if (budget < block) break;
+    // First half of the candidates: consecutive allocations (the mode usually flips within ~8 GB of
+    // allocated memory).  Second half: jump ahead by skip blocks of 1, 2, 4 ... GiB (at most 16) first.
+    if (c >= (max_candidates + 1) / 2) {
+      size_t skip = std::min<size_t>((size_t)1 << (30 + std::min(c - (max_candidates + 1) / 2, 4)), budget / 4);
+      void* sp = nullptr;
+      if (skip >= ((size_t)256 << 20) && budget >= skip + block) {
+        if (hipMalloc(&sp, skip) == hipSuccess) { held.push_back(sp); budget -= skip; } else (void)hipGetLastError();
+      }
+    }
     double* nb = nullptr;
     if (hipMalloc(&nb, block) != hipSuccess) { (void)hipGetLastError(); break; }
     budget -= block;
@@ -650,6 +666,7 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
       held.push_back(nb); cleanup(); return rc;
     }
     ++tried;
+    if (verbose) fprintf(stderr, "[dxm_tune_placement] candidate %d %p: %.4f ms\n", c, (void*)nb, t);
     if (t > t_max) t_max = t;
     if (t < t_best) {
       held.push_back(best.base);   // the former best becomes a loser

@@ -382,7 +382,7 @@ class HIPMaterial:
             )
         )
 
-    def tune_placement(self, grad_ptr, flux_ptr, ct_ptr, max_candidates=16):
+    def tune_placement(self, grad_ptr, flux_ptr, ct_ptr, max_candidates=24):
         """Optional, synchronous: measure the update on up to ``max_candidates`` fresh allocations of
         the resident state with the caller's real device arrays and keep the fastest (the kernel time
         is bimodal, up to 13 %, in where the state sits relative to those arrays: DESIGN.md section 3).

@@ -167,7 +167,10 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
  * handle's own stream) with the caller's real device arrays on up to max_candidates fresh state
  * allocations and keeps the fastest; s0 is preserved, s1 / flux_dev / ct_dev / the stats end up as
  * after one dxm_integrate_device(grad_dev, ...).  Stops early once both modes have been seen.
- * Temporarily holds up to half of the free device memory.  No-op for laws without state.
+ * The first half of the candidates are consecutive allocations, the second half jump ahead by skip
+ * blocks of 1, 2, 4 ... 16 GiB (fast regions can be tens of GB apart); everything but the winner is
+ * freed before returning; at most half of the free device memory is held meanwhile.  10 ms to a few
+ * seconds.  DXM_TUNE_VERBOSE=1 logs every candidate to stderr.  No-op for laws without state.
  * ms_before / ms_after: kernel time (ms) on the initial / chosen placement; n_tried: candidates
  * measured (any may be NULL).  No counterpart in the reference (its state lives in jax arrays). */
 int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,

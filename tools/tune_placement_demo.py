@@ -48,7 +48,7 @@ def main():
         before = tm(m)
         import time
         t0 = time.perf_counter()
-        info = m.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=int(os.environ.get("TUNE_K", "16")))
+        info = m.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=int(os.environ.get("TUNE_K", "24")))
         wall = time.perf_counter() - t0
         after = tm(m)
         print(json.dumps({"handle": k, "median_ms_before": before, "median_ms_after": after, "tune": {a: round(b, 4) for a, b in info.items()},
