@@ -130,7 +130,10 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True):
         m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
         if tune:
-            m.tune_placement(g1.data_ptr(), flux.data_ptr(), ct.data_ptr())
+            try:
+                m.tune_placement(g1.data_ptr(), flux.data_ptr(), ct.data_ptr())
+            except Exception:
+                pass
         for _ in range(2):
             m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         rc, stats = m.stats()
@@ -233,9 +236,12 @@ def main():
     tuning = []
     if not args.no_tune:
         for j, m in enumerate(mats):
-            info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr())
-            tuning.append({"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4),
-                           "candidates_tried": info["candidates_tried"]})
+            try:
+                info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr())
+                tuning.append({"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4),
+                               "candidates_tried": info["candidates_tried"]})
+            except Exception as exc:  # an optimisation of the setup: never lose the run over it
+                tuning.append({"error": repr(exc)})
 
     def step(i):
         j = i % 3
