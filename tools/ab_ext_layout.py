@@ -33,15 +33,22 @@ def main():
     ld = (n + 255) // 256 * 256 + 32
     half = 7 * ld * 8
     _lib.load()
-    libs = {k: _lib._bind(ctypes.CDLL(os.path.join(ROOT, "dolfinx_materials_amd", "_jit", "ab", f))) for k, f in
-            (("soa", "libdxmat_ext.so"), ("tiled", "libdxmat_ext_tiled.so"))}
-    pools = [torch.zeros(6 << 30, dtype=torch.uint8, device=dev) for _ in range(4)]
+    # LIBS="name=lib.so[:blocks_per_cu],..."
+    pairs = [x.split("=") for x in os.environ.get("LIBS", "soa=libdxmat_ext.so,tiled=libdxmat_ext_tiled.so").split(",")]
+    bpc = {k: (f.split(":")[1] if ":" in f else None) for k, f in pairs}
+    pairs = [(k, f.split(":")[0]) for k, f in pairs]
+    libs = {k: _lib._bind(ctypes.CDLL(os.path.join(ROOT, "dolfinx_materials_amd", "_jit", "ab", f))) for k, f in pairs}
+    kinds = [k for k, _ in pairs] * 2
+    pools = [torch.zeros(len(kinds) * (1200 << 20) + (64 << 20), dtype=torch.uint8, device=dev) for _ in range(4)]
     mats = []
     for pi, p in enumerate(pools):
-        for slot, kind in enumerate(("soa", "tiled", "soa", "tiled")):
+        for slot, kind in enumerate(kinds):
             a0 = p.data_ptr() + slot * (1200 << 20)
             os.environ["DXM_STATE_EXTERNAL"] = hex(a0)
             os.environ["DXM_STATE_EXTERNAL_S1"] = hex(a0 + half)
+            os.environ.pop("DXM_BLOCKS_PER_CU", None)
+            if bpc[kind]:
+                os.environ["DXM_BLOCKS_PER_CU"] = bpc[kind]
             orig = _lib.load
             _lib.load = lambda lib=libs[kind]: lib
             try:
