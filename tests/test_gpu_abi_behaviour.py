@@ -220,6 +220,11 @@ def test_tune_placement_preserves_state_and_results():
             other.data_manager.update()
     torch.cuda.synchronize()
     assert torch.equal(flux, f2) and torch.equal(ct, c2)
+    with pytest.raises(_lib.DxmError):
+        mat.tune_placement(0, flux.data_ptr(), ct.data_ptr())          # null gradient pointer
+    with pytest.raises(_lib.DxmError):
+        mat.tune_placement(g[1].data_ptr() + 8, flux.data_ptr(), ct.data_ptr())   # not 16-byte aligned
+    assert mat.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=0)["candidates_tried"] == 0
     # no state, nothing to place
     el = JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU)))
     el.set_data_manager(1000)
