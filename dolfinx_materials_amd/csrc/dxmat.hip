@@ -938,6 +938,13 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
     else
       hipLaunchKernelGGL(tet4_gradient_kernel<1>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
                          u_dev, mesh->n_cells, mesh->qp.nqp, grad_dev);
+  } else if (mesh->qp.nqp >= 4 && !getenv("DXM_GRADIENT_DIRECT")) {   // nodal data staged through LDS once per cell
+    if (kind == 0)
+      hipLaunchKernelGGL(hex8_gradient_staged_kernel<0>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
+                         u_dev, mesh->n_cells, mesh->qp, grad_dev);
+    else
+      hipLaunchKernelGGL(hex8_gradient_staged_kernel<1>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
+                         u_dev, mesh->n_cells, mesh->qp, grad_dev);
   } else if (kind == 0) {
     hipLaunchKernelGGL(hex8_gradient_kernel<0>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
                        u_dev, mesh->n_cells, mesh->qp, grad_dev);

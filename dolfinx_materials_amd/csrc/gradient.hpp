@@ -3,10 +3,12 @@
 // dolfinx_materials/quadrature_function.py:45-51, called from quadrature_map.py:247-253), so that
 // only the displacement vector (24 B/node) crosses PCIe instead of the strain array (48 B/point).
 //
-// One thread per Gauss point: gathers the 8 nodes of its cell (coordinates and displacements;
-// the 8 threads of a cell hit the same lines), builds the isoparametric Jacobian, and writes the
-// Mandel strain (6) or the deformation gradient F = I + grad u (9) in the AoS layout the
-// constitutive kernels consume.  Memory-light next to them (the mesh is read through L2).
+// One thread per Gauss point.  Hexahedra with >= 4 points per cell: the block gathers the nodal data of
+// its cells once into LDS (one (cell, corner) per thread) and the points read their cell's record
+// from there; otherwise every thread gathers its 8 nodes itself (the points of a cell hit the same
+// lines).  The thread builds the isoparametric Jacobian and writes the Mandel strain (6) or the
+// deformation gradient F = I + grad u (9) in the AoS layout the constitutive kernels consume.
+// 0.25 ms per 1e7 points staged vs 0.32 ms direct (profiles/r01_bench_gradient_v2.jsonl).
 #pragma once
 #include "dxm_common.hpp"
 
@@ -20,34 +22,28 @@ __device__ __constant__ const signed char HEX_SZ[8] = {-1, -1, -1, -1, 1, 1, 1, 
 
 struct QuadPoints { int nqp; double xi[27][3]; };
 
+// Displacement gradient of one Gauss point of a trilinear hexahedron.  `node(m, X, U)` hands over
+// coordinates and displacement of corner m (from global memory or from the LDS stage below).
 // kind 0: Mandel strain (6)  [utils.py:146-165];  kind 1: F = I + grad u (9) [utils.py:168-190]
-template <int KIND>
-__global__ void __launch_bounds__(256)
-hex8_gradient_kernel(const double* __restrict__ coords, const int32_t* __restrict__ conn,
-                     const double* __restrict__ u, const int64_t ncells, const QuadPoints qp,
-                     double* __restrict__ grad) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t npts = ncells * qp.nqp;
-  if (gid >= npts) return;
-  const int64_t cell = gid / qp.nqp;
-  const int q = (int)(gid - cell * qp.nqp);
-  const double x = qp.xi[q][0], y = qp.xi[q][1], z = qp.xi[q][2];
+template <int KIND, class NodeFn>
+__device__ __forceinline__ void hex8_point(const double x, const double y, const double z, NodeFn node,
+                                           double* __restrict__ o) {
   double Jm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // Jm[a][d] = dX_a / dxi_d
   double dN[8][3];
-  int32_t nd[8];
+  double Un[8][3];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    nd[m] = conn[cell * 8 + m];
     const double sx = HEX_SX[m], sy = HEX_SY[m], sz = HEX_SZ[m];
     dN[m][0] = 0.125 * sx * (1 + sy * y) * (1 + sz * z);
     dN[m][1] = 0.125 * sy * (1 + sx * x) * (1 + sz * z);
     dN[m][2] = 0.125 * sz * (1 + sx * x) * (1 + sy * y);
-    const double X0 = coords[3 * (int64_t)nd[m]], X1 = coords[3 * (int64_t)nd[m] + 1], X2 = coords[3 * (int64_t)nd[m] + 2];
+    double X[3];
+    node(m, X, Un[m]);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      Jm[0 + d] += X0 * dN[m][d];
-      Jm[3 + d] += X1 * dN[m][d];
-      Jm[6 + d] += X2 * dN[m][d];
+      Jm[0 + d] += X[0] * dN[m][d];
+      Jm[3 + d] += X[1] * dN[m][d];
+      Jm[6 + d] += X[2] * dN[m][d];
     }
   }
   // inverse of Jm: Ji[d][a] = dxi_d / dX_a
@@ -69,24 +65,83 @@ hex8_gradient_kernel(const double* __restrict__ coords, const int32_t* __restric
     double g[3];  // physical gradient of shape function m
 #pragma unroll
     for (int a = 0; a < 3; ++a) g[a] = dN[m][0] * Ji[0 + a] + dN[m][1] * Ji[3 + a] + dN[m][2] * Ji[6 + a];
-    const double u0 = u[3 * (int64_t)nd[m]], u1 = u[3 * (int64_t)nd[m] + 1], u2 = u[3 * (int64_t)nd[m] + 2];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      H[0 + a] += u0 * g[a];
-      H[3 + a] += u1 * g[a];
-      H[6 + a] += u2 * g[a];
+      H[0 + a] += Un[m][0] * g[a];
+      H[3 + a] += Un[m][1] * g[a];
+      H[6 + a] += Un[m][2] * g[a];
     }
   }
   if constexpr (KIND == 0) {
     const double r = 0.70710678118654752440;  // sqrt(2) * (1/2)
-    double* o = grad + gid * 6;
-    o[0] = H[0]; o[1] = H[4]; o[2] = H[8];
-    o[3] = r * (H[1] + H[3]); o[4] = r * (H[2] + H[6]); o[5] = r * (H[5] + H[7]);
+    double2_t* o2 = reinterpret_cast<double2_t*>(o);   // 48 B per point: 16 B aligned
+    o2[0] = double2_t{H[0], H[4]};
+    o2[1] = double2_t{H[8], r * (H[1] + H[3])};
+    o2[2] = double2_t{r * (H[2] + H[6]), r * (H[5] + H[7])};
   } else {
-    double* o = grad + gid * 9;
     o[0] = 1.0 + H[0]; o[1] = 1.0 + H[4]; o[2] = 1.0 + H[8];
     o[3] = H[1]; o[4] = H[3]; o[5] = H[2]; o[6] = H[6]; o[7] = H[5]; o[8] = H[7];
   }
+}
+
+// Direct variant (any nqp): every thread gathers the 8 nodes of its cell from global memory.
+template <int KIND>
+__global__ void __launch_bounds__(256)
+hex8_gradient_kernel(const double* __restrict__ coords, const int32_t* __restrict__ conn,
+                     const double* __restrict__ u, const int64_t ncells, const QuadPoints qp,
+                     double* __restrict__ grad) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t npts = ncells * qp.nqp;
+  if (gid >= npts) return;
+  const int64_t cell = gid / qp.nqp;
+  const int q = (int)(gid - cell * qp.nqp);
+  auto node = [&](int m, double* X, double* U) {
+    const int64_t nd = conn[cell * 8 + m];
+    X[0] = coords[3 * nd]; X[1] = coords[3 * nd + 1]; X[2] = coords[3 * nd + 2];
+    U[0] = u[3 * nd]; U[1] = u[3 * nd + 1]; U[2] = u[3 * nd + 2];
+  };
+  hex8_point<KIND>(qp.xi[q][0], qp.xi[q][1], qp.xi[q][2], node, grad + gid * (KIND == 0 ? 6 : 9));
+}
+
+// Staged variant (nqp >= 4, i.e. at most 65 cells per 256-point block): the points of a cell share
+// its 8 nodes, so the block first gathers every (cell, corner) once -- one corner per thread: 1
+// connectivity entry + 6 doubles instead of 8 + 48 per thread -- into LDS, and the points then read
+// their cell's record from there (the 8 lanes of a cell read the same addresses: LDS broadcast).
+// Record stride 50 doubles = 100 dwords: the 8 cells of a wave start 36 dwords apart modulo 64 banks.
+constexpr int HEX_STAGE_CELLS = 66;
+constexpr int HEX_STAGE_REC = 50;
+template <int KIND>
+__global__ void __launch_bounds__(256)
+hex8_gradient_staged_kernel(const double* __restrict__ coords, const int32_t* __restrict__ conn,
+                            const double* __restrict__ u, const int64_t ncells, const QuadPoints qp,
+                            double* __restrict__ grad) {
+  __shared__ __attribute__((aligned(16))) double nod[HEX_STAGE_CELLS * HEX_STAGE_REC];
+  const int64_t npts = ncells * qp.nqp;
+  const int64_t p0 = (int64_t)blockIdx.x * 256;
+  const int64_t plast = (p0 + 255 < npts ? p0 + 255 : npts - 1);
+  const int64_t c0 = p0 / qp.nqp;
+  const int ncb = (int)(plast / qp.nqp - c0) + 1;
+  for (int e = threadIdx.x; e < ncb * 8; e += 256) {
+    const int64_t nd = conn[c0 * 8 + e];   // the block's connectivity rows are contiguous
+    double2_t* d = reinterpret_cast<double2_t*>(nod + (e >> 3) * HEX_STAGE_REC + (e & 7) * 6);
+    const double X0 = coords[3 * nd], X1 = coords[3 * nd + 1], X2 = coords[3 * nd + 2];
+    const double U0 = u[3 * nd], U1 = u[3 * nd + 1], U2 = u[3 * nd + 2];
+    d[0] = double2_t{X0, X1};
+    d[1] = double2_t{X2, U0};
+    d[2] = double2_t{U1, U2};
+  }
+  __syncthreads();
+  const int64_t gid = p0 + threadIdx.x;
+  if (gid >= npts) return;
+  const int64_t cell = gid / qp.nqp;
+  const int q = (int)(gid - cell * qp.nqp);
+  const double2_t* rec = reinterpret_cast<const double2_t*>(nod + (int)(cell - c0) * HEX_STAGE_REC);
+  auto node = [&](int m, double* X, double* U) {
+    const double2_t a = rec[m * 3], b = rec[m * 3 + 1], c = rec[m * 3 + 2];
+    X[0] = a.x; X[1] = a.y; X[2] = b.x;
+    U[0] = b.y; U[1] = c.x; U[2] = c.y;
+  };
+  hex8_point<KIND>(qp.xi[q][0], qp.xi[q][1], qp.xi[q][2], node, grad + gid * (KIND == 0 ? 6 : 9));
 }
 
 // First-order tetrahedra (affine): the displacement gradient is constant per cell,
