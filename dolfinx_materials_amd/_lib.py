@@ -82,6 +82,7 @@ SYMBOLS = {
     "dxm_get_stats": (C.c_int, [_h, C.POINTER(Stats)]),
     "dxm_isv_device": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_void_p]),
     "dxm_state_ptr": (C.c_void_p, [_h, C.c_int, C.c_int, C.c_int]),
+    "dxm_integrate_displacement_device": (C.c_int, [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dxm_tune_placement": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dxm_kernel_name": (C.c_char_p, [_h]),

@@ -519,19 +519,32 @@ int dxm_revert(dxm_material* m) {
 // The block records of the launch go to m->d_stats[stats_off ...).
 template <int LAW>
 static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64_t off, int64_t cnt,
-                                const double* grad, double* flux, double* ct, int stats_off) {
+                                const double* grad, double* flux, double* ct, int stats_off,
+                                const Hex8Source* fused = nullptr) {
   const double* s0 = m->state[0] + off;
   double* s1 = m->state[1] + off;
+  BlockStats* bs = m->d_stats + stats_off;
+  if (fused) {   // strain evaluated in the kernel from the displacement vector (whole batch only)
+    if (m->sym_tangent)
+      hipLaunchKernelGGL((small_strain_kernel<LAW, true, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
+                         grad, s0, s1, m->ld, flux, ct, bs, *fused);
+    else
+      hipLaunchKernelGGL((small_strain_kernel<LAW, false, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
+                         grad, s0, s1, m->ld, flux, ct, bs, *fused);
+    return;
+  }
+  const Hex8Source none{};
   if (m->sym_tangent)
-    hipLaunchKernelGGL((small_strain_kernel<LAW, true>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
-                       grad, s0, s1, m->ld, flux, ct, m->d_stats + stats_off);
+    hipLaunchKernelGGL((small_strain_kernel<LAW, true, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
+                       grad, s0, s1, m->ld, flux, ct, bs, none);
   else
-    hipLaunchKernelGGL((small_strain_kernel<LAW, false>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
-                       grad, s0, s1, m->ld, flux, ct, m->d_stats + stats_off);
+    hipLaunchKernelGGL((small_strain_kernel<LAW, false, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
+                       grad, s0, s1, m->ld, flux, ct, bs, none);
 }
 
 static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double* grad, double* flux,
-                        double* ct, hipStream_t st, int stats_off, int* grid_out) {
+                        double* ct, hipStream_t st, int stats_off, int* grid_out,
+                        const Hex8Source* fused = nullptr) {
   if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
     return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
   const int64_t ntiles = (cnt + WAVE - 1) / WAVE;
@@ -541,9 +554,9 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
   if (stats_off + blocks > m->stats_capacity) return fail(-1, "internal: stats buffer too small");
   const int grid = (int)blocks;
   switch (m->law) {
-    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
-    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
-    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off); break;
+    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
+    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
+    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
     case DXM_LAW_FEFP_J2_VOCE:
       hipLaunchKernelGGL(fefp_kernel<1>, dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad,
                          m->state[0] + off, m->state[1] + off, m->ld, flux, ct, m->d_stats + stats_off);
@@ -559,10 +572,11 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
   return 0;
 }
 
-static int launch(dxm_material* m, const double* grad, double* flux, double* ct, hipStream_t st) {
+static int launch(dxm_material* m, const double* grad, double* flux, double* ct, hipStream_t st,
+                  const Hex8Source* fused = nullptr) {
   if (m->n == 0) { m->last_grid = 0; return 0; }
   int grid = 0;
-  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid)) return rc;
+  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused)) return rc;
   m->last_grid = grid;
   m->last_stream = st;
   m->launched = true;
@@ -742,12 +756,10 @@ static int ensure_host_path_buffers(dxm_material* m) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  if (!m->d_grad) {
-    HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * n * d.n_grad));
-    HIP_TRY(hipMalloc(&m->d_flux, sizeof(double) * n * d.n_flux));
-    HIP_TRY(hipMalloc(&m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad));  // sized for the full layout
-    if (total > 0) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * n * total));
-  }
+  if (!m->d_grad) HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * n * d.n_grad));
+  if (!m->d_flux) HIP_TRY(hipMalloc(&m->d_flux, sizeof(double) * n * d.n_flux));
+  if (!m->d_ct) HIP_TRY(hipMalloc(&m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad));  // sized for the full layout
+  if (total > 0 && !m->d_isv) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * n * total));
   return 0;
 }
 
@@ -978,6 +990,31 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
     return 0;
   };
   return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats);
+}
+
+int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const double* u_dev, double dt,
+                                      double* flux_dev, double* ct_dev, void* hip_stream) {
+  (void)dt;
+  if (!m || !mesh) return fail(-1, "null argument");
+  if (mesh->device != m->device) return fail(-1, "mesh and material live on different devices");
+  if (dxm_mesh_npoints(mesh) != m->n) return fail(-1, "mesh has %lld Gauss points, material %lld",
+                                                   (long long)dxm_mesh_npoints(mesh), (long long)m->n);
+  if (m->n > 0 && (!u_dev || !flux_dev || !ct_dev)) return fail(-1, "null device pointer");
+  DEVICE_GUARD(m);
+  hipStream_t st = (hipStream_t)hip_stream;
+  const LawDesc& d = kLaws[m->law];
+  const bool fusable = mesh->nodes_per_cell == 8 && mesh->qp.nqp == 8 && d.n_grad == 6 && !getenv("DXM_NO_FUSED_GRADIENT");
+  if (fusable) {   // one kernel: no gradient array at all
+    Hex8Source src{};
+    src.coords = mesh->d_coords; src.conn = mesh->d_conn; src.u = u_dev; src.ncells = mesh->n_cells;
+    for (int q = 0; q < 8; ++q)
+      for (int a = 0; a < 3; ++a) src.xi[q][a] = mesh->qp.xi[q][a];
+    return launch(m, flux_dev /* unused, only checked for alignment */, flux_dev, ct_dev, st, &src);
+  }
+  // two kernels on the caller's stream through the handle's gradient scratch
+  if (!m->d_grad) HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * m->n * d.n_grad));
+  if (int rc = dxm_mesh_gradient_device(mesh, u_dev, d.n_grad == 9 ? 1 : 0, m->d_grad, hip_stream)) return rc;
+  return launch(m, m->d_grad, flux_dev, ct_dev, st);
 }
 
 const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp) {

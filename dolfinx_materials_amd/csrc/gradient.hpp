@@ -22,28 +22,47 @@ __device__ __constant__ const signed char HEX_SZ[8] = {-1, -1, -1, -1, 1, 1, 1, 
 
 struct QuadPoints { int nqp; double xi[27][3]; };
 
+// What the fused displacement -> update kernels read instead of a gradient array: a hex8 mesh with
+// exactly 8 Gauss points per cell (one 64-point tile = 8 cells, one (cell, corner) per lane).
+struct Hex8Source {
+  const double* coords;
+  const int32_t* conn;
+  const double* u;
+  int64_t ncells;
+  double xi[8][3];
+};
+constexpr int HEX_FUSED_REC = 50;   // doubles per staged cell record (8 corners x 6, padded: see the staged kernel)
+
 // Displacement gradient of one Gauss point of a trilinear hexahedron.  `node(m, X, U)` hands over
-// coordinates and displacement of corner m (from global memory or from the LDS stage below).
-// kind 0: Mandel strain (6)  [utils.py:146-165];  kind 1: F = I + grad u (9) [utils.py:168-190]
-template <int KIND, class NodeFn>
-__device__ __forceinline__ void hex8_point(const double x, const double y, const double z, NodeFn node,
-                                           double* __restrict__ o) {
+// coordinates and displacement of corner m (from global memory or from an LDS stage).
+#ifndef HEX_UNROLL
+#define HEX_UNROLL 2
+#endif
+// reference gradient of shape function m at (x, y, z)
+__device__ __forceinline__ void hex8_dN(int m, double x, double y, double z, double* dN) {
+  const double sx = HEX_SX[m], sy = HEX_SY[m], sz = HEX_SZ[m];
+  dN[0] = 0.125 * sx * (1 + sy * y) * (1 + sz * z);
+  dN[1] = 0.125 * sy * (1 + sx * x) * (1 + sz * z);
+  dN[2] = 0.125 * sz * (1 + sx * x) * (1 + sy * y);
+}
+
+// Two passes over the corners (coordinates, then displacements) with the shape-function gradients
+// recomputed in the second one: ~70 VGPRs live instead of ~110 when dN and the nodal values of all 8
+// corners are kept (matters inside the fused update kernels, which run at 128).
+template <class NodeFn>
+__device__ __forceinline__ void hex8_disp_grad(const double x, const double y, const double z, NodeFn node,
+                                               double* __restrict__ H /* H[i][j] = du_i / dX_j */) {
   double Jm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // Jm[a][d] = dX_a / dxi_d
-  double dN[8][3];
-  double Un[8][3];
-#pragma unroll
+#pragma unroll HEX_UNROLL
   for (int m = 0; m < 8; ++m) {
-    const double sx = HEX_SX[m], sy = HEX_SY[m], sz = HEX_SZ[m];
-    dN[m][0] = 0.125 * sx * (1 + sy * y) * (1 + sz * z);
-    dN[m][1] = 0.125 * sy * (1 + sx * x) * (1 + sz * z);
-    dN[m][2] = 0.125 * sz * (1 + sx * x) * (1 + sy * y);
-    double X[3];
-    node(m, X, Un[m]);
+    double dN[3], X[3], U[3];
+    hex8_dN(m, x, y, z, dN);
+    node(m, X, U);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      Jm[0 + d] += X[0] * dN[m][d];
-      Jm[3 + d] += X[1] * dN[m][d];
-      Jm[6 + d] += X[2] * dN[m][d];
+      Jm[0 + d] += X[0] * dN[d];
+      Jm[3 + d] += X[1] * dN[d];
+      Jm[6 + d] += X[2] * dN[d];
     }
   }
   // inverse of Jm: Ji[d][a] = dxi_d / dX_a
@@ -59,19 +78,30 @@ __device__ __forceinline__ void hex8_point(const double x, const double y, const
     Ji[5] = (Jm[2] * Jm[3] - Jm[0] * Jm[5]) * idet;
     Ji[8] = (Jm[0] * Jm[4] - Jm[1] * Jm[3]) * idet;
   }
-  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H[i][j] = du_i / dX_j
 #pragma unroll
+  for (int k = 0; k < 9; ++k) H[k] = 0.0;
+#pragma unroll HEX_UNROLL
   for (int m = 0; m < 8; ++m) {
-    double g[3];  // physical gradient of shape function m
+    double dN[3], X[3], U[3], g[3];  // g: physical gradient of shape function m
+    hex8_dN(m, x, y, z, dN);
+    node(m, X, U);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) g[a] = dN[m][0] * Ji[0 + a] + dN[m][1] * Ji[3 + a] + dN[m][2] * Ji[6 + a];
+    for (int a = 0; a < 3; ++a) g[a] = dN[0] * Ji[0 + a] + dN[1] * Ji[3 + a] + dN[2] * Ji[6 + a];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      H[0 + a] += Un[m][0] * g[a];
-      H[3 + a] += Un[m][1] * g[a];
-      H[6 + a] += Un[m][2] * g[a];
+      H[0 + a] += U[0] * g[a];
+      H[3 + a] += U[1] * g[a];
+      H[6 + a] += U[2] * g[a];
     }
   }
+}
+
+// kind 0: Mandel strain (6)  [utils.py:146-165];  kind 1: F = I + grad u (9) [utils.py:168-190]
+template <int KIND, class NodeFn>
+__device__ __forceinline__ void hex8_point(const double x, const double y, const double z, NodeFn node,
+                                           double* __restrict__ o) {
+  double H[9];
+  hex8_disp_grad(x, y, z, node, H);
   if constexpr (KIND == 0) {
     const double r = 0.70710678118654752440;  // sqrt(2) * (1/2)
     double2_t* o2 = reinterpret_cast<double2_t*>(o);   // 48 B per point: 16 B aligned

@@ -382,6 +382,14 @@ class HIPMaterial:
             )
         )
 
+    def integrate_displacement_device(self, mesh, u_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
+        """Device-resident form of :meth:`integrate_displacement`: ``u_ptr`` is the device address of
+        the ``(n_nodes, 3)`` displacement vector, ``flux_ptr`` / ``ct_ptr`` device arrays as for
+        :meth:`integrate_device`; asynchronous on ``stream``.  For hex8 meshes with 8 Gauss points per
+        cell and the small-strain laws the gradient is evaluated inside the update kernel."""
+        self._chk(self._lib.dxm_integrate_displacement_device(
+            self._require(), mesh._handle, int(u_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None))
+
     def tune_placement(self, grad_ptr, flux_ptr, ct_ptr, max_candidates=24):
         """Optional, synchronous: measure the update on up to ``max_candidates`` fresh allocations of
         the resident state with the caller's real device arrays and keep the fastest (the kernel time

@@ -146,3 +146,59 @@ def test_tet4_gradient_matches_host_and_drives_the_update():
     fb, _, cb = b.integrate(eps_ref)
     assert a.last_stats["n_plastic"] > 0
     assert np.abs(fa - fb).max() < 1e-9 * np.abs(fb).max() and np.abs(ca - cb).max() < 1e-9 * np.abs(cb).max()
+
+
+@pytest.mark.parametrize("law", ["elastic", "j2_voce", "j2_linear_sym", "fefp"])
+@pytest.mark.parametrize("ncell", [3, 5])
+def test_integrate_displacement_device_equals_gradient_then_update(law, ncell):
+    """dxm_integrate_displacement_device (for hex8 x 8 points and the small-strain laws: gradient
+    evaluated inside the update kernel, no strain array) against the two-kernel sequence
+    dxm_mesh_gradient_device -> dxm_integrate_device, over two increments with an advance between."""
+    torch = pytest.importorskip("torch")
+    from helpers import E, NU, SIG0_V, SIGU_V, B_V, SIG0_F, SIGU_F, B_F, SIG0_LIN, H_LIN
+
+    dev = torch.device("cuda:0")
+    hm, coords = make_mesh(ncell)
+    conn = hm.conn
+    mesh = Hex8Mesh(coords, conn)
+    n = mesh.npoints            # 27 * 8 = 216 (ragged last tile) and 125 * 8 = 1000
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    kw = {}
+    if law == "elastic":
+        mk, kind, scale = (lambda: jm.ElasticBehavior(el)), 0, 5e-3
+    elif law == "j2_voce":
+        mk, kind, scale = (lambda: jm.vonMisesIsotropicHardening(el, jm.VoceHardening(SIG0_V, SIGU_V, B_V))), 0, 8e-3
+    elif law == "j2_linear_sym":
+        mk, kind, scale = (lambda: jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN))), 0, 8e-3
+        kw = {"tangent_layout": "sym"}
+    else:
+        mk, kind, scale = (lambda: jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F))), 1, 2e-2
+    rng = np.random.default_rng(3)
+    st = torch.cuda.current_stream().cuda_stream
+    a, b = JAXMaterial(mk(), **kw), JAXMaterial(mk(), **kw)
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    ng, nf = a._info.n_grad, a._info.n_flux
+    nt = 21 if kw else nf * ng
+    grad = torch.empty((n, ng), dtype=torch.float64, device=dev)
+    fa, fb = torch.empty((n, nf), dtype=torch.float64, device=dev), torch.empty((n, nf), dtype=torch.float64, device=dev)
+    ca, cb = torch.empty((n, nt), dtype=torch.float64, device=dev), torch.empty((n, nt), dtype=torch.float64, device=dev)
+    for t in (0.6, 1.0):
+        u = t * (coords * np.array([scale, -0.4 * scale, -0.4 * scale]) + rng.standard_normal(coords.shape) * 0.05 * scale)
+        ud = torch.from_numpy(u.ravel().copy()).to(dev)
+        mesh.gradient_device(ud.data_ptr(), kind, grad.data_ptr(), st)
+        a.integrate_device(grad.data_ptr(), fa.data_ptr(), ca.data_ptr(), st)
+        b.integrate_displacement_device(mesh, ud.data_ptr(), fb.data_ptr(), cb.data_ptr(), st)
+        torch.cuda.synchronize()
+        sa, sb = a.stats()[1], b.stats()[1]
+        assert sa == sb and sa["n_nan"] == 0
+        if law != "elastic":
+            assert sa["n_plastic"] > 0
+        # the in-kernel gradient uses the same arithmetic; fused-multiply-add contraction may differ by an ulp
+        scale_f = float(fa.abs().max())
+        assert float((fa - fb).abs().max()) <= 1e-12 * scale_f
+        assert float((ca - cb).abs().max()) <= 1e-12 * float(ca.abs().max())
+        for k, v in a.get_final_state_dict().items():
+            assert np.abs(v - b.get_final_state_dict()[k]).max() <= 1e-12 * max(np.abs(v).max(), 1e-300), k
+        a.data_manager.update()
+        b.data_manager.update()

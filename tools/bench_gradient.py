@@ -81,9 +81,16 @@ def main():
         m.integrate_device(grad.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
 
     t_both = timeit(torch, both, a.reps)
+    flux2, ct2 = torch.empty_like(flux), torch.empty_like(ct)
+    t_one_call = timeit(torch, lambda: m.integrate_displacement_device(mesh, ud.data_ptr(), flux2.data_ptr(), ct2.data_ptr(), st), a.reps)
+    both()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(flux, flux2)) and bool(torch.equal(ct, ct2))
+    dmax = float((flux - flux2).abs().max())
     rc, stats = m.stats()
     print(json.dumps({"cells": a.cells ** 3, "points": n, "nodes": len(coords), "law": a.law,
-                      "gradient_ms": round(t_grad, 4), "law_ms": round(t_law, 4), "both_ms": round(t_both, 4),
+                      "gradient_ms": round(t_grad, 4), "law_ms": round(t_law, 4), "both_ms": round(t_both, 4), "integrate_displacement_device_ms": round(t_one_call, 4),
+                      "same_result_as_two_kernels": same, "max_abs_flux_diff": dmax,
                       "gradient_write_GBs": round(n * ng * 8 / t_grad / 1e6, 1),
                       "plastic_fraction": round(stats["n_plastic"] / n, 3), "rc": rc}), flush=True)
 
