@@ -338,8 +338,8 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
       case DXM_LAW_ELASTIC_ISO: fn = (const void*)small_strain_kernel<LAW_ELASTIC, false>; break;
       case DXM_LAW_J2_LINEAR: fn = (const void*)small_strain_kernel<LAW_J2_LINEAR, false>; break;
       case DXM_LAW_J2_VOCE: fn = (const void*)small_strain_kernel<LAW_J2_VOCE, false>; break;
-      case DXM_LAW_FEFP_J2_LINEAR: fn = (const void*)fefp_kernel<0>; break;
-      default: fn = (const void*)fefp_kernel<1>; break;
+      case DXM_LAW_FEFP_J2_LINEAR: fn = (const void*)fefp_kernel<0, 0>; break;
+      default: fn = (const void*)fefp_kernel<1, 0>; break;
     }
     // residency from the kernel's own resources (the occupancy API over-reports on ROCm 7.2):
     // waves/SIMD by allocated VGPRs (512-entry file, granule 8), workgroups by LDS (160 KiB/CU)
@@ -558,13 +558,22 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
     case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
     case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
     case DXM_LAW_FEFP_J2_VOCE:
-      hipLaunchKernelGGL(fefp_kernel<1>, dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad,
-                         m->state[0] + off, m->state[1] + off, m->ld, flux, ct, m->d_stats + stats_off);
+    case DXM_LAW_FEFP_J2_LINEAR: {
+      const double* s0 = m->state[0] + off;
+      double* s1 = m->state[1] + off;
+      BlockStats* bs = m->d_stats + stats_off;
+      const Hex8Source none{};
+      const bool voce = m->law == DXM_LAW_FEFP_J2_VOCE;
+      if (fused && voce)
+        hipLaunchKernelGGL((fefp_kernel<1, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, *fused);
+      else if (fused)
+        hipLaunchKernelGGL((fefp_kernel<0, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, *fused);
+      else if (voce)
+        hipLaunchKernelGGL((fefp_kernel<1, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, none);
+      else
+        hipLaunchKernelGGL((fefp_kernel<0, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, none);
       break;
-    case DXM_LAW_FEFP_J2_LINEAR:
-      hipLaunchKernelGGL(fefp_kernel<0>, dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad,
-                         m->state[0] + off, m->state[1] + off, m->ld, flux, ct, m->d_stats + stats_off);
-      break;
+    }
     default: return fail(-1, "law %d not launchable", m->law);
   }
   HIP_TRY(hipGetLastError());
@@ -1003,7 +1012,7 @@ int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const dou
   DEVICE_GUARD(m);
   hipStream_t st = (hipStream_t)hip_stream;
   const LawDesc& d = kLaws[m->law];
-  const bool fusable = mesh->nodes_per_cell == 8 && mesh->qp.nqp == 8 && d.n_grad == 6 && !getenv("DXM_NO_FUSED_GRADIENT");
+  const bool fusable = mesh->nodes_per_cell == 8 && mesh->qp.nqp == 8 && !getenv("DXM_NO_FUSED_GRADIENT");
   if (fusable) {   // one kernel: no gradient array at all
     Hex8Source src{};
     src.coords = mesh->d_coords; src.conn = mesh->d_conn; src.u = u_dev; src.ncells = mesh->n_cells;

@@ -18,6 +18,7 @@
 // an LDS out-tile and leave as contiguous 1 KiB wave stores (full 64 B HBM write requests).
 #pragma once
 #include "dxm_common.hpp"
+#include "gradient.hpp"
 
 namespace dxm {
 
@@ -33,6 +34,7 @@ constexpr int F2_REC = 73;   // record stride: 54 staged doubles per point, padd
                              // point slots of a 32-lane read group land on (almost) disjoint banks
 constexpr int F2_OUT = ((F2_PPR * 81 + 127) / 128) * 128;   // out-tile, padded to whole KiB
 static_assert(F2_OUT >= FEFP_STAGE, "the out-tile aliases the F / PK1 staging region");
+static_assert(8 * HEX_FUSED_REC <= F2_PPR * F2_REC, "the 8 cell records of a fused tile live in the coefficient region");
 constexpr int F2_LDS_PER_WAVE = F2_OUT + F2_PPR * F2_REC;
 
 __device__ __forceinline__ double det3(const double* A) {
@@ -95,11 +97,14 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
 }
 
 // HARD: 0 = linear hardening R = sig0 + H p (prm.h1 = H), 1 = Voce (prm.h1 = sigu, prm.h2 = b)
-template <int HARD>
+// GRAD: 0 = F comes from the (N,9) array Fin; 1 = F = I + grad u is evaluated in the kernel from the
+//       displacement vector of a hex8 mesh with 8 Gauss points per cell (`src`, see small_strain.hpp)
+template <int HARD, int GRAD = 0>
 __global__ void __launch_bounds__(BLOCK, 2)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
             const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
-            double* __restrict__ Pout, double* __restrict__ ct, BlockStats* __restrict__ stats) {
+            double* __restrict__ Pout, double* __restrict__ ct, BlockStats* __restrict__ stats,
+            const Hex8Source src) {
   __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * F2_LDS_PER_WAVE];
   __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
 
@@ -137,43 +142,82 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     const bool valid = lane < npts;
     const int64_t gi = base + lane;
 
-    // ---- 1. coalesced load of F (64 x 9 doubles = 288 double2 per tile) ------------------------
-    if (npts == WAVE) {
-      const double2_t* gsrc = reinterpret_cast<const double2_t*>(Fin + base * 9);
-      double2_t v[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int idx = k * WAVE + lane;
-        v[k] = (idx < 288) ? stream_load<2>(gsrc + idx) : double2_t{0.0, 0.0};
-      }
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int idx = k * WAVE + lane;
-        if (idx < 288) stage2[idx] = v[k];
-      }
-    } else {  // ragged last tile: 8-byte accesses, identity for the missing points
-      const double* gsrc = Fin + base * 9;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const int idx = k * WAVE + lane;
-        const int c = idx % 9;
-        stage[idx] = (idx < npts * 9) ? gsrc[idx] : (c < 3 ? 1.0 : 0.0);
-      }
-    }
-    double p_n = 0.0, g6[6] = {1, 1, 1, 0, 0, 0};
-    if (valid) {
-      p_n = stream_load<3>(s0 + (int64_t)FEFP_SLOT_P * ld + gi);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) g6[c] = stream_load<3>(s0 + (int64_t)(FEFP_SLOT_CPI + c) * ld + gi);
-    }
-    wave_lds_sync();
     double F[9];
-    {
-      const double* f = stage + lane * 9;
-      F[0] = f[0]; F[4] = f[1]; F[8] = f[2]; F[1] = f[3]; F[3] = f[4];
-      F[2] = f[5]; F[6] = f[6]; F[5] = f[7]; F[7] = f[8];
+    double p_n = 0.0, g6[6] = {1, 1, 1, 0, 0, 0};
+    if constexpr (GRAD == 0) {
+      // ---- 1. coalesced load of F (64 x 9 doubles = 288 double2 per tile) ------------------------
+      if (npts == WAVE) {
+        const double2_t* gsrc = reinterpret_cast<const double2_t*>(Fin + base * 9);
+        double2_t v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int idx = k * WAVE + lane;
+          v[k] = (idx < 288) ? stream_load<2>(gsrc + idx) : double2_t{0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int idx = k * WAVE + lane;
+          if (idx < 288) stage2[idx] = v[k];
+        }
+      } else {  // ragged last tile: 8-byte accesses, identity for the missing points
+        const double* gsrc = Fin + base * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int idx = k * WAVE + lane;
+          const int c = idx % 9;
+          stage[idx] = (idx < npts * 9) ? gsrc[idx] : (c < 3 ? 1.0 : 0.0);
+        }
+      }
+      if (valid) {
+        p_n = stream_load<3>(s0 + (int64_t)FEFP_SLOT_P * ld + gi);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) g6[c] = stream_load<3>(s0 + (int64_t)(FEFP_SLOT_CPI + c) * ld + gi);
+      }
+      wave_lds_sync();
+      {
+        const double* f = stage + lane * 9;
+        F[0] = f[0]; F[4] = f[1]; F[8] = f[2]; F[1] = f[3]; F[3] = f[4];
+        F[2] = f[5]; F[6] = f[6]; F[5] = f[7]; F[7] = f[8];
+      }
+      wave_lds_sync();
+    } else {
+      // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
+      {
+        const int64_t cell = (base >> 3) + (lane >> 3);
+        double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
+        if (cell < src.ncells) {
+          const int64_t nd = src.conn[cell * 8 + (lane & 7)];
+          r0 = double2_t{src.coords[3 * nd], src.coords[3 * nd + 1]};
+          r1 = double2_t{src.coords[3 * nd + 2], src.u[3 * nd]};
+          r2 = double2_t{src.u[3 * nd + 1], src.u[3 * nd + 2]};
+        }
+        double2_t* d = reinterpret_cast<double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC + (lane & 7) * 6);
+        d[0] = r0; d[1] = r1; d[2] = r2;
+      }
+      wave_lds_sync();
+      {
+        const double2_t* rec = reinterpret_cast<const double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC);
+        auto node = [&](int m, double* X, double* U) {
+          const double2_t a = rec[m * 3], b = rec[m * 3 + 1], c = rec[m * 3 + 2];
+          X[0] = a.x; X[1] = a.y; X[2] = b.x;
+          U[0] = b.y; U[1] = c.x; U[2] = c.y;
+        };
+        const int q = lane & 7;
+        if (valid) {
+          hex8_disp_grad(src.xi[q][0], src.xi[q][1], src.xi[q][2], node, F);   // H[i][j], row-major like F
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) F[k] = 0.0;
+        }
+        F[0] += 1.0; F[4] += 1.0; F[8] += 1.0;
+      }
+      wave_lds_sync();  // the coefficient region is rewritten by the tangent rounds
+      if (valid) {
+        p_n = stream_load<3>(s0 + (int64_t)FEFP_SLOT_P * ld + gi);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) g6[c] = stream_load<3>(s0 + (int64_t)(FEFP_SLOT_CPI + c) * ld + gi);
+      }
     }
-    wave_lds_sync();
 
     // ---- 2. trial state ------------------------------------------------------------------------
     double G[9];

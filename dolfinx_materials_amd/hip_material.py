@@ -386,7 +386,7 @@ class HIPMaterial:
         """Device-resident form of :meth:`integrate_displacement`: ``u_ptr`` is the device address of
         the ``(n_nodes, 3)`` displacement vector, ``flux_ptr`` / ``ct_ptr`` device arrays as for
         :meth:`integrate_device`; asynchronous on ``stream``.  For hex8 meshes with 8 Gauss points per
-        cell and the small-strain laws the gradient is evaluated inside the update kernel."""
+        cell the gradient is evaluated inside the update kernel."""
         self._chk(self._lib.dxm_integrate_displacement_device(
             self._require(), mesh._handle, int(u_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None))
 
