@@ -761,11 +761,11 @@ int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_st
   return pack_isv_range(m, which, 0, m->n, isv_aos_dev, (hipStream_t)hip_stream);
 }
 
-static int ensure_host_path_buffers(dxm_material* m) {
+static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  if (!m->d_grad) HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * n * d.n_grad));
+  if (need_grad && !m->d_grad) HIP_TRY(hipMalloc(&m->d_grad, sizeof(double) * n * d.n_grad));
   if (!m->d_flux) HIP_TRY(hipMalloc(&m->d_flux, sizeof(double) * n * d.n_flux));
   if (!m->d_ct) HIP_TRY(hipMalloc(&m->d_ct, sizeof(double) * n * d.n_flux * d.n_grad));  // sized for the full layout
   if (total > 0 && !m->d_isv) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * n * total));
@@ -782,7 +782,7 @@ static int ensure_host_path_buffers(dxm_material* m) {
 // range; its block-stat records are appended after the previous chunk's.
 template <class Upload>
 static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
-                            double* ct_aos, dxm_stats* stats) {
+                            double* ct_aos, dxm_stats* stats, const Hex8Source* fused = nullptr) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
@@ -802,8 +802,10 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     hipStream_t st = streams[c & 1];
     if (int rc = upload(off, cnt, st)) return rc;
     int grid = 0;
-    if (int rc = launch_range(m, off, cnt, m->d_grad + off * d.n_grad, m->d_flux + off * d.n_flux,
-                              m->d_ct + off * nt, st, stats_off, &grid))
+    Hex8Source src{};
+    if (fused) { src = *fused; src.cell0 = off / 8; }   // chunks are multiples of 256 points = 32 cells
+    if (int rc = launch_range(m, off, cnt, fused ? m->d_flux : m->d_grad + off * d.n_grad, m->d_flux + off * d.n_flux,
+                              m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr))
       return rc;
     stats_off += grid;
     if (flux_aos)
@@ -977,6 +979,17 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
   return 0;
 }
 
+static Hex8Source hex8_source(const dxm_mesh* mesh, const double* u_dev) {
+  Hex8Source src{};
+  src.coords = mesh->d_coords; src.conn = mesh->d_conn; src.u = u_dev; src.ncells = mesh->n_cells; src.cell0 = 0;
+  for (int q = 0; q < 8; ++q)
+    for (int a = 0; a < 3; ++a) src.xi[q][a] = mesh->qp.xi[q][a];
+  return src;
+}
+static bool fusable(const dxm_mesh* mesh) {
+  return mesh->nodes_per_cell == 8 && mesh->qp.nqp == 8 && !getenv("DXM_NO_FUSED_GRADIENT");
+}
+
 int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
                                double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats) {
   (void)dt;
@@ -985,19 +998,26 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
   if (dxm_mesh_npoints(mesh) != m->n) return fail(-1, "mesh has %lld Gauss points, material %lld",
                                                    (long long)dxm_mesh_npoints(mesh), (long long)m->n);
   DEVICE_GUARD(m);
-  if (int rc = ensure_host_path_buffers(m)) return rc;
+  const bool fuse = fusable(mesh);   // hex8 x 8 points: gradient evaluated inside the update kernel
+  if (int rc = ensure_host_path_buffers(m, !fuse)) return rc;
   hipStream_t st = m->own_stream;
   if (m->launched) HIP_TRY(hipStreamSynchronize(m->last_stream));
   HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * 3 * mesh->n_nodes, hipMemcpyHostToDevice, st));
-  const int kind = kLaws[m->law].n_grad == 9 ? 1 : 0;
-  if (int rc = dxm_mesh_gradient_device(mesh, mesh->d_u, kind, m->d_grad, st)) return rc;
-  // the whole gradient array is produced on own_stream; chunks on the second stream wait for it
+  Hex8Source src{};
+  if (fuse) {
+    src = hex8_source(mesh, mesh->d_u);
+  } else {
+    const int kind = kLaws[m->law].n_grad == 9 ? 1 : 0;
+    if (int rc = dxm_mesh_gradient_device(mesh, mesh->d_u, kind, m->d_grad, st)) return rc;
+  }
+  // the displacement upload (and the gradient array) are produced on own_stream; chunks on the second stream wait for it
   if (!mesh->grad_done) HIP_TRY(hipEventCreateWithFlags(&mesh->grad_done, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(mesh->grad_done, st));
   auto upload = [&](int64_t, int64_t, hipStream_t s) -> int {
     if (s != st) HIP_TRY(hipStreamWaitEvent(s, mesh->grad_done, 0));
     return 0;
   };
+  if (fuse) return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats, &src);
   return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats);
 }
 
@@ -1012,12 +1032,8 @@ int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const dou
   DEVICE_GUARD(m);
   hipStream_t st = (hipStream_t)hip_stream;
   const LawDesc& d = kLaws[m->law];
-  const bool fusable = mesh->nodes_per_cell == 8 && mesh->qp.nqp == 8 && !getenv("DXM_NO_FUSED_GRADIENT");
-  if (fusable) {   // one kernel: no gradient array at all
-    Hex8Source src{};
-    src.coords = mesh->d_coords; src.conn = mesh->d_conn; src.u = u_dev; src.ncells = mesh->n_cells;
-    for (int q = 0; q < 8; ++q)
-      for (int a = 0; a < 3; ++a) src.xi[q][a] = mesh->qp.xi[q][a];
+  if (fusable(mesh)) {   // one kernel: no gradient array at all
+    const Hex8Source src = hex8_source(mesh, u_dev);
     return launch(m, flux_dev /* unused, only checked for alignment */, flux_dev, ct_dev, st, &src);
   }
   // two kernels on the caller's stream through the handle's gradient scratch

@@ -183,7 +183,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     } else {
       // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
       {
-        const int64_t cell = (base >> 3) + (lane >> 3);
+        const int64_t cell = src.cell0 + (base >> 3) + (lane >> 3);
         double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
         if (cell < src.ncells) {
           const int64_t nd = src.conn[cell * 8 + (lane & 7)];

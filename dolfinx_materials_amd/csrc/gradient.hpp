@@ -29,6 +29,7 @@ struct Hex8Source {
   const int32_t* conn;
   const double* u;
   int64_t ncells;
+  int64_t cell0;   // first cell of the launched point range (chunked host path), else 0
   double xi[8][3];
 };
 constexpr int HEX_FUSED_REC = 50;   // doubles per staged cell record (8 corners x 6, padded: see the staged kernel)

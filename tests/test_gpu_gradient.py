@@ -202,3 +202,37 @@ def test_integrate_displacement_device_equals_gradient_then_update(law, ncell):
             assert np.abs(v - b.get_final_state_dict()[k]).max() <= 1e-12 * max(np.abs(v).max(), 1e-300), k
         a.data_manager.update()
         b.data_manager.update()
+
+
+@pytest.mark.parametrize("law", ["j2", "fefp"])
+def test_chunked_host_displacement_path_uses_the_right_cells(law):
+    """Above 524288 points the host-buffer form is cut into chunks issued on two streams; with the gradient
+    evaluated inside the update kernel every chunk must start at its own cell (Hex8Source.cell0)."""
+    torch = pytest.importorskip("torch")
+    m, coords = make_mesh(42)            # 74 088 cells, 592 704 points -> 2 chunks
+    rng = np.random.default_rng(5)
+    u = (coords * np.array([8e-3, -3e-3, -3e-3]) + 2e-4 * rng.standard_normal(coords.shape)).ravel()
+    el = jm.LinearElasticIsotropic(E=70e3, nu=0.3)
+    beh = (jm.vonMisesIsotropicHardening(el, jm.LinearHardening(250.0, 5e3)) if law == "j2"
+           else jm.FeFpJ2Plasticity(el, jm.VoceHardening(500.0, 750.0, 1000.0)))
+    mesh = Hex8Mesh(coords, m.conn)
+    n = mesh.npoints
+    assert n > 2 * 262144
+    a, b = JAXMaterial(beh), JAXMaterial(beh)
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    fa, ia, ca = a.integrate_displacement(mesh, u)              # host path, chunked, fused
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    ng, nf = b._info.n_grad, b._info.n_flux
+    ud = torch.from_numpy(u.copy()).to(dev)
+    grad = torch.empty((n, ng), dtype=torch.float64, device=dev)
+    fb = torch.empty((n, nf), dtype=torch.float64, device=dev)
+    cb = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)
+    mesh.gradient_device(ud.data_ptr(), 0 if ng == 6 else 1, grad.data_ptr(), st)   # gradient kernel -> update kernel
+    b.integrate_device(grad.data_ptr(), fb.data_ptr(), cb.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert a.last_stats["n_plastic"] > 0 and a.last_stats["n_plastic"] == b.stats()[1]["n_plastic"]
+    fbh, cbh = fb.cpu().numpy(), cb.cpu().numpy().reshape(ca.shape)
+    assert np.abs(fa - fbh).max() <= 1e-12 * np.abs(fbh).max()
+    assert np.abs(ca - cbh).max() <= 1e-12 * np.abs(cbh).max()
