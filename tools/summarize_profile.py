@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--law", default="j2_linear")
     ap.add_argument("--alg-bytes", type=int, default=496)
     ap.add_argument("--no-traffic-json", action="store_true")
+    ap.add_argument("--command-text", default="`bash tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around\n"
+                    "`python3 bench.py --steps 30 --warmup 6 --no-cpu-baseline` (the default bench command without its CPU leg).")
     ap.add_argument("--steps", type=int, default=30, help="timed steps of the bench command = the LAST dispatches of the kernel")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.prefix) or ".", exist_ok=True)
@@ -65,7 +67,7 @@ def main():
                      "min_ns": min(e - b for b, e in last), "max_ns": max(e - b for b, e in last)}
 
     pmc, counts = {}, {}
-    for d in ("pmc_fetch", "pmc_write", "pmc_ea", "pmc_sq"):
+    for d in ("pmc_fetch", "pmc_write", "pmc_ea", "pmc_sq", "pmc_tcc"):
         c, n = counters(os.path.join(a.src, d), a.kernel)
         pmc.update(c)
         counts.update(n)
@@ -103,8 +105,7 @@ def main():
 
     with open(a.prefix + "_summary.md", "w") as f:
         f.write(f"# rocprofv3 summary: `{a.kernel}` ({a.law}, {a.points} points per launch)\n\n")
-        f.write("Command: `bash tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around\n")
-        f.write("`python3 bench.py --steps 30 --warmup 6 --no-cpu-baseline` (the default bench command without its CPU leg).\n\n## kernel-trace --stats\n\n")
+        f.write("Command: " + a.command_text + "\n\n## kernel-trace --stats\n\n")
         if rows:
             f.write("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
             for r in rows:
@@ -113,7 +114,7 @@ def main():
             f.write(f"\nAlgorithmic bytes per launch {alg:.4g} / average duration {float(krow['AverageNs'])/1e3:.1f} us = "
                     f"**{out['achieved_GBs_from_rocprof_avg']:.0f} GB/s** = {out['achieved_GBs_from_rocprof_avg']/8000:.3f} of the 8 TB/s HBM3E peak.\n")
         if timed:
-            f.write(f"\nTimed region of `bench.py` = the last {timed['dispatches']} of the {timed['of']} dispatches of this kernel in the trace (the earlier ones "
+            f.write(f"\nTimed region = the last {timed['dispatches']} of the {timed['of']} dispatches of this kernel in the trace (the earlier ones "
                     f"are setup: load-step contexts, placement tuning including its rejected slow candidates, warm-up): average "
                     f"**{timed['avg_ns']/1e3:.1f} us** (min {timed['min_ns']/1e3:.1f}, max {timed['max_ns']/1e3:.1f}) = **{alg/timed['avg_ns']:.0f} GB/s** = "
                     f"{alg/timed['avg_ns']/8000:.3f} of peak; this is the figure `roofline.achieved` of the bench line corresponds to.\n")
