@@ -99,3 +99,20 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "oracle_c" not in txt and "liboracle" not in txt, f
+
+
+def test_header_is_plain_c99_and_the_c_host_example_links():
+    """The boundary is a C ABI: include/dxmat.h must compile as strict C99, and a host written in plain C
+    (examples/c_host/j2_batch.c, no Python, no torch) must link against libdxmat.so."""
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "dxmat.h"\nint main(void) { return dxm_abi_version() == DXM_ABI_VERSION ? 0 : 1; }\n')
+        subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", src,
+                        "-o", os.path.join(d, "t.o")], check=True)
+    subprocess.run(["make", "-C", os.path.join(root, "examples", "c_host"), "clean"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(root, "examples", "c_host")], check=True, capture_output=True)
+    assert os.path.exists(os.path.join(root, "examples", "c_host", "j2_batch"))

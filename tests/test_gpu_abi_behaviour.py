@@ -229,3 +229,16 @@ def test_tune_placement_preserves_state_and_results():
     el = JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU)))
     el.set_data_manager(1000)
     assert el.tune_placement(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr())["candidates_tried"] == 0
+
+
+def test_plain_c_host_runs():
+    """examples/c_host/j2_batch.c: the constitutive update driven from C through include/dxmat.h only; exits 0 when
+    four load steps match the closed-form radial return to 1e-10."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples", "c_host")], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(root, "examples", "c_host", "j2_batch"), "300001"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "plastic points = 300001" in r.stdout
