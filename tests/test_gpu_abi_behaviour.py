@@ -196,8 +196,10 @@ def test_tune_placement_preserves_state_and_results():
     s1_before = mat.get_final_state_dict()
     flux.zero_()
     ct.zero_()
+    free_before = torch.cuda.mem_get_info()[0]
     info = mat.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=3)
     assert info["candidates_tried"] >= 1 and info["ms_after"] <= info["ms_before"] * 1.0001
+    assert abs(torch.cuda.mem_get_info()[0] - free_before) <= (4 << 20)   # losers and the replaced block are freed
     torch.cuda.synchronize()
     assert torch.equal(flux, ref_flux) and torch.equal(ct, ref_ct)       # acts like integrate_device
     s0_after, s1_after = mat.get_initial_state_dict(), mat.get_final_state_dict()
