@@ -14,11 +14,17 @@ converged state of the previous increment -- the cadence of QuadratureMap.update
 solve (reference solvers.py:72, quadrature_map.py:297-334).  Inputs and outputs are device
 resident in the AoS layout of the dolfinx quadrature Functions.
 
+Setup (untimed, before the W warm-up steps): the three load-step contexts are built by integrating the
+earlier increments, and every handle runs ``tune_placement`` once with the real arrays -- the kernel has a
+fast and a slow mode in where the resident state sits relative to them (DESIGN.md section 3);
+``config.placement_tuning`` reports what that did, ``--no-tune`` skips it.
+
 The JSON line also carries
   roofline      achieved algorithmic HBM GB/s of the constitutive kernel (496 B/point x points
                 per launch / mean launch duration from HIP events on the launch stream);
   cpu_baseline  the plain-C oracle ("port") timed on this box's host cores on a bounded sample;
-  gather        (N > 1) the same steps followed by an RCCL all-gather of stress and tangent.
+  gather_inclusive  (N > 1) the same steps followed by an RCCL all-gather of stress and tangent;
+  other_laws    (N = 1) kernel rates of the elastic, J2-Voce and FeFp laws at the same batch size.
 """
 from __future__ import annotations
 
