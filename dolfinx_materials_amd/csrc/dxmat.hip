@@ -520,20 +520,20 @@ int dxm_revert(dxm_material* m) {
 template <int LAW>
 static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64_t off, int64_t cnt,
                                 const double* grad, double* flux, double* ct, int stats_off,
-                                const Hex8Source* fused = nullptr) {
+                                const MeshSource* fused = nullptr) {
   const double* s0 = m->state[0] + off;
   double* s1 = m->state[1] + off;
   BlockStats* bs = m->d_stats + stats_off;
-  if (fused) {   // strain evaluated in the kernel from the displacement vector (whole batch only)
-    if (m->sym_tangent)
-      hipLaunchKernelGGL((small_strain_kernel<LAW, true, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
-                         grad, s0, s1, m->ld, flux, ct, bs, *fused);
-    else
-      hipLaunchKernelGGL((small_strain_kernel<LAW, false, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
-                         grad, s0, s1, m->ld, flux, ct, bs, *fused);
+  if (fused) {   // strain evaluated in the kernel from the displacement vector
+#define DXM_LAUNCH_SS(SYM, G)                                                                              \
+  hipLaunchKernelGGL((small_strain_kernel<LAW, SYM, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, \
+                     m->ld, flux, ct, bs, *fused)
+    if (fused->kind == 1) { if (m->sym_tangent) DXM_LAUNCH_SS(true, 1); else DXM_LAUNCH_SS(false, 1); }
+    else                  { if (m->sym_tangent) DXM_LAUNCH_SS(true, 2); else DXM_LAUNCH_SS(false, 2); }
+#undef DXM_LAUNCH_SS
     return;
   }
-  const Hex8Source none{};
+  const MeshSource none{};
   if (m->sym_tangent)
     hipLaunchKernelGGL((small_strain_kernel<LAW, true, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
                        grad, s0, s1, m->ld, flux, ct, bs, none);
@@ -544,7 +544,7 @@ static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64
 
 static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double* grad, double* flux,
                         double* ct, hipStream_t st, int stats_off, int* grid_out,
-                        const Hex8Source* fused = nullptr) {
+                        const MeshSource* fused = nullptr) {
   if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
     return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
   const int64_t ntiles = (cnt + WAVE - 1) / WAVE;
@@ -562,16 +562,17 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
       const double* s0 = m->state[0] + off;
       double* s1 = m->state[1] + off;
       BlockStats* bs = m->d_stats + stats_off;
-      const Hex8Source none{};
+      const MeshSource none{};
       const bool voce = m->law == DXM_LAW_FEFP_J2_VOCE;
-      if (fused && voce)
-        hipLaunchKernelGGL((fefp_kernel<1, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, *fused);
-      else if (fused)
-        hipLaunchKernelGGL((fefp_kernel<0, 1>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, *fused);
+#define DXM_LAUNCH_FEFP(HARD, G) \
+  hipLaunchKernelGGL((fefp_kernel<HARD, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, *fused)
+      if (fused && fused->kind == 1) { if (voce) DXM_LAUNCH_FEFP(1, 1); else DXM_LAUNCH_FEFP(0, 1); }
+      else if (fused)                { if (voce) DXM_LAUNCH_FEFP(1, 2); else DXM_LAUNCH_FEFP(0, 2); }
       else if (voce)
         hipLaunchKernelGGL((fefp_kernel<1, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, none);
       else
         hipLaunchKernelGGL((fefp_kernel<0, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, none);
+#undef DXM_LAUNCH_FEFP
       break;
     }
     default: return fail(-1, "law %d not launchable", m->law);
@@ -582,7 +583,7 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
 }
 
 static int launch(dxm_material* m, const double* grad, double* flux, double* ct, hipStream_t st,
-                  const Hex8Source* fused = nullptr) {
+                  const MeshSource* fused = nullptr) {
   if (m->n == 0) { m->last_grid = 0; return 0; }
   int grid = 0;
   if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused)) return rc;
@@ -782,7 +783,7 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 // range; its block-stat records are appended after the previous chunk's.
 template <class Upload>
 static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
-                            double* ct_aos, dxm_stats* stats, const Hex8Source* fused = nullptr) {
+                            double* ct_aos, dxm_stats* stats, const MeshSource* fused = nullptr) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
@@ -802,8 +803,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     hipStream_t st = streams[c & 1];
     if (int rc = upload(off, cnt, st)) return rc;
     int grid = 0;
-    Hex8Source src{};
-    if (fused) { src = *fused; src.cell0 = off / 8; }   // chunks are multiples of 256 points = 32 cells
+    MeshSource src{};
+    if (fused) { src = *fused; src.point0 = off; }
     if (int rc = launch_range(m, off, cnt, fused ? m->d_flux : m->d_grad + off * d.n_grad, m->d_flux + off * d.n_flux,
                               m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr))
       return rc;
@@ -979,16 +980,22 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
   return 0;
 }
 
-static Hex8Source hex8_source(const dxm_mesh* mesh, const double* u_dev) {
-  Hex8Source src{};
-  src.coords = mesh->d_coords; src.conn = mesh->d_conn; src.u = u_dev; src.ncells = mesh->n_cells; src.cell0 = 0;
-  for (int q = 0; q < 8; ++q)
-    for (int a = 0; a < 3; ++a) src.xi[q][a] = mesh->qp.xi[q][a];
+// kind of in-kernel gradient evaluation this mesh allows: 1 hex8 x 8 points, 2 tet4, 0 none
+static int fused_kind(const dxm_mesh* mesh) {
+  if (getenv("DXM_NO_FUSED_GRADIENT")) return 0;
+  if (mesh->nodes_per_cell == 8) return mesh->qp.nqp == 8 ? 1 : 0;
+  return mesh->nodes_per_cell == 4 ? 2 : 0;
+}
+static MeshSource mesh_source(const dxm_mesh* mesh, const double* u_dev) {
+  MeshSource src{};
+  src.coords = mesh->d_coords; src.conn = mesh->d_conn; src.u = u_dev; src.ncells = mesh->n_cells; src.point0 = 0;
+  src.kind = fused_kind(mesh); src.nqp = mesh->qp.nqp;
+  if (src.kind == 1)
+    for (int q = 0; q < 8; ++q)
+      for (int a = 0; a < 3; ++a) src.xi[q][a] = mesh->qp.xi[q][a];
   return src;
 }
-static bool fusable(const dxm_mesh* mesh) {
-  return mesh->nodes_per_cell == 8 && mesh->qp.nqp == 8 && !getenv("DXM_NO_FUSED_GRADIENT");
-}
+static bool fusable(const dxm_mesh* mesh) { return fused_kind(mesh) != 0; }
 
 int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
                                double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats) {
@@ -1003,9 +1010,9 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
   hipStream_t st = m->own_stream;
   if (m->launched) HIP_TRY(hipStreamSynchronize(m->last_stream));
   HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * 3 * mesh->n_nodes, hipMemcpyHostToDevice, st));
-  Hex8Source src{};
+  MeshSource src{};
   if (fuse) {
-    src = hex8_source(mesh, mesh->d_u);
+    src = mesh_source(mesh, mesh->d_u);
   } else {
     const int kind = kLaws[m->law].n_grad == 9 ? 1 : 0;
     if (int rc = dxm_mesh_gradient_device(mesh, mesh->d_u, kind, m->d_grad, st)) return rc;
@@ -1033,7 +1040,7 @@ int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const dou
   hipStream_t st = (hipStream_t)hip_stream;
   const LawDesc& d = kLaws[m->law];
   if (fusable(mesh)) {   // one kernel: no gradient array at all
-    const Hex8Source src = hex8_source(mesh, u_dev);
+    const MeshSource src = mesh_source(mesh, u_dev);
     return launch(m, flux_dev /* unused, only checked for alignment */, flux_dev, ct_dev, st, &src);
   }
   // two kernels on the caller's stream through the handle's gradient scratch

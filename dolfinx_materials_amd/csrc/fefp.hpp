@@ -97,14 +97,14 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
 }
 
 // HARD: 0 = linear hardening R = sig0 + H p (prm.h1 = H), 1 = Voce (prm.h1 = sigu, prm.h2 = b)
-// GRAD: 0 = F comes from the (N,9) array Fin; 1 = F = I + grad u is evaluated in the kernel from the
-//       displacement vector of a hex8 mesh with 8 Gauss points per cell (`src`, see small_strain.hpp)
+// GRAD: 0 = F comes from the (N,9) array Fin; 1 / 2 = F = I + grad u is evaluated in the kernel from the
+//       displacement vector of a hex8 mesh with 8 Gauss points per cell / of a tet4 mesh (`src`, see small_strain.hpp)
 template <int HARD, int GRAD = 0>
 __global__ void __launch_bounds__(BLOCK, 2)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
             const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
             double* __restrict__ Pout, double* __restrict__ ct, BlockStats* __restrict__ stats,
-            const Hex8Source src) {
+            const MeshSource src) {
   __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * F2_LDS_PER_WAVE];
   __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
 
@@ -181,37 +181,46 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       }
       wave_lds_sync();
     } else {
-      // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
-      {
-        const int64_t cell = src.cell0 + (base >> 3) + (lane >> 3);
-        double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
-        if (cell < src.ncells) {
-          const int64_t nd = src.conn[cell * 8 + (lane & 7)];
-          r0 = double2_t{src.coords[3 * nd], src.coords[3 * nd + 1]};
-          r1 = double2_t{src.coords[3 * nd + 2], src.u[3 * nd]};
-          r2 = double2_t{src.u[3 * nd + 1], src.u[3 * nd + 2]};
+      if constexpr (GRAD == 1) {
+        // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
+        {
+          const int64_t cell = ((src.point0 + base) >> 3) + (lane >> 3);
+          double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
+          if (cell < src.ncells) {
+            const int64_t nd = src.conn[cell * 8 + (lane & 7)];
+            r0 = double2_t{src.coords[3 * nd], src.coords[3 * nd + 1]};
+            r1 = double2_t{src.coords[3 * nd + 2], src.u[3 * nd]};
+            r2 = double2_t{src.u[3 * nd + 1], src.u[3 * nd + 2]};
+          }
+          double2_t* d = reinterpret_cast<double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC + (lane & 7) * 6);
+          d[0] = r0; d[1] = r1; d[2] = r2;
         }
-        double2_t* d = reinterpret_cast<double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC + (lane & 7) * 6);
-        d[0] = r0; d[1] = r1; d[2] = r2;
-      }
-      wave_lds_sync();
-      {
-        const double2_t* rec = reinterpret_cast<const double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC);
-        auto node = [&](int m, double* X, double* U) {
-          const double2_t a = rec[m * 3], b = rec[m * 3 + 1], c = rec[m * 3 + 2];
-          X[0] = a.x; X[1] = a.y; X[2] = b.x;
-          U[0] = b.y; U[1] = c.x; U[2] = c.y;
-        };
-        const int q = lane & 7;
+        wave_lds_sync();
+        {
+          const double2_t* rec = reinterpret_cast<const double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC);
+          auto node = [&](int m, double* X, double* U) {
+            const double2_t a = rec[m * 3], b = rec[m * 3 + 1], c = rec[m * 3 + 2];
+            X[0] = a.x; X[1] = a.y; X[2] = b.x;
+            U[0] = b.y; U[1] = c.x; U[2] = c.y;
+          };
+          const int q = lane & 7;
+          if (valid) {
+            hex8_disp_grad(src.xi[q][0], src.xi[q][1], src.xi[q][2], node, F);   // H[i][j], row-major like F
+          } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) F[k] = 0.0;
+          }
+        }
+        wave_lds_sync();  // the coefficient region is rewritten by the tangent rounds
+      } else {
         if (valid) {
-          hex8_disp_grad(src.xi[q][0], src.xi[q][1], src.xi[q][2], node, F);   // H[i][j], row-major like F
+          tet4_cell_disp_grad(src.coords, src.conn, src.u, (src.point0 + gi) / src.nqp, F);
         } else {
 #pragma unroll
           for (int k = 0; k < 9; ++k) F[k] = 0.0;
         }
-        F[0] += 1.0; F[4] += 1.0; F[8] += 1.0;
       }
-      wave_lds_sync();  // the coefficient region is rewritten by the tangent rounds
+      F[0] += 1.0; F[4] += 1.0; F[8] += 1.0;
       if (valid) {
         p_n = stream_load<3>(s0 + (int64_t)FEFP_SLOT_P * ld + gi);
 #pragma unroll

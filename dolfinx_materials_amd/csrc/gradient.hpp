@@ -22,15 +22,18 @@ __device__ __constant__ const signed char HEX_SZ[8] = {-1, -1, -1, -1, 1, 1, 1, 
 
 struct QuadPoints { int nqp; double xi[27][3]; };
 
-// What the fused displacement -> update kernels read instead of a gradient array: a hex8 mesh with
-// exactly 8 Gauss points per cell (one 64-point tile = 8 cells, one (cell, corner) per lane).
-struct Hex8Source {
+// What the fused displacement -> update kernels read instead of a gradient array.
+//   kind 1: hex8 mesh with exactly 8 Gauss points per cell (one 64-point tile = 8 cells, one (cell, corner) per lane)
+//   kind 2: tet4 mesh, any number of points per cell (every lane gathers the 4 nodes of its own cell)
+struct MeshSource {
   const double* coords;
   const int32_t* conn;
   const double* u;
   int64_t ncells;
-  int64_t cell0;   // first cell of the launched point range (chunked host path), else 0
-  double xi[8][3];
+  int64_t point0;   // first Gauss point of the launched range (chunked host path), else 0
+  int32_t kind;
+  int32_t nqp;
+  double xi[8][3];  // hex8 only
 };
 constexpr int HEX_FUSED_REC = 50;   // doubles per staged cell record (8 corners x 6, padded: see the staged kernel)
 
@@ -179,22 +182,8 @@ hex8_gradient_staged_kernel(const double* __restrict__ coords, const int32_t* __
 //   H = sum_m u_m (x) grad N_m,  grad N from the inverse of the edge matrix [X1-X0, X2-X0, X3-X0].
 // One thread per Gauss point (the nqp points of a cell repeat the cell value, as a dolfinx
 // quadrature Function of degree > 1 would hold it).
-template <int KIND>
-__global__ void __launch_bounds__(256)
-tet4_gradient_kernel(const double* __restrict__ coords, const int32_t* __restrict__ conn,
-                     const double* __restrict__ u, const int64_t ncells, const int nqp,
-                     double* __restrict__ grad) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= ncells * nqp) return;
-  const int64_t cell = gid / nqp;
-  int64_t nd[4];
-  double X[4][3], U[4][3];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    nd[m] = conn[cell * 4 + m];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { X[m][a] = coords[3 * nd[m] + a]; U[m][a] = u[3 * nd[m] + a]; }
-  }
+// Displacement gradient of a linear tetrahedron from the coordinates X and displacements U of its 4 nodes.
+__device__ __forceinline__ void tet4_disp_grad(const double (*X)[3], const double (*U)[3], double* __restrict__ H) {
   // A[a][d] = X_{d+1}[a] - X_0[a]  (dX_a / dxi_d for the reference tetrahedron)
   double A[9];
 #pragma unroll
@@ -214,12 +203,35 @@ tet4_gradient_kernel(const double* __restrict__ coords, const int32_t* __restric
     Ai[8] = (A[0] * A[4] - A[1] * A[3]) * idet;
   }
   // H[i][a] = sum_d (U_{d+1}[i] - U_0[i]) Ai[d][a]
-  double H[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
       H[i * 3 + a] = (U[1][i] - U[0][i]) * Ai[0 + a] + (U[2][i] - U[0][i]) * Ai[3 + a] + (U[3][i] - U[0][i]) * Ai[6 + a];
+}
+
+// gathers the 4 nodes of `cell` and evaluates its (constant) displacement gradient
+__device__ __forceinline__ void tet4_cell_disp_grad(const double* __restrict__ coords, const int32_t* __restrict__ conn,
+                                                    const double* __restrict__ u, int64_t cell, double* __restrict__ H) {
+  double X[4][3], U[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int64_t nd = conn[cell * 4 + m];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { X[m][a] = coords[3 * nd + a]; U[m][a] = u[3 * nd + a]; }
+  }
+  tet4_disp_grad(X, U, H);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+tet4_gradient_kernel(const double* __restrict__ coords, const int32_t* __restrict__ conn,
+                     const double* __restrict__ u, const int64_t ncells, const int nqp,
+                     double* __restrict__ grad) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncells * nqp) return;
+  double H[9];
+  tet4_cell_disp_grad(coords, conn, u, gid / nqp, H);
   if constexpr (KIND == 0) {
     const double r = 0.70710678118654752440;
     double* o = grad + gid * 6;

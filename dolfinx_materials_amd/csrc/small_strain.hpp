@@ -64,13 +64,14 @@ __device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
 // the displacement vector of a hex8 mesh with 8 Gauss points per cell (`src`; `eps` unused): lane
 // (cell c of the tile, corner k) gathers one node into a wave-private LDS record, every lane then
 // evaluates the isoparametric gradient at its own point -- the strain array (48 B/point written by the
-// gradient kernel and read back here) never exists.
+// gradient kernel and read back here) never exists.  GRAD = 2: tet4 mesh, every lane gathers the 4
+// nodes of its own cell (the gradient is constant per cell).
 template <int LAW, bool SYM, int GRAD = 0>
 __global__ void __launch_bounds__(BLOCK, 4)  // 4 waves per SIMD; a 5-wave (96 VGPR) build measured 1 % slower
 small_strain_kernel(const LawParams prm, const int64_t n, const double* __restrict__ eps,
                     const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
                     double* __restrict__ sig, double* __restrict__ ct,
-                    BlockStats* __restrict__ stats, const Hex8Source src) {
+                    BlockStats* __restrict__ stats, const MeshSource src) {
   __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * SS_LDS_PER_WAVE];
   __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
 
@@ -125,41 +126,52 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
       }
       wave_lds_sync();  // staging region is reused for the stress below
     } else {
-      // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
-      {
-        const int64_t cell = src.cell0 + (base >> 3) + (lane >> 3);
-        double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
-        if (cell < src.ncells) {
-          const int64_t nd = src.conn[cell * 8 + (lane & 7)];
-          r0 = double2_t{src.coords[3 * nd], src.coords[3 * nd + 1]};
-          r1 = double2_t{src.coords[3 * nd + 2], src.u[3 * nd]};
-          r2 = double2_t{src.u[3 * nd + 1], src.u[3 * nd + 2]};
+      double Hd[9];
+      if constexpr (GRAD == 1) {
+        // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
+        {
+          const int64_t cell = ((src.point0 + base) >> 3) + (lane >> 3);
+          double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
+          if (cell < src.ncells) {
+            const int64_t nd = src.conn[cell * 8 + (lane & 7)];
+            r0 = double2_t{src.coords[3 * nd], src.coords[3 * nd + 1]};
+            r1 = double2_t{src.coords[3 * nd + 2], src.u[3 * nd]};
+            r2 = double2_t{src.u[3 * nd + 1], src.u[3 * nd + 2]};
+          }
+          double2_t* d = reinterpret_cast<double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC + (lane & 7) * 6);
+          d[0] = r0; d[1] = r1; d[2] = r2;
         }
-        double2_t* d = reinterpret_cast<double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC + (lane & 7) * 6);
-        d[0] = r0; d[1] = r1; d[2] = r2;
-      }
-      wave_lds_sync();
-      // ---- 2'. strain at my Gauss point (point q = lane & 7 of cell lane >> 3) -------------------
-      {
-        const double2_t* rec = reinterpret_cast<const double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC);
-        auto node = [&](int m, double* X, double* U) {
-          const double2_t a = rec[m * 3], b = rec[m * 3 + 1], c = rec[m * 3 + 2];
-          X[0] = a.x; X[1] = a.y; X[2] = b.x;
-          U[0] = b.y; U[1] = c.x; U[2] = c.y;
-        };
-        const int q = lane & 7;
-        double Hd[9];
+        wave_lds_sync();
+        // ---- 2'. displacement gradient at my Gauss point (point q = lane & 7 of cell lane >> 3) -----
+        {
+          const double2_t* rec = reinterpret_cast<const double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC);
+          auto node = [&](int m, double* X, double* U) {
+            const double2_t a = rec[m * 3], b = rec[m * 3 + 1], c = rec[m * 3 + 2];
+            X[0] = a.x; X[1] = a.y; X[2] = b.x;
+            U[0] = b.y; U[1] = c.x; U[2] = c.y;
+          };
+          const int q = lane & 7;
+          if (valid) {
+            hex8_disp_grad(src.xi[q][0], src.xi[q][1], src.xi[q][2], node, Hd);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Hd[k] = 0.0;
+          }
+        }
+        wave_lds_sync();  // the coefficient region is rewritten in step 5
+      } else {
         if (valid) {
-          hex8_disp_grad(src.xi[q][0], src.xi[q][1], src.xi[q][2], node, Hd);
+          tet4_cell_disp_grad(src.coords, src.conn, src.u, (src.point0 + gi) / src.nqp, Hd);
         } else {
 #pragma unroll
           for (int k = 0; k < 9; ++k) Hd[k] = 0.0;
         }
+      }
+      {
         const double r = 0.70710678118654752440;
         e[0] = Hd[0]; e[1] = Hd[4]; e[2] = Hd[8];
         e[3] = r * (Hd[1] + Hd[3]); e[4] = r * (Hd[2] + Hd[6]); e[5] = r * (Hd[5] + Hd[7]);
       }
-      wave_lds_sync();  // the coefficient region is rewritten in step 5
       // old state only now: 14 registers fewer live through the gradient evaluation
       if constexpr (LAW != LAW_ELASTIC) {
         if (valid) {

@@ -213,8 +213,8 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
 
 /* Device-resident form of dxm_integrate_displacement: u_dev (n_nodes*3), flux_dev, ct_dev are device
  * arrays, the call is asynchronous on hip_stream and capturable like dxm_integrate_device.  For
- * hexahedra with 8 Gauss points per cell the gradient is evaluated inside the update kernel (no
- * strain / deformation-gradient array is written or read); otherwise the gradient kernel fills a scratch
+ * hexahedra with 8 Gauss points per cell and for tetrahedra the gradient is evaluated inside the
+ * update kernel (no strain / deformation-gradient array is written or read); otherwise the gradient kernel fills a scratch
  * array owned by the handle and the update kernel follows on the same stream. */
 int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const double* u_dev, double dt,
                                       double* flux_dev, double* ct_dev, void* hip_stream);

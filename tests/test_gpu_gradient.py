@@ -120,8 +120,7 @@ def test_tet4_gradient_matches_host_and_drives_the_update():
 
     m, coords = make_mesh(3, distort=0.2, seed=4)
     # Kuhn split of every hexahedron (corner order of HexMesh.conn) into 6 tetrahedra along 0-6
-    kuhn = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]
-    conn = np.concatenate([m.conn[:, list(k)] for k in kuhn], axis=0).astype(np.int32)
+    conn = np.concatenate([m.conn[:, list(k)] for k in KUHN], axis=0).astype(np.int32)
     rng = np.random.default_rng(8)
     u = 2e-2 * m.h * rng.standard_normal(m.ndof)
     X, U = coords[conn], u.reshape(-1, 3)[conn]
@@ -148,20 +147,32 @@ def test_tet4_gradient_matches_host_and_drives_the_update():
     assert np.abs(fa - fb).max() < 1e-9 * np.abs(fb).max() and np.abs(ca - cb).max() < 1e-9 * np.abs(cb).max()
 
 
+KUHN = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]   # hex -> 6 tets along 0-6
+
+
 @pytest.mark.parametrize("law", ["elastic", "j2_voce", "j2_linear_sym", "fefp"])
-@pytest.mark.parametrize("ncell", [3, 5])
-def test_integrate_displacement_device_equals_gradient_then_update(law, ncell):
-    """dxm_integrate_displacement_device (for hex8 x 8 points and the small-strain laws: gradient
-    evaluated inside the update kernel, no strain array) against the two-kernel sequence
-    dxm_mesh_gradient_device -> dxm_integrate_device, over two increments with an advance between."""
+@pytest.mark.parametrize("cells", ["hex3", "hex5", "tet3x1", "tet4x4", "hex3x27"])
+def test_integrate_displacement_device_equals_gradient_then_update(law, cells):
+    """dxm_integrate_displacement_device (hex8 x 8 points and tet4 meshes: gradient evaluated inside the
+    update kernel, no strain / F array; hex8 with 27 points: two kernels through the handle's scratch)
+    against the explicit sequence dxm_mesh_gradient_device -> dxm_integrate_device, over two increments
+    with an advance between."""
     torch = pytest.importorskip("torch")
+    from dolfinx_materials_amd.gradient import Tet4Mesh
     from helpers import E, NU, SIG0_V, SIGU_V, B_V, SIG0_F, SIGU_F, B_F, SIG0_LIN, H_LIN
 
     dev = torch.device("cuda:0")
+    ncell = int(cells[3])
     hm, coords = make_mesh(ncell)
     conn = hm.conn
-    mesh = Hex8Mesh(coords, conn)
-    n = mesh.npoints            # 27 * 8 = 216 (ragged last tile) and 125 * 8 = 1000
+    if cells.startswith("tet"):
+        tconn = np.concatenate([conn[:, list(k)] for k in KUHN], axis=0).astype(np.int32)
+        mesh = Tet4Mesh(coords, tconn, nqp=int(cells.split("x")[1]))   # 162 x 1 and 384 x 4 points
+    elif cells.endswith("x27"):
+        mesh = Hex8Mesh(coords, conn, qpoints=gauss_points_hex(4))     # 27 points per cell: not fusable
+    else:
+        mesh = Hex8Mesh(coords, conn)
+    n = mesh.npoints            # hex: 27 * 8 = 216 (ragged last tile) and 125 * 8 = 1000
     el = jm.LinearElasticIsotropic(E=E, nu=NU)
     kw = {}
     if law == "elastic":

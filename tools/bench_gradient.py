@@ -45,11 +45,13 @@ def main():
     ap.add_argument("--cells", type=int, default=108)
     ap.add_argument("--law", default="j2_linear", choices=["j2_linear", "fefp"])
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--tet", type=int, default=0, metavar="NQP",
+                    help="split every hexahedron into 6 linear tetrahedra with NQP Gauss points each")
     a = ap.parse_args()
     import torch
 
     import dolfinx_materials_amd.materials as jm
-    from dolfinx_materials_amd.gradient import Hex8Mesh
+    from dolfinx_materials_amd.gradient import Hex8Mesh, Tet4Mesh
     from dolfinx_materials_amd.jaxmat import JAXMaterial
     from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_F, SIGU_F, B_F
 
@@ -57,7 +59,11 @@ def main():
     coords, conn = box_mesh(a.cells)
     rng = np.random.default_rng(0)
     coords[:, :] += rng.uniform(-0.2, 0.2, coords.shape) / a.cells  # distorted cells: nothing special-cased
-    mesh = Hex8Mesh(coords, conn)
+    if a.tet:
+        kuhn = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]
+        mesh = Tet4Mesh(coords, np.concatenate([conn[:, list(k)] for k in kuhn], axis=0).astype(np.int32), nqp=a.tet)
+    else:
+        mesh = Hex8Mesh(coords, conn)
     n = mesh.npoints
     el = jm.LinearElasticIsotropic(E=E, nu=NU)
     if a.law == "j2_linear":
@@ -88,7 +94,7 @@ def main():
     same = bool(torch.equal(flux, flux2)) and bool(torch.equal(ct, ct2))
     dmax = float((flux - flux2).abs().max())
     rc, stats = m.stats()
-    print(json.dumps({"cells": a.cells ** 3, "points": n, "nodes": len(coords), "law": a.law,
+    print(json.dumps({"mesh": f"tet4 x {a.tet}" if a.tet else "hex8 x 8", "cells": mesh.n_cells, "points": n, "nodes": len(coords), "law": a.law,
                       "gradient_ms": round(t_grad, 4), "law_ms": round(t_law, 4), "both_ms": round(t_both, 4), "integrate_displacement_device_ms": round(t_one_call, 4),
                       "same_result_as_two_kernels": same, "max_abs_flux_diff": dmax,
                       "gradient_write_GBs": round(n * ng * 8 / t_grad / 1e6, 1),
