@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The suites need the in-tree native pieces (`__graft_entry__.build()` makes them).  If one is missing --
+    a fresh clone where build() has not run -- build it here; existing ones are left alone (no rebuild on
+    the GPU box, where the built files travel with the snapshot)."""
+    import subprocess
+
+    for lib, mk in ((os.path.join(ROOT, "dolfinx_materials_amd", "libdxmat.so"), os.path.join(ROOT, "dolfinx_materials_amd", "csrc")),
+                    (os.path.join(ROOT, "oracle", "liboracle_dxmat.so"), os.path.join(ROOT, "oracle"))):
+        if not os.path.exists(lib):
+            subprocess.run(["make", "-C", mk], check=True)
+
+
 def _gpu_count():
     try:
         from dolfinx_materials_amd import _lib
