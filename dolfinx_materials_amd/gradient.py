@@ -7,8 +7,6 @@ the strain / deformation gradient array is produced directly in HBM from the dis
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 
 from . import _lib

@@ -7,7 +7,7 @@ import dolfinx_materials_amd.materials as jm
 from dolfinx_materials_amd import _lib
 from oracle import constitutive_np as onp
 
-from helpers import E, NU, SIG0_V, SIGU_V, B_V, SIG0_F, SIGU_F, B_F, j2_history, random_j2_state, fefp_path
+from helpers import E, NU, SIG0_V, SIGU_V, B_V, j2_history, random_j2_state, fefp_path
 
 
 class PowerLaw:

@@ -8,7 +8,6 @@ with explicit state pointers:
 import ctypes as C
 import json
 import os
-import sys
 
 import numpy as np
 

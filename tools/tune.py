@@ -3,7 +3,6 @@
 (cdna_hip_programming.md section 5.4 rule 24).  Variants are selected through the environment
 variables libdxmat reads at dxm_create time."""
 import argparse
-import itertools
 import json
 import os
 import sys
@@ -28,7 +27,6 @@ def main():
     import bench
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
-    from helpers import SIG0_V, SIGU_V, B_V
 
     dev = torch.device("cuda:0")
     n = a.points
