@@ -218,7 +218,7 @@ def test_integrate_displacement_device_equals_gradient_then_update(law, cells):
 @pytest.mark.parametrize("law", ["j2", "fefp"])
 def test_chunked_host_displacement_path_uses_the_right_cells(law):
     """Above 524288 points the host-buffer form is cut into chunks issued on two streams; with the gradient
-    evaluated inside the update kernel every chunk must start at its own cell (Hex8Source.cell0)."""
+    evaluated inside the update kernel every chunk must start at its own point (MeshSource.point0)."""
     torch = pytest.importorskip("torch")
     m, coords = make_mesh(42)            # 74 088 cells, 592 704 points -> 2 chunks
     rng = np.random.default_rng(5)
