@@ -661,7 +661,7 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   size_t budget = free_b / 2;
-  int tried = 0;
+  int tried = 0, after_contrast = 0;
   const bool verbose = getenv("DXM_TUNE_VERBOSE") != nullptr;
   if (verbose) fprintf(stderr, "[dxm_tune_placement] initial %p: %.4f ms\n", (void*)m->state_base, t);
   for (int c = 0; c < max_candidates; ++c) {
@@ -700,7 +700,9 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
     }
     // state[0] of `best` always holds s0: every candidate received a copy and the kernel never writes it
     m->state_base = best.base; m->state[0] = best.s[0]; m->state[1] = best.s[1];
-    if (t_best <= 0.95f * t_max) break;   // both modes seen: the best is a fast placement
+    // both modes seen: the best is a fast placement.  Fast placements still differ by 2-3 % among
+    // themselves, so a few more candidates are measured before stopping.
+    if (t_best <= 0.95f * t_max && ++after_contrast > 6) break;
   }
   // one more launch on the chosen block so that s1, flux, tangent and the stats are those of `best`
   int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 1, e0, e1, &t);

@@ -166,7 +166,7 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
  * This call measures instead: it runs the update (exactly as dxm_integrate_device would, on the
  * handle's own stream) with the caller's real device arrays on up to max_candidates fresh state
  * allocations and keeps the fastest; s0 is preserved, s1 / flux_dev / ct_dev / the stats end up as
- * after one dxm_integrate_device(grad_dev, ...).  Stops early once both modes have been seen.
+ * after one dxm_integrate_device(grad_dev, ...).  Stops six candidates after both modes have been seen.
  * The first half of the candidates are consecutive allocations, the second half jump ahead by skip
  * blocks of 1, 2, 4 ... 16 GiB (fast regions can be tens of GB apart); everything but the winner is
  * freed before returning; at most half of the free device memory is held meanwhile.  10 ms to a few
