@@ -247,3 +247,45 @@ def test_chunked_host_displacement_path_uses_the_right_cells(law):
     fbh, cbh = fb.cpu().numpy(), cb.cpu().numpy().reshape(ca.shape)
     assert np.abs(fa - fbh).max() <= 1e-12 * np.abs(fbh).max()
     assert np.abs(ca - cbh).max() <= 1e-12 * np.abs(cbh).max()
+
+
+def test_fused_displacement_path_is_graph_capturable():
+    """dxm_integrate_displacement_device on a fusable mesh is one kernel launch without allocation or
+    synchronisation: a Newton cadence (new displacement vector -> update) can be captured in a HIP graph and
+    replayed after the displacement buffer has been overwritten in place."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    hm, coords = make_mesh(6)
+    mesh = Hex8Mesh(coords, hm.conn)
+    n = mesh.npoints
+    el = jm.LinearElasticIsotropic(E=70e3, nu=0.3)
+    mat = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(250.0, 5e3)))
+    mat.set_data_manager(n)
+    rng = np.random.default_rng(11)
+    u1 = (coords * np.array([6e-3, -2e-3, -2e-3]) + 1e-4 * rng.standard_normal(coords.shape)).ravel()
+    u2 = 1.5 * u1
+    ud = torch.from_numpy(u1.copy()).to(dev)
+    f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    mat.integrate_displacement_device(mesh, ud.data_ptr(), f.data_ptr(), c.data_ptr(), st)   # eager, u1
+    torch.cuda.synchronize()
+    f1 = f.clone()
+    ud.copy_(torch.from_numpy(u2))
+    mat.integrate_displacement_device(mesh, ud.data_ptr(), f.data_ptr(), c.data_ptr(), st)   # eager, u2
+    torch.cuda.synchronize()
+    f2, c2 = f.clone(), c.clone()
+    assert not torch.equal(f1, f2)
+    graph = torch.cuda.CUDAGraph()
+    f.zero_()
+    with torch.cuda.graph(graph):
+        mat.integrate_displacement_device(mesh, ud.data_ptr(), f.data_ptr(), c.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert float(f.abs().max()) == 0.0          # nothing ran during capture
+    ud.copy_(torch.from_numpy(u1))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(f, f1)
+    ud.copy_(torch.from_numpy(u2))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(f, f2) and torch.equal(c, c2)
