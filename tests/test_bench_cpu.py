@@ -29,3 +29,18 @@ def test_cpu_baseline_leg_runs_and_reports_threads():
     out = bench.cpu_baseline(20000, 1234, budget_s=1.0)
     assert out["kind"] == "port" and out["unit"] == "Mpoints/s" and out["value"] > 0
     assert 1 <= out["cores"] <= (os.cpu_count() or 1) and "20000 points" in out["sample"]
+
+
+def test_self_launcher_propagates_a_failing_rank_without_hanging():
+    """`python bench.py --gpus 2` starts its own ranks; here (no GPU) every rank fails its GPU assertion and the
+    launcher must come back with a non-zero code instead of leaving ranks waiting in the rendezvous."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"),
+                        "--gpus", "2", "--points", "1000", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a GPU" in r.stderr

@@ -1,0 +1,113 @@
+"""N > 1 path with the HIP kernels as the per-shard compute: two ranks share
+GPU 0 of the box (one process each, ``gloo`` for the exchange because RCCL refuses two ranks on one
+device), every rank owns a contiguous block of Gauss points with its state resident in its own
+``HIPMaterial`` handle, integrates the whole load/unload history and all-gathers stress, tangent and
+internal state variables; rank 0's reassembled arrays must equal the single-process oracle on the
+full batch.  Also: ``python bench.py --gpus 2`` starts its own ranks (no external launcher)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, j2_history
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, law, q):
+    import torch
+    import torch.distributed as dist
+
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+    from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = ShardPlan(n, world)
+        lo, hi = plan.range(rank)
+        sig0 = SIG0_LIN if law == "linear" else SIG0_V
+        hard = jm.LinearHardening(SIG0_LIN, H_LIN) if law == "linear" else jm.VoceHardening(SIG0_V, SIGU_V, B_V)
+        mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard), device=0)
+        mat.set_data_manager(hi - lo)
+        out = []
+        for eps in j2_history(n, seed=77, sig0=sig0):  # same global batch on every rank; each takes its block
+            sig, isv, ct = mat.integrate(eps[lo:hi])
+            assert mat.last_stats["n_nan"] == 0 and mat.last_stats["n_not_converged"] == 0
+            g_sig = allgather_rows(torch.from_numpy(np.array(sig)), plan)
+            g_ct = allgather_rows(torch.from_numpy(np.array(ct).reshape(-1, 36)), plan)
+            g_isv = allgather_rows_p2p(torch.from_numpy(np.array(isv)), plan)
+            assert torch.equal(g_ct, allgather_rows_p2p(torch.from_numpy(np.array(ct).reshape(-1, 36)), plan))
+            out.append((g_sig.numpy(), g_isv.numpy(), g_ct.numpy()))
+            mat.data_manager.update()
+        if rank == 0:
+            q.put(out)
+        mat.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,law", [(4096, "linear"), (10_001, "voce")])
+def test_two_ranks_with_hipmaterial_per_shard_match_single_process_oracle(gpu_available, n, law):
+    if not gpu_available:
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    from oracle import constitutive_np as onp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, law, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    sig0 = SIG0_LIN if law == "linear" else SIG0_V
+    hard = onp.LinearHardening(SIG0_LIN, H_LIN) if law == "linear" else onp.VoceHardening(SIG0_V, SIGU_V, B_V)
+    epsp, p_ = np.zeros((n, 6)), np.zeros(n)
+    for eps, (sig, isv, ct) in zip(j2_history(n, seed=77, sig0=sig0), got):
+        ref = onp.j2_update(eps, epsp, p_, E, NU, hard)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * sig0
+        for a, b in ((sig, ref["sig"]), (ct, ref["Ct"].reshape(n, 36)), (isv[:, 0], ref["p"]), (isv[:, 1:], ref["epsp"])):
+            err = np.abs(a[safe] - b[safe]).max() / max(np.abs(b).max(), 1e-300)
+            assert err < 1e-12, err  # contract: rtol 1e-6 plastic (BASELINE.json north_star)
+        epsp, p_ = ref["epsp"], ref["p"]
+
+
+def test_bench_starts_its_own_ranks(gpu_available):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py launches the two
+    ranks itself before any GPU call (debug share mode: both on GPU 0, gloo) and rank 0 prints ONE line."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--points", "300000",
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-other-laws", "--gather-steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    pg = out["process_group"]
+    assert pg["ranks_in_group"] == 2 and pg["ranks_counted_by_all_reduce"] == 2 and pg["launcher"] == "self"
+    assert out["gather_inclusive"]["value"] > 0 and out["gather_inclusive"]["p2p_schedule"]["value"] > 0
+    assert out["value"] > out["gather_inclusive"]["value"]
