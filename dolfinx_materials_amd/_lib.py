@@ -183,12 +183,23 @@ def load_custom(expr_R: str, expr_dR: str) -> C.CDLL:
         cmd = [
             HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-shared",
             "-DDXM_CUSTOM_HARDENING", f"-DDXM_CUSTOM_R={expr_R}", f"-DDXM_CUSTOM_DR={expr_dR}",
-            "-o", out + ".tmp", os.path.join(CSRC_DIR, "dxmat.hip"),
+            "-o", None, os.path.join(CSRC_DIR, "dxmat.hip"),
         ]
+        # every rank of a multi-process run may hit the cold cache at once: each compiles into its own
+        # temporary file and publishes it with an atomic rename (identical content, last one wins)
+        import tempfile
+
+        fd, tmp = tempfile.mkstemp(prefix="libdxmat_custom.", suffix=f".{os.getpid()}.tmp", dir=out_dir)
+        os.close(fd)
+        cmd[cmd.index(None)] = tmp
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
             raise DxmError(f"compiling the custom hardening law failed:\n{r.stderr[-2000:]}")
-        os.replace(out + ".tmp", out)
+        os.replace(tmp, out)
     _share_hip_runtime_with_torch()
     lib = _bind(C.CDLL(out))
     assert lib.dxm_has_custom_hardening() == 1
@@ -212,33 +223,41 @@ def device_count() -> int:
     return max(n, 0)
 
 
+def _free_pinned(lib, ptr):
+    lib.dxm_host_free(ptr)
+
+
 class PinnedArray:
-    """A C-contiguous fp64 numpy array in page-locked host memory (``dxm_host_alloc``)."""
+    """A C-contiguous fp64 numpy array in page-locked host memory (``dxm_host_alloc``).
+
+    The memory belongs to the ARRAY, not to this object: numpy views keep the underlying ctypes
+    buffer alive, and the page-locked block is released by a finalizer on that buffer, i.e. when
+    the last view of it is gone.  ``release()`` only drops this object's own reference, so arrays
+    already handed to a caller (``integrate`` results, state dicts) never dangle."""
 
     def __init__(self, shape):
+        import weakref
+
         import numpy as np
 
         self.shape = tuple(int(s) for s in shape)
         n = 1
         for s in self.shape:
             n *= s
-        self._ptr = load().dxm_host_alloc(8 * max(n, 1))
-        if not self._ptr:
+        lib = load()
+        ptr = lib.dxm_host_alloc(8 * max(n, 1))
+        if not ptr:
             raise DxmError(f"dxm_host_alloc failed: {last_error()}")
-        buf = (C.c_double * max(n, 1)).from_address(self._ptr)
+        buf = (C.c_double * max(n, 1)).from_address(ptr)
+        # atexit=False: at interpreter exit the OS reclaims the block; no HIP calls during teardown
+        weakref.finalize(buf, _free_pinned, lib, ptr).atexit = False
+        self.ptr = ptr
         self.array = np.frombuffer(buf, dtype=np.float64, count=n).reshape(self.shape)
 
-    def free(self):
-        if getattr(self, "_ptr", None):
-            self.array = None
-            load().dxm_host_free(self._ptr)
-            self._ptr = None
+    def release(self):
+        self.array = None
 
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
+    free = release
 
 
 def law_info(law: int, lib=None) -> LawInfo:

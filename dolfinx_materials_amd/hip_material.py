@@ -72,12 +72,19 @@ class DataManager:
 class HIPMaterial:
     """A constitutive behaviour integrated on an MI355X through ``libdxmat.so``."""
 
-    def __init__(self, behavior, device: int = 0, gradient_name=None, flux_name=None, tangent_layout="full"):
-        """``tangent_layout="sym"`` (small-strain laws only) makes ``integrate`` return the 21
+    def __init__(self, behavior, jit=True, device: int = 0, gradient_name=None, flux_name=None, tangent_layout="full"):
+        """``JAXMaterial(behavior, jit=True)`` (``jaxmat.py:144``): ``jit`` is accepted for signature
+        compatibility and has no effect -- the kernels are compiled ahead of time (or, for a traced /
+        custom hardening law, by hipcc on construction).
+
+        ``tangent_layout="sym"`` (small-strain laws only) makes ``integrate`` return the 21
         upper-triangle entries per point, ``(N, 21)``, instead of the full ``(N, 6, 6)`` block the
         reference's ``jacobian_flatten`` expects (``conventions.unpack_sym_tangent`` expands it)."""
         if tangent_layout not in ("full", "sym"):
             raise ValueError("tangent_layout must be 'full' or 'sym'")
+        if not isinstance(jit, (bool, type(None))):
+            raise TypeError("the second argument of JAXMaterial / HIPMaterial is `jit` (jaxmat.py:144); pass the GPU index as device=")
+        self.jit = bool(jit)
         self.tangent_layout = tangent_layout
         self.behavior = behavior
         self.device = int(device)
@@ -163,9 +170,16 @@ class HIPMaterial:
             obj = getattr(obj, p)
         if not hasattr(obj, parts[-1]):
             raise ValueError(f"Unknown material property {key!r}")
-        value = float(np.asarray(value).reshape(-1)[0]) if np.size(value) == 1 else value
-        if not np.isscalar(value):
-            raise NotImplementedError("per-point material property fields are not supported")
+        arr = np.asarray(value, dtype=np.float64).reshape(-1)
+        if arr.size == 0:
+            raise ValueError(f"empty value for material property {key!r}")
+        # QuadratureMap.update_material_properties hands 0-d arrays for numbers and one value per Gauss point
+        # for UFL-valued properties (quadrature_map.py:160-172); a uniform field is a number
+        if not np.all(arr == arr[0]):
+            raise NotImplementedError(
+                f"material property {key!r} varies from point to point: the fused kernels take uniform parameters "
+                "(split the domain into one QuadratureMap per material, tests/mfront/test_multimaterials.py:23-172)")
+        value = float(arr[0])
         setattr(obj, parts[-1], value)
         self.material_properties[key] = value
         if self._handle:
@@ -224,12 +238,25 @@ class HIPMaterial:
         return g
 
     def close(self):
+        """Release the device state.  Arrays already returned by ``integrate`` / the state dicts stay
+        valid: their page-locked memory is owned by the arrays themselves (``_lib.PinnedArray``)."""
         if getattr(self, "_handle", None):
             self._lib.dxm_destroy(self._handle)
             self._handle = None
         for p in getattr(self, "_pinned", []):
-            p.free()
+            p.release()
         self._pinned = []
+        self._out_isv = self._out_ct = None
+        self._flux_buf = []
+
+    # ---- protocol: external state variables (quadrature_map.py:195, :225) --------------------------
+    def initialize_external_state_variable(self, name, values):
+        raise NotImplementedError(
+            f"external state variable {name!r}: the HIP laws (elastic, J2, FeFp J2) take none "
+            "(neither do the jaxmat behaviours they replace: JAXMaterial has no such method either)")
+
+    def update_external_state_variable(self, name, values):
+        self.initialize_external_state_variable(name, values)
 
     def __del__(self):
         try:
@@ -317,27 +344,29 @@ class HIPMaterial:
         """
         h = self._require()
         ng, nf = self._info.n_grad, self._info.n_flux
-        g = _as_c(gradients)
-        if g.shape != (self._n, ng):
-            raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
-        flux = self._next_flux_buffer()
-        st = Stats()
-        # same timer names as the reference (jaxmat.py:214-218) so that existing scripts that read
-        # timing("jaxmat: Constitutive update") keep working when dolfinx is present
+        # the reference's four timer names (jaxmat.py:209, :215, :218, :223), so that scripts reading
+        # timing("jaxmat: ...") keep working when dolfinx is present
+        with _Timer("jaxmat: dolfinx to jaxmat conversion"):
+            g = _as_c(gradients)
+            if g.shape != (self._n, ng):
+                raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
+            flux = self._next_flux_buffer()
+            st = Stats()
         timer_name = "jaxmat: Constitutive update" if self._warm else "jaxmat: First pass (includes jit compilation)"
         self._warm = True
         with _Timer(timer_name):
             rc = self._lib.dxm_integrate(
                 h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)
             )
-        self._chk(rc)
-        self.last_stats = st.as_dict()
-        if rc > 0:
-            warnings.warn(
-                f"local Newton did not converge at {rc} quadrature points", RuntimeWarning
-            )
-        self._grad[1] = g
-        self._flux[1] = flux
+        with _Timer("jaxmat: jaxmat to dolfinx conversion"):
+            self._chk(rc)
+            self.last_stats = st.as_dict()
+            if rc > 0:
+                warnings.warn(
+                    f"local Newton did not converge at {rc} quadrature points", RuntimeWarning
+                )
+            self._grad[1] = g
+            self._flux[1] = flux
         return flux, self._out_isv, self._out_ct
 
     def _next_flux_buffer(self):

@@ -3,9 +3,10 @@ uses it (``tests/test_FeFp_jax.py:17-19``, ``demos/jax/elastoplasticity/plane_el
 ``demos/jax/finite_strain_elastoplasticity/finite_strain_elastoplasticity.py:165-169``).
 
 A descriptor only carries parameters and names; it selects one fused HIP kernel (a law id of
-``include/dxmat.h``).  Hardening must be one of the closed-form laws below: an arbitrary Python
-callable (``yield_stress(p)`` in ``tests/test_FeFp_jax.py:14-15``) cannot be compiled into the
-kernel and is rejected with a ``NotImplementedError``.
+``include/dxmat.h``).  Hardening is one of the closed-form laws below, a :class:`CustomHardening`
+(C expressions) or -- as in the reference, ``tests/test_FeFp_jax.py:14-19`` -- any Python callable
+``yield_stress(p)`` written with arithmetic operators and numpy ufuncs: it is traced once
+(``tracing.py``), differentiated symbolically and compiled into the kernel on first use.
 """
 from __future__ import annotations
 
@@ -63,7 +64,10 @@ class CustomHardening:
     parameters; R(0) must equal ``sig0`` and R must be non-decreasing (the local Newton relies on
     it, as with the built-in laws)."""
 
-    _RESERVED = {"p", "sig0", "c"}
+    #: names that mean something else inside the generated C expression
+    _RESERVED = {"p", "sig0", "c", "exp", "expm1", "log", "log1p", "log2", "log10", "pow", "sqrt", "cbrt", "tanh", "sinh",
+                 "cosh", "sin", "cos", "tan", "atan", "asin", "acos", "fabs", "fmax", "fmin", "fma", "erf", "double", "float",
+                 "int", "const", "return", "if", "else", "for", "while", "prm"}
 
     def __init__(self, R: str, dR: str, sig0: float, **params):
         import re
@@ -84,6 +88,17 @@ class CustomHardening:
             return "(" + expr + ")"
 
         self.expr_R, self.expr_dR = sub(R), sub(dR)
+
+    @classmethod
+    def from_callable(cls, func):
+        """Trace a Python ``yield_stress(p)`` (operators + numpy ufuncs) into the two C expressions; numbers the
+        callable closes over become literals, ``sig0 = yield_stress(0)``."""
+        from .tracing import TracedLaw
+
+        law = TracedLaw(func)
+        self = cls(law.expr_R, law.expr_dR, sig0=law.sig0)
+        self.traced = law
+        return self
 
     def coefficients(self):
         return self.values + [0.0] * (6 - len(self.values))
@@ -138,10 +153,11 @@ class FiniteStrainBehavior(Behavior):
 def _check_hardening(yield_stress):
     if isinstance(yield_stress, (LinearHardening, VoceHardening, CustomHardening)):
         return yield_stress
-    raise NotImplementedError(
-        "yield_stress must be a materials.LinearHardening, materials.VoceHardening or "
-        "materials.CustomHardening (C expressions for R(p) and dR/dp) instance: an arbitrary Python "
-        "callable cannot be fused into the HIP return-mapping kernel."
+    if callable(yield_stress):   # what the reference passes (tests/test_FeFp_jax.py:14-19)
+        return CustomHardening.from_callable(yield_stress)
+    raise TypeError(
+        "yield_stress must be a callable yield_stress(p) (arithmetic operators and numpy ufuncs), or a "
+        "materials.LinearHardening / VoceHardening / CustomHardening instance"
     )
 
 
@@ -181,9 +197,9 @@ class vonMisesIsotropicHardening(SmallStrainBehavior):
         self.elasticity = elasticity
         self.yield_stress = _check_hardening(yield_stress)
         self.law = (
-            _lib.LAW_J2_LINEAR if isinstance(yield_stress, LinearHardening) else _lib.LAW_J2_VOCE
+            _lib.LAW_J2_LINEAR if isinstance(self.yield_stress, LinearHardening) else _lib.LAW_J2_VOCE
         )
-        self.custom_hardening = yield_stress if isinstance(yield_stress, CustomHardening) else None
+        self.custom_hardening = self.yield_stress if isinstance(self.yield_stress, CustomHardening) else None
 
     def params(self):
         return _hardening_params(self.elasticity, self.yield_stress)
@@ -200,8 +216,8 @@ class FeFpJ2Plasticity(FiniteStrainBehavior):
     def __init__(self, elasticity: LinearElasticIsotropic, yield_stress):
         self.elasticity = elasticity
         self.yield_stress = _check_hardening(yield_stress)
-        self.law = _lib.LAW_FEFP_J2_LINEAR if isinstance(yield_stress, LinearHardening) else _lib.LAW_FEFP_J2_VOCE
-        self.custom_hardening = yield_stress if isinstance(yield_stress, CustomHardening) else None
+        self.law = _lib.LAW_FEFP_J2_LINEAR if isinstance(self.yield_stress, LinearHardening) else _lib.LAW_FEFP_J2_VOCE
+        self.custom_hardening = self.yield_stress if isinstance(self.yield_stress, CustomHardening) else None
 
     def params(self):
         return _hardening_params(self.elasticity, self.yield_stress)

@@ -73,8 +73,15 @@ def test_protocol_surface_without_gpu():
     assert f.internal_state_variables == {"p": 1, "be_bar": 6}
     e = LinearElasticIsotropic(70e3, 0.3)
     assert e.gradients == {"Strain": 6} and e.fluxes == {"Stress": 6} and e.internal_state_variables == {}
-    with pytest.raises(NotImplementedError):
-        jm.vonMisesIsotropicHardening(el, lambda p: 250.0 + p)
+    traced = jm.vonMisesIsotropicHardening(el, lambda p: 250.0 + 1e3 * p)  # a Python callable is traced (tests/test_FeFp_jax.py:14-19)
+    assert traced.custom_hardening.expr_dR == "(1000.0)" and traced.params()[2] == 250.0
+    with pytest.raises(TypeError):
+        jm.vonMisesIsotropicHardening(el, 250.0)
+    assert JAXMaterial(jm.ElasticBehavior(el), True).jit is True  # JAXMaterial(behavior, jit=True): jaxmat.py:144
+    with pytest.raises(TypeError):
+        JAXMaterial(jm.ElasticBehavior(el), 1)  # a GPU index must be passed as device=
+    with pytest.raises(NotImplementedError, match="external state variable"):
+        m.initialize_external_state_variable("Temperature", np.zeros(4))
     with pytest.raises(_lib.DxmError):
         m.integrate(np.zeros((4, 6)))  # set_data_manager not called
 
