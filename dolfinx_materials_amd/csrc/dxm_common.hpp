@@ -28,6 +28,18 @@ struct LawParams {
 // plastic strain), `sig0` and `c[0..5]`: R(p) and dR/dp of an arbitrary isotropic hardening law
 // (what a Python `yield_stress(p)` callable is to jaxmat: tests/test_FeFp_jax.py:14-15).  The
 // Python layer compiles such a library on demand (dolfinx_materials_amd/_lib.py::load_custom).
+// A value the optimiser cannot look through: a product passed through this is never contracted into an
+// FMA with a neighbouring add.  The Voce law and every traced Python law (tracing.py emits DXM_MUL for
+// each product) are evaluated with these plain, individually rounded operations, so that (i) a traced
+// callable and the built-in law with the same formula give bit-identical results whatever the
+// surrounding code looks like, and (ii) the device evaluates R(p) with the roundings of the Python
+// callable itself (up to the exp / pow implementations).
+__device__ __forceinline__ double opaque(double x) {
+  asm("" : "+v"(x));
+  return x;
+}
+#define DXM_MUL(a, b) (::dxm::opaque((a) * (b)))
+
 #ifdef DXM_CUSTOM_HARDENING
 __device__ __forceinline__ double custom_R(const LawParams& prm, double p) {
   const double sig0 = prm.sig0;

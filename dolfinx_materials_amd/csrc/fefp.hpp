@@ -89,9 +89,9 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
     R = custom_R(prm, p);
     dR = custom_dR(prm, p);
 #else
-    const double ex = exp(-prm.h2 * p);
-    R = prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - ex);
-    dR = (prm.h1 - prm.sig0) * prm.h2 * ex;
+    const double ex = exp(DXM_MUL(-prm.h2, p));
+    R = prm.sig0 + DXM_MUL(prm.h1 - prm.sig0, 1.0 - ex);
+    dR = DXM_MUL((prm.h1 - prm.sig0) * prm.h2, ex);
 #endif
   }
 }

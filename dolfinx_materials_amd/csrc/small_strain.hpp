@@ -43,7 +43,7 @@ __device__ __forceinline__ double hardening_R(const LawParams& prm, double p) {
 #ifdef DXM_CUSTOM_HARDENING
     return custom_R(prm, p);
 #else
-    return prm.sig0 + (prm.h1 - prm.sig0) * (1.0 - exp(-prm.h2 * p));
+    return prm.sig0 + DXM_MUL(prm.h1 - prm.sig0, 1.0 - exp(DXM_MUL(-prm.h2, p)));
 #endif
   }
 }
@@ -55,7 +55,7 @@ __device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
 #ifdef DXM_CUSTOM_HARDENING
     return custom_dR(prm, p);
 #else
-    return (prm.h1 - prm.sig0) * prm.h2 * exp(-prm.h2 * p);
+    return DXM_MUL((prm.h1 - prm.sig0) * prm.h2, exp(DXM_MUL(-prm.h2, p)));
 #endif
   }
 }

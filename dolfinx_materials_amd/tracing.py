@@ -211,6 +211,8 @@ def emit_c(n):
         sym = {"add": "+", "sub": "-", "mul": "*", "div": "/"}[op]
         if op == "mul" and is_const(n[1], -1.0):
             return f"(-{emit_c(n[2])})"
+        if op == "mul":   # individually rounded, never contracted into an FMA (dxm_common.hpp: DXM_MUL)
+            return f"DXM_MUL({emit_c(n[1])}, {emit_c(n[2])})"
         return f"({emit_c(n[1])} {sym} {emit_c(n[2])})"
     if op == "pow":
         return f"pow({emit_c(n[1])}, {emit_c(n[2])})"

@@ -80,8 +80,13 @@ def test_unknown_property_and_callable_hardening():
     m = _mat(4)
     with pytest.raises(ValueError):
         m.update_material_property("elasticity.G", 1.0)
-    with pytest.raises(NotImplementedError):
-        m.update_material_property("elasticity.E", np.ones(4))
+    with pytest.raises(NotImplementedError, match="varies from point to point"):
+        m.update_material_property("elasticity.E", np.array([1.0, 2.0, 3.0, 4.0]))
+    # what QuadratureMap.update_material_properties hands over (quadrature_map.py:160-172): 0-d arrays for
+    # numbers, one value per Gauss point for UFL-valued properties; a uniform field is a number
+    m.update_material_property("elasticity.E", np.asarray(71e3))
+    m.update_material_property("elasticity.E", np.full(4, 72e3))
+    assert m.material_properties["elasticity.E"] == 72e3 and m.behavior.elasticity.E == 72e3
 
 
 def test_device_path_on_a_non_default_torch_stream():

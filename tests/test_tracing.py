@@ -28,8 +28,8 @@ def reference_yield_stress():
 
 def test_reference_voce_callable_traces_to_the_hand_written_expressions():
     law = tracing.TracedLaw(reference_yield_stress())
-    assert law.expr_R == "(500.0 + (250.0 * (1.0 - exp(((-1000.0) * p)))))"
-    assert law.expr_dR == "(250000.0 * exp(((-1000.0) * p)))"   # one folded coefficient, like (sigu - sig0) * b * exp(-b p)
+    assert law.expr_R == "(500.0 + DXM_MUL(250.0, (1.0 - exp(DXM_MUL((-1000.0), p)))))"
+    assert law.expr_dR == "DXM_MUL(250000.0, exp(DXM_MUL((-1000.0), p)))"   # one folded coefficient, like (sigu - sig0) * b * exp(-b p)
     assert law.sig0 == 500.0
     p = np.linspace(0.0, 0.02, 11)
     v = onp.VoceHardening(500.0, 750.0, 1000.0)
@@ -58,11 +58,13 @@ def test_traced_value_and_symbolic_derivative(k):
     # the emitted C is an expression in p only: evaluate it with Python's math as a cross-check of emit_c
     env = {k_: getattr(math, k_) for k_ in ("exp", "expm1", "log", "log1p", "sqrt", "tanh", "sinh", "cosh", "sin", "cos", "atan", "fabs", "pow")}
     env["cbrt"] = np.cbrt
+    env["_mul"] = lambda a_, b_: a_ * b_
 
     def c_eval(expr, x):
         import re
 
         py = re.sub(r"\(\(([^?]*?)\) \? ([^:]*?) : ([^)]*?)\)", r"((\2) if (\1) else (\3))", expr)   # not needed for the nested-free cases below
+        py = re.sub(r"DXM_MUL\(", "_mul(", py)
         py = re.sub(r"(0x[0-9a-f.]+p[+-]?\d+)", lambda m_: repr(float.fromhex(m_.group(1))), py)
         return eval(py, {"__builtins__": {}}, dict(env, p=x))
 
