@@ -86,6 +86,11 @@ SYMBOLS = {
     "dxm_tune_placement": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dxm_kernel_name": (C.c_char_p, [_h]),
+    "dxm_launch_generation": (C.c_uint64, [_h]),
+    "dxm_set_option": (C.c_int, [_h, C.c_char_p, C.c_double]),
+    "dxm_isv_host": (C.c_int, [_h, C.c_int, C.c_void_p]),
+    "dxm_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "dxm_host_unregister": (C.c_int, [C.c_void_p]),
     "dxm_host_alloc": (C.c_void_p, [C.c_uint64]),
     "dxm_host_free": (C.c_int, [C.c_void_p]),
     "dxm_mesh_create_hex8": (_h, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int]),

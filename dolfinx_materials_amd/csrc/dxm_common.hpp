@@ -72,6 +72,17 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The same ordering point without memory-model fences, for code that has LDS-DMA requests
+// (`global_load_lds`) in flight: a fence, even at wavefront scope, makes the compiler drain the vector
+// memory counter (`s_waitcnt vmcnt(0)`: the DMA is a pending LDS write) and with it every global store
+// issued before.  A compiler-level memory barrier keeps the LDS accesses on their side of the point; the
+// hardware executes one wave's DS operations in order.
+__device__ __forceinline__ void wave_lds_order() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
@@ -86,12 +97,15 @@ __device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
   return v;
 }
 
-// Reduce per-thread counters over the workgroup and let thread 0 store the block record.
+// Reduce per-thread counters over the workgroup and let thread 0 store the block record.  `red` is LDS:
+// wave w uses the 4 words at red[w * stride ...] (its own wave-private region once the tile loop is over:
+// a kernel with LDS-DMA in flight must keep ALL its LDS in one __shared__ object -- with a second one the
+// compiler drains `vmcnt(0)` before the first LDS write that follows a DMA request).
 __device__ __forceinline__ void store_block_stats(BlockStats* out, unsigned long long n_plastic,
                                                   unsigned long long n_notconv,
                                                   unsigned long long n_nan,
                                                   unsigned long long max_it,
-                                                  unsigned long long* red /* LDS, 4*WAVES_PER_BLOCK */) {
+                                                  unsigned long long* red, int stride = 4) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x >> 6;
   n_plastic = wave_sum(n_plastic);
@@ -99,19 +113,19 @@ __device__ __forceinline__ void store_block_stats(BlockStats* out, unsigned long
   n_nan = wave_sum(n_nan);
   max_it = wave_max(max_it);
   if (lane == 0) {
-    red[wid * 4 + 0] = n_plastic;
-    red[wid * 4 + 1] = n_notconv;
-    red[wid * 4 + 2] = n_nan;
-    red[wid * 4 + 3] = max_it;
+    red[wid * stride + 0] = n_plastic;
+    red[wid * stride + 1] = n_notconv;
+    red[wid * stride + 2] = n_nan;
+    red[wid * stride + 3] = max_it;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     BlockStats s = {0, 0, 0, 0};
     for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
-      s.n_plastic += red[w * 4 + 0];
-      s.n_not_converged += red[w * 4 + 1];
-      s.n_nan += red[w * 4 + 2];
-      s.max_iters = red[w * 4 + 3] > s.max_iters ? red[w * 4 + 3] : s.max_iters;
+      s.n_plastic += red[w * stride + 0];
+      s.n_not_converged += red[w * stride + 1];
+      s.n_nan += red[w * stride + 2];
+      s.max_iters = red[w * stride + 3] > s.max_iters ? red[w * stride + 3] : s.max_iters;
     }
     out[blockIdx.x] = s;
   }

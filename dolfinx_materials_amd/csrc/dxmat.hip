@@ -8,7 +8,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -102,8 +107,87 @@ static int isv_total(const LawDesc& d) {
 }
 
 // ------------------------------------------------------------------------------------------
+// host side of the host-buffer form: symmetric-packed tangent -> full 6x6 block
+// ------------------------------------------------------------------------------------------
+// The small-strain tangent is symmetric, so the host-buffer form moves only its 21 upper-triangle
+// entries over PCIe (168 instead of 288 B/point of the 392 B/point coming back) and rebuilds the
+// (N, 6, 6) block the reference's jacobian_flatten expects (quadrature_map.py:83-105, :334) on the
+// host, chunk by chunk on a few worker threads while the next chunks are still in flight.  The full
+// and the packed kernels evaluate every entry with the same expression, so the result is bit-identical
+// to the full-tangent download.
+static void expand_sym_tangent(const double* __restrict__ s, double* __restrict__ d, int64_t n) {
+  // upper triangle, row-major: row 0 -> 0..5, row 1 -> 6..10, row 2 -> 11..14, row 3 -> 15..17, row 4 -> 18..19, row 5 -> 20
+  static const int T[36] = {0, 1, 2, 3, 4, 5,  1, 6, 7, 8, 9, 10,  2, 7, 11, 12, 13, 14,
+                            3, 8, 12, 15, 16, 17,  4, 9, 13, 16, 18, 19,  5, 10, 14, 17, 19, 20};
+  const bool aligned = (reinterpret_cast<uintptr_t>(d) & 15) == 0;
+  for (int64_t p = 0; p < n; ++p, s += 21, d += 36) {
+    if (aligned) {   // streaming stores: the block is not read again by these threads
+      for (int k = 0; k < 36; k += 2) {
+        const double2_t v = {s[T[k]], s[T[k + 1]]};
+        __builtin_nontemporal_store(v, reinterpret_cast<double2_t*>(d + k));
+      }
+    } else {
+      for (int k = 0; k < 36; ++k) d[k] = s[T[k]];
+    }
+  }
+}
+
+// A few persistent worker threads per handle (created on the first host-path call that needs them).
+struct HostPool {
+  struct Job { const double* src; double* dst; int64_t n; };
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  std::deque<Job> queue;
+  int pending = 0;
+  bool stop = false;
+  explicit HostPool(int nthreads) {
+    for (int t = 0; t < nthreads; ++t) threads.emplace_back([this] { run(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    for (auto& t : threads) t.join();
+  }
+  void run() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return stop || !queue.empty(); });
+        if (queue.empty()) return;
+        j = queue.front();
+        queue.pop_front();
+      }
+      expand_sym_tangent(j.src, j.dst, j.n);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  // rows [0, n) of one chunk, cut into one piece per thread
+  void submit(const double* src, double* dst, int64_t n) {
+    const int64_t pieces = (int64_t)threads.size();
+    const int64_t per = (n + pieces - 1) / pieces;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int64_t o = 0; o < n; o += per) {
+      queue.push_back(Job{src + o * 21, dst + o * 36, std::min(per, n - o)});
+      ++pending;
+    }
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [this] { return pending == 0; });
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
+constexpr int DXM_MAX_CHUNKS = 16;
+
 struct dxm_material {
   int law = 0;
   int device = 0;
@@ -121,9 +205,27 @@ struct dxm_material {
   int stats_capacity = 0;
   int last_grid = 0;                      // stats records written by the last integrate
   hipStream_t pipe_stream = nullptr;      // second stream of the chunk-pipelined host path
-  hipStream_t last_stream = nullptr;
+  // completion of the last launch: an event owned by the handle, recorded on the caller's stream (the
+  // stream itself may be gone by the time the handle is asked to wait: e.g. a torch side stream)
+  hipEvent_t last_event = nullptr;
+  bool last_event_recorded = false;       // false while the last launch was stream-captured (no event then)
   bool launched = false;
   hipStream_t own_stream = nullptr;
+  // launch configuration identity (dxm_launch_generation): epoch changes with parameters / layout /
+  // placement / options, parity with every advance that swaps the two state buffers
+  uint64_t epoch = 0;
+  int parity = 0;
+  // options (dxm_set_option)
+  bool opt_pipeline = true;               // chunk-pipelined host path
+  bool opt_sym_transfer = true;           // host path: move the symmetric tangent packed, expand on the host
+  bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
+  bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
+  bool opt_tune_verbose = false;
+  int opt_host_threads = 8;
+  int opt_max_chunks = DXM_MAX_CHUNKS;
+  HostPool* pool = nullptr;
+  double* h_ct21 = nullptr;               // page-locked (n, 21) landing area of the packed tangent
+  hipEvent_t chunk_done[DXM_MAX_CHUNKS] = {};
   int num_cu = 256;
   int blocks_per_cu = 5;
   bool sym_tangent = false;  // symmetric-packed (21) tangent instead of the full 6x6 (36)
@@ -134,6 +236,8 @@ struct dxm_material {
   double* d_ct = nullptr;
   double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
 };
+
+static int sync_last(dxm_material* m);
 
 // number of parameters a law takes in THIS build: a JIT build with a user-supplied hardening law
 // (DXM_CUSTOM_HARDENING) takes [E, nu, sig0, c0..c5] for the two "voce" slots
@@ -295,29 +399,19 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   // kernel falls into a slow mode (0.91 vs 0.83 ms at 1e7 points, bimodal by allocation address);
   // a 256 B stagger per slot removes it (profiles/r01_tune_state_stride.txt).
   m->ld = ((npoints + 255) / 256) * 256 + 32;
-  if (const char* s = getenv("DXM_LD_PAD")) m->ld += (atoi(s) / 2) * 2 - 32;   // tuning knob (doubles)
-  if (const char* s = getenv("DXM_S1_SKEW")) m->s1_skew = (size_t)atol(s) & ~(size_t)15;  // tuning knob (bytes)
   auto bail = [&](void) -> dxm_material* { dxm_destroy(m); return nullptr; };
   if (build_params(m, params, n_params) != 0) return bail();
   DeviceGuard guard(device);
   if (!guard.ok) { fail(-2, "hipSetDevice(%d) failed", device); return bail(); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->num_cu = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
-    fail(-2, "hipStreamCreate failed"); return bail();
+  if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&m->last_event, hipEventDisableTiming) != hipSuccess) {
+    fail(-2, "hipStreamCreate / hipEventCreate failed"); return bail();
   }
   const LawDesc& d = kLaws[law];
   if (d.n_slots > 0) {
     const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
-#ifdef DXM_EXPERIMENT_EXTERNAL_STATE
-    // Placement experiments only (tools/placement_*.py build their own copy of the library with this
-    // flag): the state lives at caller-chosen device addresses and is not owned by the handle.
-    if (const char* e0 = getenv("DXM_STATE_EXTERNAL")) {
-      m->state[0] = reinterpret_cast<double*>(strtoull(e0, nullptr, 16));
-      m->state[1] = reinterpret_cast<double*>(reinterpret_cast<char*>(m->state[0]) + bytes + m->s1_skew);
-      if (const char* e1 = getenv("DXM_STATE_EXTERNAL_S1")) m->state[1] = reinterpret_cast<double*>(strtoull(e1, nullptr, 16));
-    } else
-#endif
     {
       if (hipMalloc(&m->state_base, 2 * bytes + m->s1_skew) != hipSuccess) {
         fail(-3, "hipMalloc of %zu state bytes failed", 2 * bytes + m->s1_skew); return bail();
@@ -355,10 +449,9 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
       m->blocks_per_cu = occ;
     }
     if (law == DXM_LAW_ELASTIC_ISO || law == DXM_LAW_J2_LINEAR || law == DXM_LAW_J2_VOCE) m->blocks_per_cu = 32;
-    if (const char* s = getenv("DXM_BLOCKS_PER_CU")) m->blocks_per_cu = atoi(s) > 0 ? atoi(s) : m->blocks_per_cu;
-    if (m->blocks_per_cu > 256) m->blocks_per_cu = 256;
   }
-  m->stats_capacity = m->num_cu * m->blocks_per_cu * 8;  // up to 8 chunk launches per integrate
+  // one record per workgroup and launch; sized for the largest grid dxm_set_option("blocks_per_cu") allows
+  m->stats_capacity = m->num_cu * 256;
   if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {
     fail(-3, "hipMalloc of stats failed"); return bail();
   }
@@ -370,7 +463,11 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
 int dxm_destroy(dxm_material* m) {
   if (!m) return 0;
   DeviceGuard guard(m->device);
-  if (m->launched) (void)hipStreamSynchronize(m->last_stream);
+  (void)sync_last(m);
+  delete m->pool;
+  if (m->h_ct21) (void)hipHostFree(m->h_ct21);
+  for (hipEvent_t e : m->chunk_done) if (e) (void)hipEventDestroy(e);
+  if (m->last_event) (void)hipEventDestroy(m->last_event);
   if (m->state_base) (void)hipFree(m->state_base);
   if (m->d_stats) (void)hipFree(m->d_stats);
   if (m->d_grad) (void)hipFree(m->d_grad);
@@ -389,6 +486,7 @@ int dxm_law(const dxm_material* m) { return m ? m->law : -1; }
 
 int dxm_set_params(dxm_material* m, const double* params, int n_params) {
   if (!m || !params) return fail(-1, "null argument");
+  ++m->epoch;
   return build_params(m, params, n_params);
 }
 
@@ -398,6 +496,7 @@ int dxm_set_tangent_layout(dxm_material* m, int layout) {
   if (layout == DXM_TANGENT_SYM && kLaws[m->law].n_grad == 9)
     return fail(-1, "the FeFp tangent dP/dF is not symmetric: only DXM_TANGENT_FULL is available");
   m->sym_tangent = (layout == DXM_TANGENT_SYM);
+  ++m->epoch;
   return 0;
 }
 
@@ -408,6 +507,7 @@ int dxm_set_newton(dxm_material* m, int maxit, double rtol) {
   if (maxit < 1 || !(rtol > 0.0)) return fail(-1, "invalid Newton controls maxit=%d rtol=%g", maxit, rtol);
   m->maxit = maxit;
   m->rtol = rtol;
+  ++m->epoch;
   return build_params(m, m->raw_params.data(), (int)m->raw_params.size());
 }
 
@@ -419,9 +519,14 @@ static int check_field(const dxm_material* m, int which, int field) {
   return 0;
 }
 
+// Wait for the last launch on the handle.  The event belongs to the handle; if the last launch went
+// into a stream capture (no event can be recorded there) the whole device is waited for.
 static int sync_last(dxm_material* m) {
-  if (m->launched) {
-    HIP_TRY(hipStreamSynchronize(m->last_stream));
+  if (!m->launched) return 0;
+  if (m->last_event_recorded) {
+    HIP_TRY(hipEventSynchronize(m->last_event));
+  } else {
+    HIP_TRY(hipDeviceSynchronize());
   }
   return 0;
 }
@@ -501,6 +606,7 @@ int dxm_advance(dxm_material* m) {
     m->state[0] = m->state[1];
     m->state[1] = t;
     m->s1_alias = true;
+    m->parity ^= 1;   // launches now read / write the other buffer: dxm_launch_generation changes
   }
   return 0;
 }
@@ -520,7 +626,7 @@ int dxm_revert(dxm_material* m) {
 template <int LAW>
 static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64_t off, int64_t cnt,
                                 const double* grad, double* flux, double* ct, int stats_off,
-                                const MeshSource* fused = nullptr) {
+                                const MeshSource* fused, bool sym) {
   const double* s0 = m->state[0] + off;
   double* s1 = m->state[1] + off;
   BlockStats* bs = m->d_stats + stats_off;
@@ -528,13 +634,13 @@ static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64
 #define DXM_LAUNCH_SS(SYM, G)                                                                              \
   hipLaunchKernelGGL((small_strain_kernel<LAW, SYM, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, \
                      m->ld, flux, ct, bs, *fused)
-    if (fused->kind == 1) { if (m->sym_tangent) DXM_LAUNCH_SS(true, 1); else DXM_LAUNCH_SS(false, 1); }
-    else                  { if (m->sym_tangent) DXM_LAUNCH_SS(true, 2); else DXM_LAUNCH_SS(false, 2); }
+    if (fused->kind == 1) { if (sym) DXM_LAUNCH_SS(true, 1); else DXM_LAUNCH_SS(false, 1); }
+    else                  { if (sym) DXM_LAUNCH_SS(true, 2); else DXM_LAUNCH_SS(false, 2); }
 #undef DXM_LAUNCH_SS
     return;
   }
   const MeshSource none{};
-  if (m->sym_tangent)
+  if (sym)
     hipLaunchKernelGGL((small_strain_kernel<LAW, true, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
                        grad, s0, s1, m->ld, flux, ct, bs, none);
   else
@@ -542,9 +648,11 @@ static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64
                        grad, s0, s1, m->ld, flux, ct, bs, none);
 }
 
+// sym: tangent layout of THIS launch (the host path may ask for the packed form although the handle's
+// layout is the full block: it expands on the host)
 static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double* grad, double* flux,
                         double* ct, hipStream_t st, int stats_off, int* grid_out,
-                        const MeshSource* fused = nullptr) {
+                        const MeshSource* fused, bool sym) {
   if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
     return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
   const int64_t ntiles = (cnt + WAVE - 1) / WAVE;
@@ -554,9 +662,9 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
   if (stats_off + blocks > m->stats_capacity) return fail(-1, "internal: stats buffer too small");
   const int grid = (int)blocks;
   switch (m->law) {
-    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
-    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
-    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused); break;
+    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, sym); break;
+    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, sym); break;
+    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, sym); break;
     case DXM_LAW_FEFP_J2_VOCE:
     case DXM_LAW_FEFP_J2_LINEAR: {
       const double* s0 = m->state[0] + off;
@@ -586,11 +694,18 @@ static int launch(dxm_material* m, const double* grad, double* flux, double* ct,
                   const MeshSource* fused = nullptr) {
   if (m->n == 0) { m->last_grid = 0; return 0; }
   int grid = 0;
-  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused)) return rc;
+  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused, m->sym_tangent)) return rc;
   m->last_grid = grid;
-  m->last_stream = st;
   m->launched = true;
   m->s1_alias = false;  // the kernel rewrites every slot of s1
+  // completion marker owned by the handle (not recordable while the stream is being captured into a graph)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  m->last_event_recorded = false;
+  if (cap == hipStreamCaptureStatusNone) {
+    HIP_TRY(hipEventRecord(m->last_event, st));
+    m->last_event_recorded = true;
+  }
   return 0;
 }
 
@@ -662,7 +777,8 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
   (void)hipMemGetInfo(&free_b, &total_b);
   size_t budget = free_b / 2;
   int tried = 0, after_contrast = 0;
-  const bool verbose = getenv("DXM_TUNE_VERBOSE") != nullptr;
+  const bool verbose = m->opt_tune_verbose;
+  ++m->epoch;   // the state moves: graphs captured before are stale
   if (verbose) fprintf(stderr, "[dxm_tune_placement] initial %p: %.4f ms\n", (void*)m->state_base, t);
   for (int c = 0; c < max_candidates; ++c) {
     if (budget < block) break;
@@ -720,9 +836,8 @@ int dxm_get_stats(dxm_material* m, dxm_stats* stats) {
   if (m->launched && m->last_grid > 0) {
     DEVICE_GUARD(m);
     std::vector<BlockStats> h(m->last_grid);
-    HIP_TRY(hipMemcpyAsync(h.data(), m->d_stats, sizeof(BlockStats) * m->last_grid,
-                           hipMemcpyDeviceToHost, m->last_stream));
-    HIP_TRY(hipStreamSynchronize(m->last_stream));
+    if (int rc = sync_last(m)) return rc;
+    HIP_TRY(hipMemcpy(h.data(), m->d_stats, sizeof(BlockStats) * m->last_grid, hipMemcpyDeviceToHost));
     for (const BlockStats& b : h) {
       s.n_plastic += (int64_t)b.n_plastic;
       s.n_not_converged += (int64_t)b.n_not_converged;
@@ -779,24 +894,42 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 
 // Host-buffer form, shared by dxm_integrate and dxm_integrate_displacement.
 //   upload(off, cnt, stream) enqueues whatever produces m->d_grad[off .. off+cnt) on `stream`.
-// Large batches are cut into up to 8 chunks (multiples of 256 points) issued on two alternating
-// streams: the H2D of chunk c+1 and the kernel of chunk c+1 overlap the D2H of chunk c (PCIe is
-// full duplex and the 392 B/point coming back dominate).  Each chunk is one launch over a point
-// range; its block-stat records are appended after the previous chunk's.
+// Large batches are cut into up to 16 chunks (multiples of 256 points) issued on two alternating
+// streams: the H2D and the kernel of chunk c+1 overlap the D2H of chunk c (PCIe is full duplex and the
+// bytes coming back dominate).  Each chunk is one launch over a point range; its block-stat records
+// are appended after the previous chunk's.
+//
+// What crosses PCIe on the way back, per point: the flux (48 / 72 B), the tangent, and -- only when the
+// caller passes a destination -- the internal state variables (they are consumed at advance(), not per
+// Newton iteration: the Python layer fetches them on demand).  For the small-strain laws with the full
+// (N, 6, 6) tangent requested, the kernel writes the symmetric-packed form, 168 instead of 288 B/point
+// are moved into a page-locked landing area and worker threads rebuild the full block in the caller's
+// array chunk by chunk, behind the transfer of the following chunks (bit-identical to the full kernel).
 template <class Upload>
 static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
                             double* ct_aos, dxm_stats* stats, const MeshSource* fused = nullptr) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  const int nt = tangent_size(m);
+  const bool packed = m->opt_sym_transfer && !m->sym_tangent && d.n_grad == 6 && ct_aos != nullptr;
+  const bool sym = m->sym_tangent || packed;                         // layout of the launches of this call
+  const int nt = sym ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad;   // doubles per point in d_ct
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
-  int nchunks = (int)(n / 262144);
+  if (packed) {
+    if (!m->h_ct21) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_ct21), sizeof(double) * n * 21, hipHostMallocDefault));
+    if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
+      delete m->pool;
+      m->pool = new HostPool(m->opt_host_threads);
+    }
+  }
+  int nchunks = (int)(n / 131072);
   if (nchunks < 1) nchunks = 1;
-  if (nchunks > 8) nchunks = 8;
-  if (getenv("DXM_NO_PIPELINE")) nchunks = 1;
-  int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
-  int stats_off = 0;
+  if (nchunks > m->opt_max_chunks) nchunks = m->opt_max_chunks;
+  if (!m->opt_pipeline) nchunks = 1;
+  for (int c = 0; c < nchunks; ++c)
+    if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));
+  const int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
+  int stats_off = 0, issued = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
   for (int c = 0; c < nchunks; ++c) {
     const int64_t off = (int64_t)c * csize;
@@ -808,7 +941,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     MeshSource src{};
     if (fused) { src = *fused; src.point0 = off; }
     if (int rc = launch_range(m, off, cnt, fused ? m->d_flux : m->d_grad + off * d.n_grad, m->d_flux + off * d.n_flux,
-                              m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr))
+                              m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr, sym))
       return rc;
     stats_off += grid;
     if (flux_aos)
@@ -824,16 +957,29 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
                              hipMemcpyDeviceToHost, st));
     }
-    if (ct_aos)
-      HIP_TRY(hipMemcpyAsync(ct_aos + off * nt, m->d_ct + off * nt, sizeof(double) * cnt * nt,
-                             hipMemcpyDeviceToHost, st));
+    if (ct_aos) {
+      double* dst = packed ? m->h_ct21 + off * 21 : ct_aos + off * nt;
+      HIP_TRY(hipMemcpyAsync(dst, m->d_ct + off * nt, sizeof(double) * cnt * nt, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(m->chunk_done[c], st));
+    issued = c + 1;
   }
   m->last_grid = stats_off;
-  m->last_stream = m->own_stream;
   m->launched = true;
   m->s1_alias = false;  // every slot of s1 has been rewritten
-  HIP_TRY(hipStreamSynchronize(m->pipe_stream));
-  return dxm_get_stats(m, stats);  // synchronises own_stream
+  // the chunks complete in issue order on their two streams; expand each as soon as it has landed
+  for (int c = 0; c < issued; ++c) {
+    HIP_TRY(hipEventSynchronize(m->chunk_done[c]));
+    if (packed) {
+      const int64_t off = (int64_t)c * csize;
+      const int64_t cnt = (n - off) < csize ? (n - off) : csize;
+      m->pool->submit(m->h_ct21 + off * 21, ct_aos + off * 36, cnt);
+    }
+  }
+  HIP_TRY(hipEventRecord(m->last_event, m->own_stream));   // everything of this call is complete already
+  m->last_event_recorded = true;
+  if (packed) m->pool->wait();
+  return dxm_get_stats(m, stats);
 }
 
 extern "C" {
@@ -851,7 +997,7 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   if (!grad_aos) return fail(-1, "null gradient pointer");
   DEVICE_GUARD(m);
   if (int rc = ensure_host_path_buffers(m)) return rc;
-  if (m->launched) HIP_TRY(hipStreamSynchronize(m->last_stream));
+  if (int rc = sync_last(m)) return rc;
   const int ng = d.n_grad;
   auto upload = [&](int64_t off, int64_t cnt, hipStream_t st) -> int {
     HIP_TRY(hipMemcpyAsync(m->d_grad + off * ng, grad_aos + off * ng, sizeof(double) * cnt * ng,
@@ -964,7 +1110,7 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
     else
       hipLaunchKernelGGL(tet4_gradient_kernel<1>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
                          u_dev, mesh->n_cells, mesh->qp.nqp, grad_dev);
-  } else if (mesh->qp.nqp >= 4 && !getenv("DXM_GRADIENT_DIRECT")) {   // nodal data staged through LDS once per cell
+  } else if (mesh->qp.nqp >= 4) {   // nodal data staged through LDS once per cell
     if (kind == 0)
       hipLaunchKernelGGL(hex8_gradient_staged_kernel<0>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
                          u_dev, mesh->n_cells, mesh->qp, grad_dev);
@@ -984,7 +1130,6 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
 
 // kind of in-kernel gradient evaluation this mesh allows: 1 hex8 x 8 points, 2 tet4, 0 none
 static int fused_kind(const dxm_mesh* mesh) {
-  if (getenv("DXM_NO_FUSED_GRADIENT")) return 0;
   if (mesh->nodes_per_cell == 8) return mesh->qp.nqp == 8 ? 1 : 0;
   return mesh->nodes_per_cell == 4 ? 2 : 0;
 }
@@ -1007,10 +1152,10 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
   if (dxm_mesh_npoints(mesh) != m->n) return fail(-1, "mesh has %lld Gauss points, material %lld",
                                                    (long long)dxm_mesh_npoints(mesh), (long long)m->n);
   DEVICE_GUARD(m);
-  const bool fuse = fusable(mesh);   // hex8 x 8 points: gradient evaluated inside the update kernel
+  const bool fuse = m->opt_fused_gradient && fusable(mesh);   // gradient evaluated inside the update kernel
   if (int rc = ensure_host_path_buffers(m, !fuse)) return rc;
   hipStream_t st = m->own_stream;
-  if (m->launched) HIP_TRY(hipStreamSynchronize(m->last_stream));
+  if (int rc = sync_last(m)) return rc;
   HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * 3 * mesh->n_nodes, hipMemcpyHostToDevice, st));
   MeshSource src{};
   if (fuse) {
@@ -1041,7 +1186,7 @@ int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const dou
   DEVICE_GUARD(m);
   hipStream_t st = (hipStream_t)hip_stream;
   const LawDesc& d = kLaws[m->law];
-  if (fusable(mesh)) {   // one kernel: no gradient array at all
+  if (m->opt_fused_gradient && fusable(mesh)) {   // one kernel: no gradient array at all
     const MeshSource src = mesh_source(mesh, u_dev);
     return launch(m, flux_dev /* unused, only checked for alignment */, flux_dev, ct_dev, st, &src);
   }
@@ -1059,5 +1204,59 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
 }
 
 const char* dxm_kernel_name(const dxm_material* m) { return m ? kLaws[m->law].kernel : ""; }
+
+uint64_t dxm_launch_generation(const dxm_material* m) { return m ? (m->epoch << 1) | (uint64_t)m->parity : 0; }
+
+int dxm_set_option(dxm_material* m, const char* name, double value) {
+  if (!m || !name) return fail(-1, "null argument");
+  const std::string k(name);
+  const bool on = value != 0.0;
+  if (k == "pipeline") m->opt_pipeline = on;
+  else if (k == "sym_transfer") m->opt_sym_transfer = on;
+  else if (k == "fused_gradient") m->opt_fused_gradient = on;
+  else if (k == "tune_verbose") m->opt_tune_verbose = on;
+  else if (k == "host_threads") {
+    if (!(value >= 1 && value <= 256)) return fail(-1, "host_threads must be in [1, 256]");
+    m->opt_host_threads = (int)value;
+  } else if (k == "max_chunks") {
+    if (!(value >= 1 && value <= DXM_MAX_CHUNKS)) return fail(-1, "max_chunks must be in [1, %d]", DXM_MAX_CHUNKS);
+    m->opt_max_chunks = (int)value;
+  } else if (k == "blocks_per_cu") {
+    if (!(value >= 1 && value <= 256)) return fail(-1, "blocks_per_cu must be in [1, 256]");
+    m->blocks_per_cu = (int)value;
+  } else {
+    return fail(-1, "unknown option '%s'", name);
+  }
+  ++m->epoch;
+  return 0;
+}
+
+int dxm_isv_host(dxm_material* m, int which, double* isv_aos) {
+  if (!m) return fail(-1, "null handle");
+  if (which != DXM_S0 && which != DXM_S1) return fail(-1, "state selector must be DXM_S0 or DXM_S1");
+  const LawDesc& d = kLaws[m->law];
+  const int total = isv_total(d);
+  if (total == 0 || m->n == 0) return 0;
+  if (!isv_aos) return fail(-1, "null host pointer");
+  DEVICE_GUARD(m);
+  if (int rc = sync_last(m)) return rc;
+  if (!m->d_isv) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * m->n * total));
+  if (int rc = pack_isv_range(m, which, 0, m->n, m->d_isv, m->own_stream)) return rc;
+  HIP_TRY(hipMemcpyAsync(isv_aos, m->d_isv, sizeof(double) * m->n * total, hipMemcpyDeviceToHost, m->own_stream));
+  HIP_TRY(hipStreamSynchronize(m->own_stream));
+  return 0;
+}
+
+int dxm_host_register(void* p, uint64_t bytes) {
+  if (!p || bytes == 0) return fail(-1, "null / empty host range");
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) return fail(-3, "hipHostRegister(%p, %llu) failed: %s", p, (unsigned long long)bytes, hipGetErrorString(e));
+  return 0;
+}
+
+int dxm_host_unregister(void* p) {
+  if (p) HIP_TRY(hipHostUnregister(p));
+  return 0;
+}
 
 }  // extern "C"

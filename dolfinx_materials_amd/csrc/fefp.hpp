@@ -28,14 +28,18 @@ constexpr int FEFP_SLOT_CPI = 7;  // isochoric Cp^-1, Mandel (hidden state)
 constexpr int FEFP_NSLOTS = 13;
 
 constexpr int FEFP_STAGE = 64 * 9;           // F in / PK1 out staging (doubles per wave)
-constexpr int F2_PPR = 14;   // points per tangent round: two steps of 7 point slots x 9 columns
 constexpr int F2_REC = 73;   // record stride: 54 staged doubles per point, padded to 146 dwords = 18 mod 64,
-                             // so that the 14 owner lanes write conflict-free (18 l mod 32 distinct) and the
+                             // so that the owner lanes write conflict-free (18 l mod 32 distinct) and the
                              // point slots of a 32-lane read group land on (almost) disjoint banks
-constexpr int F2_OUT = ((F2_PPR * 81 + 127) / 128) * 128;   // out-tile, padded to whole KiB
+// Wave-private LDS map (doubles): [out-tile, aliasing the F / PK1 staging | records].  A tangent round handles
+// F2_PPR points: two steps of 7 point slots x 9 columns.
+constexpr int F2_PPR = 14;
+constexpr int F2_NIT = (F2_PPR * 81 + 2 * WAVE - 1) / (2 * WAVE);   // 1 KiB wave stores per round
+constexpr int F2_OUT = F2_NIT * 2 * WAVE;                           // out-tile, padded to whole KiB
+constexpr int F2_COEF = ((F2_PPR * F2_REC + 1) / 2) * 2;
+constexpr int F2_LDS_PER_WAVE = F2_OUT + F2_COEF;                   // 2176 doubles: 69.6 KB per workgroup, 2 per CU
 static_assert(F2_OUT >= FEFP_STAGE, "the out-tile aliases the F / PK1 staging region");
-static_assert(8 * HEX_FUSED_REC <= F2_PPR * F2_REC, "the 8 cell records of a fused tile live in the coefficient region");
-constexpr int F2_LDS_PER_WAVE = F2_OUT + F2_PPR * F2_REC;
+static_assert(8 * HEX_FUSED_REC <= F2_COEF, "the 8 cell records of a fused tile live in the coefficient region");
 
 __device__ __forceinline__ double det3(const double* A) {
   return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) +
@@ -96,9 +100,22 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
   }
 }
 
+// symmetric 3x3 matrices are kept as 6 values [xx, yy, zz, xy, xz, yz]; SYM(i, j) is the slot of entry (i, j)
+#define DXM_SYM(i, j) ((i) == (j) ? (i) : ((i) + (j) + 2))
+
 // HARD: 0 = linear hardening R = sig0 + H p (prm.h1 = H), 1 = Voce (prm.h1 = sigu, prm.h2 = b)
 // GRAD: 0 = F comes from the (N,9) array Fin; 1 / 2 = F = I + grad u is evaluated in the kernel from the
 //       displacement vector of a hex8 mesh with 8 Gauss points per cell / of a tet4 mesh (`src`, see small_strain.hpp)
+//
+// What was measured for this kernel in round 2 (profiles/r02_fefp_ab_prefetch_ppr.jsonl, one process, interleaved):
+//   * register diet (symmetric storage, Q = h M form of the tangent coefficients, per-tile re-derivation of the
+//     lane invariants): 256 VGPRs + 27 spilled -> 255 VGPRs, no scratch; same time (2.06 vs 2.05 ms): the spill
+//     traffic was never on the critical path;
+//   * requesting the next tile's inputs ahead of this tile's stores by LDS-DMA (global_load_lds into a spare LDS
+//     region, counted s_waitcnt at the top of the next tile; needs 7-point rounds to make room): +6 % time, of
+//     which +5 % is the 7-point rounds alone (16 % more instructions per tile) -- the kernel is bound by the
+//     instructions each of its two resident waves per SIMD has to issue (VALU + LDS), not by load latency or by
+//     the in-order completion of its memory operations.  Not shipped.
 template <int HARD, int GRAD = 0>
 __global__ void __launch_bounds__(BLOCK, 2)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
@@ -106,9 +123,8 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
             double* __restrict__ Pout, double* __restrict__ ct, BlockStats* __restrict__ stats,
             const MeshSource src) {
   __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * F2_LDS_PER_WAVE];
-  __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
 
-  const int lane = threadIdx.x & (WAVE - 1);
+  const int lane0 = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x >> 6;
   double* stage = lds_all + wid * F2_LDS_PER_WAVE;   // F in / PK1 out staging ...
   double* outt = stage;                              // ... reused as the tangent out-tile
@@ -129,23 +145,29 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
 
   constexpr int TI[9] = {0, 1, 2, 0, 1, 0, 2, 1, 2};  // row index of entry t of the 9-vector
   constexpr int TJ[9] = {0, 1, 2, 1, 0, 2, 0, 2, 1};  // column index           (utils.py:168-190)
-  // tangent epilogue: lane = (point slot ps, tangent column cc); lane 63 idles
-  const int ps = lane / 9;
-  const int cc = lane - ps * 9;
-  const int kk = (0x26124 >> (2 * cc)) & 3;   // TI[cc] packed 2 bits each: 0,1,2,0,1,0,2,1,2
-  const int LL = (0x18864 >> (2 * cc)) & 3;   // TJ[cc]: 0,1,2,1,0,2,0,2,1
-  const double mk0 = kk == 0 ? 1.0 : 0.0, mk1 = kk == 1 ? 1.0 : 0.0, mk2 = kk == 2 ? 1.0 : 0.0;
+  int lane = lane0;
 
   for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; tile < ntiles; tile += tile_stride) {
     const int64_t base = tile * WAVE;
     const int npts = (n - base) < WAVE ? (int)(n - base) : WAVE;
+    // Everything derived from the lane index is re-derived per tile from an opaque copy: hoisted out of the
+    // tile loop these per-lane invariants (LDS addresses, column indices, masks) occupy ~40 VGPRs across the
+    // whole body and the kernel spills at its 256-register budget; recomputing them costs ~30 integer ops.
+    asm volatile("" : "+v"(lane));
+    lane &= WAVE - 1;   // gives the value range back to the compiler
     const bool valid = lane < npts;
     const int64_t gi = base + lane;
+    // tangent epilogue: lane = (point slot ps, tangent column cc); lane 63 idles
+    const int ps = lane / 9;
+    const int cc = lane - ps * 9;
+    const int kk = (0x26124 >> (2 * cc)) & 3;   // TI[cc] packed 2 bits each: 0,1,2,0,1,0,2,1,2
+    const int LL = (0x18864 >> (2 * cc)) & 3;   // TJ[cc]: 0,1,2,1,0,2,0,2,1
+    const double mk0 = kk == 0 ? 1.0 : 0.0, mk1 = kk == 1 ? 1.0 : 0.0, mk2 = kk == 2 ? 1.0 : 0.0;
 
     double F[9];
     double p_n = 0.0, g6[6] = {1, 1, 1, 0, 0, 0};
     if constexpr (GRAD == 0) {
-      // ---- 1. coalesced load of F (64 x 9 doubles = 288 double2 per tile) ------------------------
+      // ---- 1. F through LDS (64 x 9 doubles = 288 double2 per tile) ---------------------------------
       if (npts == WAVE) {
         const double2_t* gsrc = reinterpret_cast<const double2_t*>(Fin + base * 9);
         double2_t v[5];
@@ -173,13 +195,13 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
 #pragma unroll
         for (int c = 0; c < 6; ++c) g6[c] = stream_load<3>(s0 + (int64_t)(FEFP_SLOT_CPI + c) * ld + gi);
       }
-      wave_lds_sync();
+      wave_lds_order();
       {
         const double* f = stage + lane * 9;
         F[0] = f[0]; F[4] = f[1]; F[8] = f[2]; F[1] = f[3]; F[3] = f[4];
         F[2] = f[5]; F[6] = f[6]; F[5] = f[7]; F[7] = f[8];
       }
-      wave_lds_sync();
+      wave_lds_order();
     } else {
       if constexpr (GRAD == 1) {
         // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
@@ -195,7 +217,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           double2_t* d = reinterpret_cast<double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC + (lane & 7) * 6);
           d[0] = r0; d[1] = r1; d[2] = r2;
         }
-        wave_lds_sync();
+        wave_lds_order();
         {
           const double2_t* rec = reinterpret_cast<const double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC);
           auto node = [&](int m, double* X, double* U) {
@@ -211,7 +233,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
             for (int k = 0; k < 9; ++k) F[k] = 0.0;
           }
         }
-        wave_lds_sync();  // the coefficient region is rewritten by the tangent rounds
+        wave_lds_order();  // the coefficient region is rewritten by the tangent rounds
       } else {
         if (valid) {
           tet4_cell_disp_grad(src.coords, src.conn, src.u, (src.point0 + gi) / src.nqp, F);
@@ -229,14 +251,14 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     }
 
     // ---- 2. trial state ------------------------------------------------------------------------
-    double G[9];
-    G[0] = g6[0]; G[4] = g6[1]; G[8] = g6[2];
-    G[1] = G[3] = g6[3] * RS2; G[2] = G[6] = g6[4] * RS2; G[5] = G[7] = g6[5] * RS2;
-    const double J = det3(F);
-    double Fi[9];
+    double G[6];   // Cp_bar^-1 (symmetric)
+    G[0] = g6[0]; G[1] = g6[1]; G[2] = g6[2];
+    G[3] = g6[3] * RS2; G[4] = g6[4] * RS2; G[5] = g6[5] * RS2;
+    double Fi[9], J;
     {
       double cf[9];
       cof3(F, cf);
+      J = F[0] * cf[0] + F[1] * cf[1] + F[2] * cf[2];
       const double iJ = fast_rcp(J);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
@@ -246,32 +268,46 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     const double J23 = cbrt(J * J);
     const double Jm23 = fast_rcp(J23);
     double h[9];  // h[L][m] = J^(-2/3) G[L][N] F[m][N]
-    mmt(G, F, h);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] *= Jm23;
-    double d[9];  // be_bar_trial = F h, then its deviator
-    mm(F, h, d);
-    const double Itr = (d[0] + d[4] + d[8]) / 3.0;  // exact for F = I (zero stress)
-    d[0] -= Itr; d[4] -= Itr; d[8] -= Itr;
-    double atr2 = 0.0;
+    for (int L = 0; L < 3; ++L)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) atr2 += d[k] * d[k];
-    const double atr = sqrt(atr2);
+      for (int m = 0; m < 3; ++m)
+        h[L * 3 + m] = Jm23 * (G[DXM_SYM(L, 0)] * F[m * 3] + G[DXM_SYM(L, 1)] * F[m * 3 + 1] + G[DXM_SYM(L, 2)] * F[m * 3 + 2]);
+    double d[6];  // be_bar_trial = F h (symmetric), then its deviator
+    {
+      constexpr int SI[6] = {0, 1, 2, 0, 0, 1}, SJ[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        d[t] = F[SI[t] * 3] * h[SJ[t]] + F[SI[t] * 3 + 1] * h[3 + SJ[t]] + F[SI[t] * 3 + 2] * h[6 + SJ[t]];
+    }
+    const double Itr = (d[0] + d[1] + d[2]) / 3.0;  // exact for F = I (zero stress)
+    d[0] -= Itr; d[1] -= Itr; d[2] -= Itr;
+    const double atr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + 2.0 * (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]));
     double R_n, dR_n;
     hardening<HARD>(prm, p_n, R_n, dR_n);
     const double f_tr = SQ32 * mu * atr - R_n;
 
     // ---- 3. return mapping ---------------------------------------------------------------------
-    double dp = 0.0, Ie = Itr, a = atr, theta = 1.0;
-    double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // Q[k][L], scaled by mu/atr below
-    double sdev[9];                             // dev(be_bar)
+    // Plastic: dev be = a s_hat, tr be / 3 = Ie from the 2x2 system (r1, r2); the tangent needs
+    //   Q[k][L] = (mu / atr) (a' dDp/dF - theta datr/dF)[k][L] = (h M)[L][k] + eq Fi[L][k]
+    // with the symmetric M = ms s_hat + mc cof(s_hat) + m1 1 (implicit differentiation of (r1, r2) with
+    // respect to (atr, det s_hat)).
+    double dp = 0.0, Ie = Itr, theta = 1.0, eq = 0.0;
+    double M[6] = {0, 0, 0, 0, 0, 0};
+    double sdev[6];                             // dev(be_bar)
     const bool plastic = f_tr > 0.0;
     if (plastic) {
-      double sh[9];
+      double sh[6], cs[6];
       const double iatr = fast_rcp(atr);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) sh[k] = d[k] * iatr;
-      const double delta = det3(sh);
+      for (int k = 0; k < 6; ++k) sh[k] = d[k] * iatr;
+      cs[0] = sh[1] * sh[2] - sh[5] * sh[5];
+      cs[1] = sh[0] * sh[2] - sh[4] * sh[4];
+      cs[2] = sh[0] * sh[1] - sh[3] * sh[3];
+      cs[3] = sh[4] * sh[5] - sh[3] * sh[2];
+      cs[4] = sh[3] * sh[5] - sh[4] * sh[1];
+      cs[5] = sh[3] * sh[4] - sh[0] * sh[5];
+      const double delta = sh[0] * cs[0] + sh[3] * cs[3] + sh[4] * cs[4];
       const double tol1 = (prm.tol / fabs(prm.sig0)) * fmax(fabs(prm.sig0), SQ32 * mu * atr);
       unsigned iters = 0;
       for (int it = 0;; ++it) {
@@ -292,82 +328,89 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         Ie += (-j11 * r2 + j21 * r1) * idet;
         ++iters;
       }
-      const double p_new = p_n + dp;
       double R_1, dR_1;
-      hardening<HARD>(prm, p_new, R_1, dR_1);
-      a = SQ23 * R_1 * imu;
+      hardening<HARD>(prm, p_n + dp, R_1, dR_1);
+      const double a = SQ23 * R_1 * imu;
       const double ap = SQ23 * dR_1 * imu;
       theta = a * iatr;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) sdev[k] = a * sh[k];
+      for (int k = 0; k < 6; ++k) sdev[k] = a * sh[k];
       // implicit differentiation of (r1, r2) = 0 with respect to (atr, delta)
       const double igI = fast_rcp(3.0 * Ie * Ie - 0.5 * a * a);
       const double dIe_da = (a * Ie - 3.0 * a * a * delta) * igI;
       const double dIe_dd = -(a * a * a) * igI;
       const double r_dp = -ap - SQ6 * Ie - SQ6 * dp * dIe_da * ap;
       const double r_dd = -SQ6 * dp * dIe_dd;
-      double cs[9], hs[9], hc[9];
-      cof3(sh, cs);
-      mm(h, sh, hs);  // (h s)[L][k]
-      mm(h, cs, hc);  // (h cof)[L][k]
-      const double trc = cs[0] + cs[4] + cs[8];
       const double ir_dp = fast_rcp(r_dp);
+      const double ca = -ap * ir_dp - theta;          // coefficient of N1 = datr/dF
+      const double cb = -ap * r_dd * ir_dp * iatr;    // coefficient of atr N2 = atr ddelta/dF
+      const double mia = mu * iatr;
+      const double ms = mia * (2.0 * ca - 6.0 * delta * cb);
+      const double mc = mia * 2.0 * cb;
+      const double m1 = -mia * (2.0 / 3.0) * (cs[0] + cs[1] + cs[2]) * cb;
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int L = 0; L < 3; ++L) {
-          const double n1 = 2.0 * hs[L * 3 + k] - (2.0 / 3.0) * atr * Fi[L * 3 + k];
-          const double n2 = (2.0 * hc[L * 3 + k] - (2.0 / 3.0) * trc * h[L * 3 + k] -
-                             2.0 * delta * atr * Fi[L * 3 + k] - 3.0 * delta * n1) * iatr;
-          const double np_ = -(n1 + r_dd * n2) * ir_dp;
-          Q[k * 3 + L] = (ap * np_ - theta * n1) * (mu * iatr);
-        }
+      for (int k = 0; k < 6; ++k) M[k] = ms * sh[k] + mc * cs[k];
+      M[0] += m1; M[1] += m1; M[2] += m1;
+      eq = -(2.0 / 3.0) * mu * ca;
       if (valid) {
         ++c_plastic;
         c_maxit = iters > c_maxit ? iters : c_maxit;
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) sdev[k] = d[k];
-      Ie = Itr;
+      for (int k = 0; k < 6; ++k) sdev[k] = d[k];
     }
     const double p_new = p_n + dp;
 
     // ---- 4. stress, new state --------------------------------------------------------------------
-    double tau[9];
     const double pr = 0.5 * kappa * (J * J - 1.0);
+    double P[9];   // P = tau F^-T, tau = mu dev(be_bar) + pr 1
+    {
+      double tau[6];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) tau[k] = mu * sdev[k];
-    tau[0] += pr; tau[4] += pr; tau[8] += pr;
-    double P[9];
-    mmt(tau, Fi, P);  // P = tau F^-T
-    double be[9];
+      for (int k = 0; k < 6; ++k) tau[k] = mu * sdev[k];
+      tau[0] += pr; tau[1] += pr; tau[2] += pr;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) be[k] = sdev[k];
-    be[0] += Ie; be[4] += Ie; be[8] += Ie;
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int Jx = 0; Jx < 3; ++Jx)
+          P[i * 3 + Jx] = tau[DXM_SYM(i, 0)] * Fi[Jx * 3] + tau[DXM_SYM(i, 1)] * Fi[Jx * 3 + 1] + tau[DXM_SYM(i, 2)] * Fi[Jx * 3 + 2];
+    }
     {
       double chk = p_new;
 #pragma unroll
       for (int k = 0; k < 9; ++k) chk += P[k];
       if (valid && !(fabs(chk) <= 1.79769313486231570e308)) ++c_nan;
     }
+    // new isochoric Cp^-1 = J^(2/3) F^-1 be F^-T with be F^-T = P / mu + (Ie - pr / mu) F^-T
+    double gn[6];
+    {
+      double t[9];
+      const double cI = Ie - pr * imu;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int Jx = 0; Jx < 3; ++Jx) t[i * 3 + Jx] = P[i * 3 + Jx] * imu + cI * Fi[Jx * 3 + i];
+      constexpr int SI[6] = {0, 1, 2, 0, 0, 1}, SJ[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        gn[k] = J23 * (Fi[SI[k] * 3] * t[SJ[k]] + Fi[SI[k] * 3 + 1] * t[3 + SJ[k]] + Fi[SI[k] * 3 + 2] * t[6 + SJ[k]]);
+    }
+
     if (valid) {
-      double t[9], gn[9];
-      mmt(be, Fi, t);   // be F^-T
-      mm(Fi, t, gn);    // F^-1 be F^-T
       stream_store<1>(s1 + (int64_t)FEFP_SLOT_P * ld + gi, p_new);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 0) * ld + gi, be[0]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 1) * ld + gi, be[4]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 2) * ld + gi, be[8]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 3) * ld + gi, SQ2 * be[1]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 4) * ld + gi, SQ2 * be[2]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 5) * ld + gi, SQ2 * be[5]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 0) * ld + gi, J23 * gn[0]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 1) * ld + gi, J23 * gn[4]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 2) * ld + gi, J23 * gn[8]);
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 3) * ld + gi, SQ2 * J23 * 0.5 * (gn[1] + gn[3]));
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 4) * ld + gi, SQ2 * J23 * 0.5 * (gn[2] + gn[6]));
-      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 5) * ld + gi, SQ2 * J23 * 0.5 * (gn[5] + gn[7]));
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 0) * ld + gi, sdev[0] + Ie);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 1) * ld + gi, sdev[1] + Ie);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 2) * ld + gi, sdev[2] + Ie);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 3) * ld + gi, SQ2 * sdev[3]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 4) * ld + gi, SQ2 * sdev[4]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_BE + 5) * ld + gi, SQ2 * sdev[5]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 0) * ld + gi, gn[0]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 1) * ld + gi, gn[1]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 2) * ld + gi, gn[2]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 3) * ld + gi, SQ2 * gn[3]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 4) * ld + gi, SQ2 * gn[4]);
+      stream_store<1>(s1 + (int64_t)(FEFP_SLOT_CPI + 5) * ld + gi, SQ2 * gn[5]);
     }
 
     // ---- 5. PK1 through LDS, coalesced store -------------------------------------------------------
@@ -376,7 +419,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       f[0] = P[0]; f[1] = P[4]; f[2] = P[8]; f[3] = P[1]; f[4] = P[3];
       f[5] = P[2]; f[6] = P[6]; f[7] = P[5]; f[8] = P[7];
     }
-    wave_lds_sync();
+    wave_lds_order();
     if (npts == WAVE) {
       double2_t* gdst = reinterpret_cast<double2_t*>(Pout + base * 9);
 #pragma unroll
@@ -402,17 +445,20 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
     // F2_PPR points and leave as contiguous 1 KiB wave stores (full 64 B HBM write requests).
     const double mt = mu * theta;
     const double c0 = kappa * J * J;
-    double V[9], U[9], Sd[9];
+    const double eqw = eq - (2.0 / 3.0) * mt;
+    const double gs = mt * Jm23;
+    double V[9], U[9], W[9], Sd[9];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int L = 0; L < 3; ++L) {
         V[k * 3 + L] = c0 * Fi[L * 3 + k] - (2.0 / 3.0) * mt * h[L * 3 + k];
         U[k * 3 + L] = mt * h[L * 3 + k] - P[k * 3 + L];                 // U[i][L], i = k here
-        Q[k * 3 + L] = Q[k * 3 + L] - (2.0 / 3.0) * mt * Fi[L * 3 + k];  // W[k][L]
+        W[k * 3 + L] = h[L * 3] * M[DXM_SYM(0, k)] + h[L * 3 + 1] * M[DXM_SYM(1, k)] + h[L * 3 + 2] * M[DXM_SYM(2, k)] +
+                       eqw * Fi[L * 3 + k];
+        // Sd[i][J] = d[i][m] Fi[J][m]   (i = k, J = L here)
+        Sd[k * 3 + L] = d[DXM_SYM(k, 0)] * Fi[L * 3] + d[DXM_SYM(k, 1)] * Fi[L * 3 + 1] + d[DXM_SYM(k, 2)] * Fi[L * 3 + 2];
       }
-    mmt(d, Fi, Sd);  // Sd[i][J] = d[i][m] Fi[J][m]
-    const double gs = mt * Jm23;
 
 #pragma unroll 1
     for (int rd = 0; rd < (WAVE + F2_PPR - 1) / F2_PPR; ++rd) {
@@ -425,14 +471,14 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           rec[t] = Fi[t];
           rec[9 + t] = V[TI[t] * 3 + TJ[t]];
           rec[18 + t] = U[t];
-          rec[27 + t] = Q[TI[t] * 3 + TJ[t]];
+          rec[27 + t] = W[TI[t] * 3 + TJ[t]];
           rec[36 + t] = Sd[TI[t] * 3 + TJ[t]];
-          rec[45 + t] = gs * G[t];
+          rec[45 + t] = gs * G[DXM_SYM(t / 3, t % 3)];
         }
       }
-      wave_lds_sync();
+      wave_lds_order();
 #pragma unroll 1
-      for (int st = 0; st < 2; ++st) {
+      for (int st = 0; st < F2_PPR / 7; ++st) {
         const int ql = st * 7 + ps;                              // point inside the round
         if (lane < 63 && ql < cnt) {
           const double* rec = coef + ql * F2_REC;
@@ -465,14 +511,14 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           for (int r = 0; r < 9; ++r) o[r * 9] = x[r];
         }
       }
-      wave_lds_sync();
+      wave_lds_order();
       {
         int nv = npts - p0;                                      // valid points of this round
         nv = nv < 0 ? 0 : (nv > cnt ? cnt : nv);
         const int nent = nv * 81;                                // wave-uniform
         double* gct = ct + (base + p0) * 81;                     // 16 B aligned: (base + p0) * 81 is even
         const double2_t* o2 = reinterpret_cast<const double2_t*>(outt);
-        constexpr int NIT = (F2_PPR * 81 + 2 * WAVE - 1) / (2 * WAVE);
+        constexpr int NIT = F2_NIT;
         double2_t v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) v[it] = o2[it * WAVE + lane];   // out-tile is padded to NIT KiB
@@ -488,10 +534,11 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           }
         }
       }
-      wave_lds_sync();
+      wave_lds_order();
     }
   }
-  store_block_stats(stats, c_plastic, c_notconv, c_nan, c_maxit, red);
+  // the workgroup reduction borrows the first words of every wave's own region (the tile loop is over)
+  store_block_stats(stats, c_plastic, c_notconv, c_nan, c_maxit, reinterpret_cast<unsigned long long*>(lds_all), F2_LDS_PER_WAVE);
 }
 
 }  // namespace dxm

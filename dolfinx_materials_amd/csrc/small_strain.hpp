@@ -75,7 +75,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
   __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * SS_LDS_PER_WAVE];
   __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
 
-  const int lane = threadIdx.x & (WAVE - 1);
+  int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x >> 6;
   double* stage = lds_all + wid * SS_LDS_PER_WAVE;
   double* coef = stage + SS_STAGE;
@@ -92,6 +92,12 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
        tile += tile_stride) {
     const int64_t base = tile * WAVE;
     const int npts = (n - base) < WAVE ? (int)(n - base) : WAVE;
+    if constexpr (LAW == LAW_J2_VOCE) {
+      // the lane index is re-read through an opaque copy once per tile: per-lane invariants hoisted out of the
+      // tile loop otherwise push the Voce kernels over their 128-register budget (2-8 spilled VGPRs)
+      asm volatile("" : "+v"(lane));
+      lane &= WAVE - 1;
+    }
     const bool valid = lane < npts;
     const int64_t gi = base + lane;
 
@@ -307,8 +313,10 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           const double ni = cf[3 + i], nj0 = cf[3 + j], nj1 = cf[4 + j];
           const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
           const double t1 = ((i < 3 && j + 1 < 3) ? k1 : 0.0) + ((i == j + 1) ? k2 : 0.0);
-          v.x = t0 + (k3 * ni) * nj0;
-          v.y = t1 + (k3 * ni) * nj1;
+          // k3 (ni nj), not (k3 ni) nj: the product ni nj commutes bit for bit, so the block is EXACTLY
+          // symmetric and the host path may rebuild it from its upper triangle (dxmat.hip: run_and_download)
+          v.x = t0 + k3 * (ni * nj0);
+          v.y = t1 + k3 * (ni * nj1);
         }
         return v;
       };
@@ -366,7 +374,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
             x = ((i < 3 && j < 3) ? lambda : 0.0) + ((i == j) ? 2.0 * mu : 0.0);
           } else {
             const double* cf = coef + (q < WAVE ? q : 0) * 9;
-            x = ((i < 3 && j < 3) ? cf[0] : 0.0) + ((i == j) ? cf[1] : 0.0) + (cf[2] * cf[3 + i]) * cf[3 + j];
+            x = (((i < 3 && j < 3) ? cf[0] : 0.0) + ((i == j) ? cf[1] : 0.0)) + cf[2] * (cf[3 + i] * cf[3 + j]);
           }
           v[u] = x;
         }

@@ -42,6 +42,56 @@ def _as_c(a, shape=None) -> np.ndarray:
     return a
 
 
+class LazyISV(np.lib.mixins.NDArrayOperatorsMixin):
+    """The ``isv`` array of ``integrate`` -- ``(N, sum isv)``, the ``_hcat_mixed`` of ``jaxmat.py:227-229`` --
+    fetched from the device on first use.  Internal state variables are consumed when an increment has
+    converged (``QuadratureMap.advance``, ``quadrature_map.py:350-360``), not in every Newton iteration, and
+    they are 56 of the 392 B/point the host-buffer form would otherwise bring back over PCIe per call.
+    Anything that looks at the values (``np.isnan(isv)``, ``isv[:, a:b]`` as in ``quadrature_map.py:323, :343-348``,
+    ``np.asarray(isv)``) triggers one download of the state the producing ``integrate`` wrote; after a later
+    ``integrate`` of the same material an un-fetched object raises instead of returning newer values."""
+
+    def __init__(self, material, shape, serial):
+        self._m, self.shape, self._serial = material, tuple(shape), serial
+        self._value = None
+        self.dtype = np.dtype(np.float64)
+        self.ndim = 2
+
+    def _get(self):
+        if self._value is None:
+            self._value = self._m._fetch_isv(self._serial)
+        return self._value
+
+    @property
+    def fetched(self):
+        return self._value is not None
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._get()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):   # isv - other, np.isnan(isv), ...
+        inputs = tuple(x._get() if isinstance(x, LazyISV) else x for x in inputs)
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __getitem__(self, idx):
+        return self._get()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getattr__(self, name):   # .any(), .copy(), .reshape(...), .T ...: whatever an ndarray offers
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._get(), name)
+
+    def __repr__(self):
+        return f"LazyISV(shape={self.shape}, fetched={self.fetched})"
+
+
 class DataManager:
     """``update`` / ``revert`` of ``generic.py:204-216`` and ``jaxmat.py:30-43``."""
 
@@ -72,19 +122,26 @@ class DataManager:
 class HIPMaterial:
     """A constitutive behaviour integrated on an MI355X through ``libdxmat.so``."""
 
-    def __init__(self, behavior, jit=True, device: int = 0, gradient_name=None, flux_name=None, tangent_layout="full"):
+    def __init__(self, behavior, jit=True, device: int = 0, gradient_name=None, flux_name=None, tangent_layout="full",
+                 lazy_isv=True):
         """``JAXMaterial(behavior, jit=True)`` (``jaxmat.py:144``): ``jit`` is accepted for signature
         compatibility and has no effect -- the kernels are compiled ahead of time (or, for a traced /
         custom hardening law, by hipcc on construction).
 
         ``tangent_layout="sym"`` (small-strain laws only) makes ``integrate`` return the 21
         upper-triangle entries per point, ``(N, 21)``, instead of the full ``(N, 6, 6)`` block the
-        reference's ``jacobian_flatten`` expects (``conventions.unpack_sym_tangent`` expands it)."""
+        reference's ``jacobian_flatten`` expects (``conventions.unpack_sym_tangent`` expands it).
+
+        ``lazy_isv=True``: the ``isv`` array ``integrate`` returns is a :class:`LazyISV`, downloaded when it
+        is first looked at; ``False`` downloads it in every call like the reference."""
         if tangent_layout not in ("full", "sym"):
             raise ValueError("tangent_layout must be 'full' or 'sym'")
         if not isinstance(jit, (bool, type(None))):
             raise TypeError("the second argument of JAXMaterial / HIPMaterial is `jit` (jaxmat.py:144); pass the GPU index as device=")
         self.jit = bool(jit)
+        self.lazy_isv = bool(lazy_isv)
+        self._serial = 0
+        self._bound = {}
         self.tangent_layout = tangent_layout
         self.behavior = behavior
         self.device = int(device)
@@ -243,6 +300,7 @@ class HIPMaterial:
         if getattr(self, "_handle", None):
             self._lib.dxm_destroy(self._handle)
             self._handle = None
+        self._unbind()
         for p in getattr(self, "_pinned", []):
             p.release()
         self._pinned = []
@@ -323,7 +381,8 @@ class HIPMaterial:
     def _advance(self):
         self._chk(self._lib.dxm_advance(self._require()))
         self._grad[0] = self._grad[1]
-        self._flux[0] = self._flux[1]
+        # a bound flux array is overwritten by the next integrate: the s0 mirror keeps its own copy then
+        self._flux[0] = self._flux[1].copy() if "flux" in self._bound else self._flux[1]
 
     def _revert(self):
         self._chk(self._lib.dxm_revert(self._require()))
@@ -354,9 +413,10 @@ class HIPMaterial:
             st = Stats()
         timer_name = "jaxmat: Constitutive update" if self._warm else "jaxmat: First pass (includes jit compilation)"
         self._warm = True
+        eager = not self.lazy_isv
         with _Timer(timer_name):
             rc = self._lib.dxm_integrate(
-                h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)
+                h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv) if eager else None, _ptr(self._out_ct), C.byref(st)
             )
         with _Timer("jaxmat: jaxmat to dolfinx conversion"):
             self._chk(rc)
@@ -367,11 +427,23 @@ class HIPMaterial:
                 )
             self._grad[1] = g
             self._flux[1] = flux
-        return flux, self._out_isv, self._out_ct
+            self._serial += 1
+            isv = self._out_isv if eager else LazyISV(self, self._out_isv.shape, self._serial)
+        return flux, isv, self._out_ct
+
+    def _fetch_isv(self, serial):
+        """Download the ISVs of s1 for the :class:`LazyISV` of integrate call number ``serial``."""
+        if serial != self._serial:
+            raise DxmError("this isv array belongs to an earlier integrate() of the material and was never read; "
+                           "read it before the next integrate(), or construct the material with lazy_isv=False")
+        self._chk(self._lib.dxm_isv_host(self._require(), S1, _ptr(self._out_isv)))
+        return self._out_isv
 
     def _next_flux_buffer(self):
         """Two pinned flux buffers alternate so that the s0 mirror (the flux of the last converged
         increment) is never the one being overwritten."""
+        if len(self._flux_buf) == 1:   # bound output array
+            return self._flux_buf[0]
         cand = self._flux_buf[self._flux_next]
         if cand is self._flux[0]:
             self._flux_next ^= 1
@@ -391,15 +463,17 @@ class HIPMaterial:
             raise ValueError(f"u must have {3 * mesh.n_nodes} entries, got {u.size}")
         flux = self._next_flux_buffer()
         st = Stats()
+        eager = not self.lazy_isv
         rc = self._lib.dxm_integrate_displacement(
-            h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(self._out_isv), _ptr(self._out_ct), C.byref(st)
+            h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(self._out_isv) if eager else None, _ptr(self._out_ct), C.byref(st)
         )
         self._chk(rc)
         self.last_stats = st.as_dict()
         if rc > 0:
             warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
         self._flux[1] = flux
-        return flux, self._out_isv, self._out_ct
+        self._serial += 1
+        return flux, (self._out_isv if eager else LazyISV(self, self._out_isv.shape, self._serial)), self._out_ct
 
     def integrate_device(self, grad_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
         """Device-pointer form: asynchronous launch on ``stream`` (a ``hipStream_t`` value, e.g.
@@ -429,6 +503,48 @@ class HIPMaterial:
         self._chk(self._lib.dxm_tune_placement(self._require(), int(grad_ptr), int(flux_ptr), int(ct_ptr),
                                                int(max_candidates), C.byref(before), C.byref(after), C.byref(tried)))
         return {"ms_before": before.value, "ms_after": after.value, "candidates_tried": tried.value}
+
+    @property
+    def launch_generation(self):
+        """``dxm_launch_generation``: a HIP graph that captured ``integrate_device`` /
+        ``integrate_displacement_device`` of this material may be replayed only while this value equals the
+        one read at capture time (``data_manager.update()`` swaps the state buffers, parameter / option
+        changes and ``tune_placement`` re-configure the launch)."""
+        return int(self._lib.dxm_launch_generation(self._require()))
+
+    def set_option(self, name, value):
+        """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"sym_transfer"``, ``"host_threads"``,
+        ``"max_chunks"``, ``"fused_gradient"``, ``"blocks_per_cu"``, ``"tune_verbose"``)."""
+        self._chk(self._lib.dxm_set_option(self._require(), name.encode(), float(value)))
+
+    def bind_outputs(self, flux=None, tangent=None):
+        """Deliver ``integrate`` results straight into caller-owned arrays -- e.g. the ``x.array`` of the flux and
+        ``jacobian_flatten`` quadrature Functions, which is what ``QuadratureMap.update`` scatters into
+        (``quadrature_map.py:331-334``, ``utils.py:136-143``; an identity scatter when the map covers all cells).
+        The arrays are page-locked in place (``dxm_host_register``) and become the arrays ``integrate``
+        returns; call after ``set_data_manager``.  ``None`` keeps the material-owned buffer."""
+        self._require()
+        nf, ng = self._info.n_flux, self._info.n_grad
+        want = {"flux": (flux, self._n * nf), "tangent": (tangent, self._out_ct.size)}
+        for key, (arr, size) in want.items():
+            if arr is None:
+                continue
+            if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size == size):
+                raise ValueError(f"{key} must be a C-contiguous float64 array with {size} entries")
+            self._unbind(key)
+            if arr.nbytes:
+                self._chk(self._lib.dxm_host_register(_ptr(arr), arr.nbytes))
+            self._bound[key] = arr
+        if "flux" in self._bound:
+            self._flux_buf = [self._bound["flux"].reshape(self._n, nf)]
+        if "tangent" in self._bound:
+            self._out_ct = self._bound["tangent"].reshape(self._out_ct.shape)
+
+    def _unbind(self, key=None):
+        for k in ([key] if key else list(self._bound)):
+            arr = self._bound.pop(k, None)
+            if arr is not None and arr.nbytes:
+                self._lib.dxm_host_unregister(_ptr(arr))
 
     def isv_device(self, which, isv_ptr, stream=0):
         self._chk(self._lib.dxm_isv_device(self._require(), which, int(isv_ptr), int(stream) or None))

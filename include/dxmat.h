@@ -24,6 +24,10 @@
  *     (dolfinx_materials/quadrature_map.py:83-105, :334);
  *   - int return codes: 0 = ok, > 0 = number of points whose local Newton did not converge,
  *     < 0 = hard error (message from dxm_last_error());
+ *   - HIP graphs: the device-pointer entry points are capturable.  A captured launch bakes in the two
+ *     state buffers (advance() swaps them on the host) and the parameters, so a graph is valid only while
+ *     dxm_launch_generation() returns the value it had at capture time; the value comes back when the
+ *     buffers swap back (two graphs, captured at consecutive increments, serve a whole load history);
  *   - one handle per (material, device); a handle is not thread-safe (the reference calls the path
  *     from the PETSc SNES callback on one thread: dolfinx_materials/solvers.py:72); successive
  *     device-pointer launches on one handle must be ordered on the same HIP stream (advance()
@@ -40,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DXM_ABI_VERSION 1
+#define DXM_ABI_VERSION 2
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
 enum {
@@ -144,7 +148,8 @@ int dxm_revert(dxm_material* m);
  *      consumer quadrature_map.py:321) ------------------------------------------------------ */
 /* Host-buffer form (what QuadratureMap hands over): grad_aos (npoints, n_grad) in host memory;
  * writes flux_aos (npoints, n_flux), isv_aos (npoints, n_isv_total) and ct_aos
- * (npoints, n_flux*n_grad) to host memory (any of the three may be NULL to skip its download).
+ * (npoints, n_flux*n_grad) to host memory (any of the three may be NULL to skip its download; the ISVs
+ * are only needed at advance() and can be fetched later with dxm_isv_host).
  * Reads state s0, writes state s1.  Synchronous.  `stats` may be NULL. */
 int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
                   double* isv_aos, double* ct_aos, dxm_stats* stats);
@@ -170,13 +175,36 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
  * The first half of the candidates are consecutive allocations, the second half jump ahead by skip
  * blocks of 1, 2, 4 ... 16 GiB (fast regions can be tens of GB apart); everything but the winner is
  * freed before returning; at most half of the free device memory is held meanwhile.  10 ms to a few
- * seconds.  DXM_TUNE_VERBOSE=1 logs every candidate to stderr.  No-op for laws without state.
+ * seconds.  Option "tune_verbose" logs every candidate to stderr.  No-op for laws without state.
  * ms_before / ms_after: kernel time (ms) on the initial / chosen placement; n_tried: candidates
  * measured (any may be NULL).  No counterpart in the reference (its state lives in jax arrays). */
 int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
                        int max_candidates, double* ms_before, double* ms_after, int* n_tried);
 /* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
 const char* dxm_kernel_name(const dxm_material* m);
+/* Identity of the launch configuration: changes whenever a launch captured into a HIP graph before would
+ * no longer do what a fresh call does -- dxm_advance (the two state buffers swap: the low bit flips and
+ * flips back at the next advance), dxm_set_params / dxm_set_newton / dxm_set_tangent_layout /
+ * dxm_set_option / dxm_tune_placement (the upper bits increase).  Replay a captured graph only while the
+ * value equals the one read at capture time.  dxm_revert does not change it. */
+uint64_t dxm_launch_generation(const dxm_material* m);
+/* Per-handle options (no environment variables are read by the library):
+ *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on two streams (default 1)
+ *   "max_chunks"     1..16   upper bound on the chunks of that pipeline (default 16)
+ *   "sym_transfer"   1 | 0   host-buffer form, small-strain laws, full tangent layout: move the symmetric
+ *                            tangent packed (168 instead of 288 B/point) and rebuild the (N,6,6) block on the
+ *                            host, bit-identical (default 1)
+ *   "host_threads"   1..256  worker threads of that rebuild (default 8)
+ *   "fused_gradient" 1 | 0   displacement forms: evaluate the gradient inside the update kernel where the mesh
+ *                            allows (default 1)
+ *   "blocks_per_cu"  1..256  grid size of the update kernel in workgroups per CU (default 32 small strain,
+ *                            the resident 2 for FeFp)
+ *   "tune_verbose"   1 | 0   dxm_tune_placement logs every candidate to stderr (default 0) */
+int dxm_set_option(dxm_material* m, const char* name, double value);
+/* get_initial_state_dict / get_final_state_dict without a device array of the caller: packs the
+ * user-visible ISVs of state `which` and downloads them into host memory (npoints, n_isv_total).  This is
+ * how the Python layer serves the `isv` array of integrate() on first access (jaxmat.py:227-229). */
+int dxm_isv_host(dxm_material* m, int which, double* isv_aos);
 
 /* ---- pinned host memory for the host-buffer form --------------------------------------------
  * integrate() returns arrays owned by the material (the reference returns views of its state
@@ -184,6 +212,11 @@ const char* dxm_kernel_name(const dxm_material* m);
  * rate without the runtime's staging copy.  Returns NULL on failure. */
 void* dxm_host_alloc(uint64_t bytes);
 int dxm_host_free(void* p);
+/* Page-lock an existing host range in place (e.g. the `x.array` of the dolfinx quadrature Functions that
+ * QuadratureMap.update scatters into, quadrature_map.py:331-334, utils.py:136-143), so that integrate()
+ * can deliver straight into it at full PCIe rate; undo with dxm_host_unregister before the memory is freed. */
+int dxm_host_register(void* p, uint64_t bytes);
+int dxm_host_unregister(void* p);
 
 /* ---- gradient evaluation on device (the step before the path; first-order hexahedra and tetrahedra) --
  * Replaces, for the device-resident flow, QuadratureExpression.eval -> fem.Expression.eval

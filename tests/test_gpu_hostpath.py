@@ -1,0 +1,185 @@
+"""The host-buffer form (what ``QuadratureMap.update`` hands over, ``quadrature_map.py:297-334``): packed
+transfer of the symmetric tangent with the full block rebuilt on the host, internal state variables on
+demand, results delivered into caller-owned (page-locked in place) arrays, options instead of environment
+variables, and the launch-generation contract for HIP graphs."""
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from dolfinx_materials_amd import _lib
+from dolfinx_materials_amd.hip_material import LazyISV
+from dolfinx_materials_amd.jaxmat import JAXMaterial
+from oracle import constitutive_np as onp
+
+from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, j2_history
+
+pytestmark = pytest.mark.gpu
+
+
+def _j2(kind="linear", **kw):
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    hard = jm.LinearHardening(SIG0_LIN, H_LIN) if kind == "linear" else jm.VoceHardening(SIG0_V, SIGU_V, B_V)
+    return JAXMaterial(jm.vonMisesIsotropicHardening(el, hard), **kw)
+
+
+@pytest.mark.parametrize("n", [1, 255, 300_001, 2_200_000])
+def test_packed_tangent_transfer_is_bit_identical_to_the_full_download(n):
+    """2.2e6 points = 16 chunks on two streams with 8 expansion threads behind them; 300001 = ragged chunks."""
+    a, b = _j2(), _j2()
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    b.set_option("sym_transfer", 0)   # moves the full 36-entry block over PCIe, as in round 1
+    for eps in j2_history(n, seed=5)[:3]:
+        fa, ia, ca = a.integrate(eps)
+        fb, ib, cb = b.integrate(eps)
+        assert ca.shape == (n, 6, 6) and np.array_equal(fa, fb) and np.array_equal(ca, cb)
+        assert np.array_equal(ca, ca.transpose(0, 2, 1)) and np.array_equal(np.asarray(ia), np.asarray(ib))
+        assert a.last_stats == b.last_stats
+        a.data_manager.update()
+        b.data_manager.update()
+    ref = onp.j2_update(j2_history(n, seed=5)[0], np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
+    c = _j2()
+    c.set_data_manager(n)
+    c.set_option("host_threads", 3)
+    c.set_option("max_chunks", 5)
+    ct = c.integrate(j2_history(n, seed=5)[0])[2]
+    safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_LIN
+    assert np.abs(ct[safe] - ref["Ct"][safe]).max() <= 1e-12 * np.abs(ref["Ct"]).max()
+
+
+def test_isv_is_fetched_on_demand_and_equals_the_eager_download():
+    n = 40_000
+    lazy, eager = _j2("voce"), _j2("voce", lazy_isv=False)
+    lazy.set_data_manager(n)
+    eager.set_data_manager(n)
+    h = j2_history(n, sig0=SIG0_V)
+    for eps in h[:2]:
+        _, il, _ = lazy.integrate(eps)
+        _, ie, _ = eager.integrate(eps)
+        assert isinstance(il, LazyISV) and not il.fetched and isinstance(ie, np.ndarray) and il.shape == ie.shape == (n, 7)
+        assert not np.isnan(il).any() and il.fetched            # quadrature_map.py:323
+        assert np.array_equal(il[:, 0:1], ie[:, 0:1]) and np.array_equal(il[:, 1:7], ie[:, 1:7])   # quadrature_map.py:343-348
+        assert np.array_equal(np.asarray(il), ie) and np.abs(il - ie).max() == 0.0 and il.max() == ie.max()
+        lazy.data_manager.update()
+        eager.data_manager.update()
+    # never looked at: the state dicts still serve the values (quadrature_map.py:355-360) ...
+    _, il, _ = lazy.integrate(h[2])
+    _, ie, _ = eager.integrate(h[2])
+    lazy.data_manager.update()
+    assert np.array_equal(lazy.get_final_state_dict()["p"][:, 0], ie[:, 0])
+    # ... and an un-fetched array of an older call refuses to return newer values
+    _, il_old, _ = lazy.integrate(h[3])
+    lazy.integrate(h[3] * 0.9)
+    with pytest.raises(_lib.DxmError, match="earlier integrate"):
+        np.asarray(il_old)
+
+
+def test_results_are_delivered_into_bound_caller_arrays():
+    n = 70_000
+    ref_m, m = _j2(), _j2()
+    ref_m.set_data_manager(n)
+    m.set_data_manager(n)
+    flux_fn = np.full(n * 6, np.nan)      # the x.array of the flux Function
+    jac_fn = np.full(n * 36, np.nan)      # the x.array of jacobian_flatten (quadrature_map.py:83-105)
+    m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+    h = j2_history(n, seed=9)
+    for eps in h[:3]:
+        f0, _, c0 = ref_m.integrate(eps)
+        f1, _, c1 = m.integrate(eps)
+        assert np.shares_memory(f1, flux_fn) and np.shares_memory(c1, jac_fn)
+        assert np.array_equal(flux_fn.reshape(n, 6), f0) and np.array_equal(jac_fn.reshape(n, 6, 6), c0)
+        s0_flux = m.get_initial_state_dict()["stress"].copy()
+        ref_m.data_manager.update()
+        m.data_manager.update()
+        assert np.array_equal(m.get_initial_state_dict()["stress"], f0)   # the s0 mirror is the converged flux ...
+    m.integrate(h[3])
+    assert np.array_equal(m.get_initial_state_dict()["stress"], f0)       # ... and survives the next integrate
+    with pytest.raises(ValueError):
+        m.bind_outputs(flux=np.zeros(5))
+    m.close()
+    flux_fn[:] = 0.0   # unregistered again: ordinary memory
+
+
+def test_options_replace_environment_variables():
+    m = _j2()
+    m.set_data_manager(1000)
+    g0 = m.launch_generation
+    for name, value in (("pipeline", 0), ("sym_transfer", 0), ("host_threads", 2), ("max_chunks", 4), ("fused_gradient", 0),
+                        ("blocks_per_cu", 8), ("tune_verbose", 0)):
+        m.set_option(name, value)
+    assert m.launch_generation > g0
+    sig = m.integrate(j2_history(1000)[2])[0].copy()
+    m.set_option("blocks_per_cu", 32)
+    assert np.array_equal(m.integrate(j2_history(1000)[2])[0], sig)
+    for name, value in (("no_such_option", 1), ("host_threads", 0), ("max_chunks", 99), ("blocks_per_cu", 1e6)):
+        with pytest.raises(_lib.DxmError):
+            m.set_option(name, value)
+
+
+def test_launch_generation_tells_when_a_captured_graph_is_stale():
+    """A captured dxm_integrate_device bakes in the two state buffers and the parameters: advance() swaps the
+    buffers (the generation's low bit flips and comes back at the next advance), parameter changes bump it."""
+    torch = pytest.importorskip("torch")
+    n = 30_000
+    dev = torch.device("cuda:0")
+    m = _j2()
+    m.set_data_manager(n)
+    h = j2_history(n, seed=21)
+    g = [torch.from_numpy(x).to(dev) for x in h]
+    f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
+    st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+    gin = torch.empty_like(g[0])
+
+    def capture():
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            m.integrate_device(gin.data_ptr(), f.data_ptr(), c.data_ptr(), st())
+        return gr, m.launch_generation
+
+    graphs = {}
+    hard = onp.LinearHardening(SIG0_LIN, H_LIN)
+    epsp, p = np.zeros((n, 6)), np.zeros(n)
+    for k in range(4):
+        gen = m.launch_generation
+        if gen not in graphs:                      # at most two captures serve the whole history
+            graphs[gen] = capture()[0]
+        gin.copy_(g[k])
+        graphs[gen].replay()
+        torch.cuda.synchronize()
+        rc, stats = m.stats()                      # the last launch went into a capture: falls back to a device sync
+        ref = onp.j2_update(h[k], epsp, p, E, NU, hard)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_LIN
+        assert np.abs(f.cpu().numpy()[safe] - ref["sig"][safe]).max() <= 1e-12 * np.abs(ref["sig"]).max()
+        assert np.abs(c.cpu().numpy().reshape(n, 6, 6)[safe] - ref["Ct"][safe]).max() <= 1e-12 * np.abs(ref["Ct"]).max()
+        epsp, p = ref["epsp"], ref["p"]
+        m.data_manager.update()
+        assert m.launch_generation != gen and (m.launch_generation ^ gen) == 1
+    assert len(graphs) == 2
+    gen = m.launch_generation
+    m.data_manager.revert()
+    assert m.launch_generation == gen              # revert does not move the buffers
+    m.update_material_property("yield_stress.H", 6e3)
+    assert m.launch_generation not in graphs       # a stale graph would integrate with the old hardening modulus
+
+
+def test_stats_after_the_launch_stream_is_gone():
+    """The handle waits on its own event, not on the caller's stream handle (which may have been destroyed)."""
+    torch = pytest.importorskip("torch")
+    n = 20_000
+    dev = torch.device("cuda:0")
+    m = _j2()
+    m.set_data_manager(n)
+    g = torch.from_numpy(j2_history(n)[2]).to(dev)
+    f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        m.integrate_device(g.data_ptr(), f.data_ptr(), c.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    del side
+    import gc
+
+    gc.collect()
+    rc, stats = m.stats()
+    assert rc == 0 and stats["n_plastic"] > 0 and m.get_final_state_dict()["p"].max() > 0

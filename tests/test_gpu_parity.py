@@ -191,13 +191,25 @@ def test_symmetric_packed_tangent_equals_upper_triangle_of_full(kind, n):
     full, sym = JAXMaterial(beh), JAXMaterial(beh, tangent_layout="sym")
     full.set_data_manager(n)
     sym.set_data_manager(n)
+    hard = None if kind == "elastic" else (onp.LinearHardening(SIG0_LIN, H_LIN) if kind == "linear" else onp.VoceHardening(SIG0_V, SIGU_V, B_V))
+    epsp, p = np.zeros((n, 6)), np.zeros(n)
     for eps in j2_history(n, seed=31, sig0=sig0)[:3]:
         sf, isvf, cf = full.integrate(eps)
         ss, isvs, cs = sym.integrate(eps)
         assert cs.shape == (n, 21)
         assert np.array_equal(sf, ss) and np.array_equal(isvf, isvs)
         assert np.array_equal(cs, pack_sym_tangent(cf))
-        assert np.abs(unpack_sym_tangent(cs) - cf).max() < 1e-9
+        assert np.array_equal(unpack_sym_tangent(cs), cf)   # the full block is exactly symmetric
+        # ... and both are the oracle's tangent (the packed layout is checked against the CPU restatement, not
+        # only against the other HIP kernel)
+        if hard is None:
+            ref_ct = np.broadcast_to(onp.elastic_matrix(E, NU), (n, 6, 6))
+            safe = np.ones(n, dtype=bool)
+        else:
+            ref = onp.j2_update(eps, epsp, p, E, NU, hard)
+            ref_ct, safe = ref["Ct"], np.abs(ref["f_trial"]) > 1e-9 * sig0
+            epsp, p = ref["epsp"], ref["p"]
+        assert np.abs(unpack_sym_tangent(cs)[safe] - ref_ct[safe]).max() <= 1e-12 * np.abs(ref_ct).max()
         full.data_manager.update()
         sym.data_manager.update()
 
