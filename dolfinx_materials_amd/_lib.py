@@ -87,6 +87,7 @@ SYMBOLS = {
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dxm_kernel_name": (C.c_char_p, [_h]),
     "dxm_launch_generation": (C.c_uint64, [_h]),
+    "dxm_notify_replay": (C.c_int, [_h]),
     "dxm_set_option": (C.c_int, [_h, C.c_char_p, C.c_double]),
     "dxm_isv_host": (C.c_int, [_h, C.c_int, C.c_void_p]),
     "dxm_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),

@@ -109,32 +109,48 @@ static int isv_total(const LawDesc& d) {
 // ------------------------------------------------------------------------------------------
 // host side of the host-buffer form: symmetric-packed tangent -> full 6x6 block
 // ------------------------------------------------------------------------------------------
-// The small-strain tangent is symmetric, so the host-buffer form moves only its 21 upper-triangle
-// entries over PCIe (168 instead of 288 B/point of the 392 B/point coming back) and rebuilds the
-// (N, 6, 6) block the reference's jacobian_flatten expects (quadrature_map.py:83-105, :334) on the
-// host, chunk by chunk on a few worker threads while the next chunks are still in flight.  The full
-// and the packed kernels evaluate every entry with the same expression, so the result is bit-identical
-// to the full-tangent download.
-static void expand_sym_tangent(const double* __restrict__ s, double* __restrict__ d, int64_t n) {
-  // upper triangle, row-major: row 0 -> 0..5, row 1 -> 6..10, row 2 -> 11..14, row 3 -> 15..17, row 4 -> 18..19, row 5 -> 20
-  static const int T[36] = {0, 1, 2, 3, 4, 5,  1, 6, 7, 8, 9, 10,  2, 7, 11, 12, 13, 14,
-                            3, 8, 12, 15, 16, 17,  4, 9, 13, 16, 18, 19,  5, 10, 14, 17, 19, 20};
+// The small-strain tangent is Ct = c1 1x1 + c2 I + c3 n x n: nine numbers per point.  The host-buffer form
+// moves those (72 instead of 288 B/point of the 392 B/point that used to come back over PCIe) and
+// rebuilds the (N, 6, 6) block the reference's jacobian_flatten expects (quadrature_map.py:83-105, :334)
+// on the host, chunk by chunk on a few worker threads while the next chunks are still in flight.  The
+// expression is the kernel's own (small_strain.hpp, step 7: t0 + k3 (ni nj) as one fused multiply-add), so
+// the block is bit-identical to the one the full-tangent kernel writes.  For the elastic law the block
+// is a constant and nothing is moved at all.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("fma")))
+#endif
+static void expand_coef_tangent(const double* __restrict__ s, double* __restrict__ d, int64_t n) {
   const bool aligned = (reinterpret_cast<uintptr_t>(d) & 15) == 0;
-  for (int64_t p = 0; p < n; ++p, s += 21, d += 36) {
-    if (aligned) {   // streaming stores: the block is not read again by these threads
-      for (int k = 0; k < 36; k += 2) {
-        const double2_t v = {s[T[k]], s[T[k + 1]]};
-        __builtin_nontemporal_store(v, reinterpret_cast<double2_t*>(d + k));
+  for (int64_t p = 0; p < n; ++p, s += 9, d += 36) {
+    const double k1 = s[0], k2 = s[1], k3 = s[2];
+    const double* nv = s + 3;
+    double o[36];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
+        o[i * 6 + j] = __builtin_fma(k3, nv[i] * nv[j], t0);
       }
+    if (aligned) {   // streaming stores: the block is not read again by these threads
+      for (int k = 0; k < 36; k += 2)
+        __builtin_nontemporal_store(double2_t{o[k], o[k + 1]}, reinterpret_cast<double2_t*>(d + k));
     } else {
-      for (int k = 0; k < 36; ++k) d[k] = s[T[k]];
+      for (int k = 0; k < 36; ++k) d[k] = o[k];
     }
   }
 }
 
+// elastic law: the same constant block for every point
+static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, double* __restrict__ d, int64_t n) {
+  double o[36];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) o[i * 6 + j] = ((i < 3 && j < 3) ? s[0] : 0.0) + ((i == j) ? 2.0 * s[1] : 0.0);
+  for (int64_t p = 0; p < n; ++p, d += 36)
+    for (int k = 0; k < 36; ++k) d[k] = o[k];
+}
+
 // A few persistent worker threads per handle (created on the first host-path call that needs them).
 struct HostPool {
-  struct Job { const double* src; double* dst; int64_t n; };
+  struct Job { const double* src; double* dst; int64_t n; int stride; };   // stride 9: coefficients, 0: constant
   std::vector<std::thread> threads;
   std::mutex mu;
   std::condition_variable cv, cv_done;
@@ -159,7 +175,8 @@ struct HostPool {
         j = queue.front();
         queue.pop_front();
       }
-      expand_sym_tangent(j.src, j.dst, j.n);
+      if (j.stride) expand_coef_tangent(j.src, j.dst, j.n);
+      else fill_const_tangent(j.src, j.dst, j.n);
       {
         std::lock_guard<std::mutex> lk(mu);
         if (--pending == 0) cv_done.notify_all();
@@ -167,12 +184,12 @@ struct HostPool {
     }
   }
   // rows [0, n) of one chunk, cut into one piece per thread
-  void submit(const double* src, double* dst, int64_t n) {
+  void submit(const double* src, double* dst, int64_t n, int stride) {
     const int64_t pieces = (int64_t)threads.size();
     const int64_t per = (n + pieces - 1) / pieces;
     std::lock_guard<std::mutex> lk(mu);
     for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * 21, dst + o * 36, std::min(per, n - o)});
+      queue.push_back(Job{src + o * stride, dst + o * 36, std::min(per, n - o), stride});
       ++pending;
     }
     cv.notify_all();
@@ -186,7 +203,7 @@ struct HostPool {
 // ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
-constexpr int DXM_MAX_CHUNKS = 16;
+constexpr int DXM_MAX_CHUNKS = 64;
 
 struct dxm_material {
   int law = 0;
@@ -217,14 +234,15 @@ struct dxm_material {
   int parity = 0;
   // options (dxm_set_option)
   bool opt_pipeline = true;               // chunk-pipelined host path
-  bool opt_sym_transfer = true;           // host path: move the symmetric tangent packed, expand on the host
+  bool opt_packed_transfer = true;        // host path: move the 9 tangent coefficients, rebuild the 6x6 block on the host
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
   bool opt_tune_verbose = false;
-  int opt_host_threads = 8;
+  int opt_host_threads = 16;
   int opt_max_chunks = DXM_MAX_CHUNKS;
   HostPool* pool = nullptr;
-  double* h_ct21 = nullptr;               // page-locked (n, 21) landing area of the packed tangent
+  double* h_coef = nullptr;               // page-locked (n, 9) landing area of the tangent coefficients
+  double elastic_lm[2] = {0.0, 0.0};      // lambda, mu handed to the constant-block fill
   hipEvent_t chunk_done[DXM_MAX_CHUNKS] = {};
   int num_cu = 256;
   int blocks_per_cu = 5;
@@ -429,9 +447,9 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
     int occ = 0;
     const void* fn = nullptr;
     switch (law) {
-      case DXM_LAW_ELASTIC_ISO: fn = (const void*)small_strain_kernel<LAW_ELASTIC, false>; break;
-      case DXM_LAW_J2_LINEAR: fn = (const void*)small_strain_kernel<LAW_J2_LINEAR, false>; break;
-      case DXM_LAW_J2_VOCE: fn = (const void*)small_strain_kernel<LAW_J2_VOCE, false>; break;
+      case DXM_LAW_ELASTIC_ISO: fn = (const void*)small_strain_kernel<LAW_ELASTIC, TL_FULL>; break;
+      case DXM_LAW_J2_LINEAR: fn = (const void*)small_strain_kernel<LAW_J2_LINEAR, TL_FULL>; break;
+      case DXM_LAW_J2_VOCE: fn = (const void*)small_strain_kernel<LAW_J2_VOCE, TL_FULL>; break;
       case DXM_LAW_FEFP_J2_LINEAR: fn = (const void*)fefp_kernel<0, 0>; break;
       default: fn = (const void*)fefp_kernel<1, 0>; break;
     }
@@ -465,7 +483,7 @@ int dxm_destroy(dxm_material* m) {
   DeviceGuard guard(m->device);
   (void)sync_last(m);
   delete m->pool;
-  if (m->h_ct21) (void)hipHostFree(m->h_ct21);
+  if (m->h_coef) (void)hipHostFree(m->h_coef);
   for (hipEvent_t e : m->chunk_done) if (e) (void)hipEventDestroy(e);
   if (m->last_event) (void)hipEventDestroy(m->last_event);
   if (m->state_base) (void)hipFree(m->state_base);
@@ -626,33 +644,29 @@ int dxm_revert(dxm_material* m) {
 template <int LAW>
 static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64_t off, int64_t cnt,
                                 const double* grad, double* flux, double* ct, int stats_off,
-                                const MeshSource* fused, bool sym) {
+                                const MeshSource* fused, int tl) {
   const double* s0 = m->state[0] + off;
   double* s1 = m->state[1] + off;
   BlockStats* bs = m->d_stats + stats_off;
-  if (fused) {   // strain evaluated in the kernel from the displacement vector
-#define DXM_LAUNCH_SS(SYM, G)                                                                              \
-  hipLaunchKernelGGL((small_strain_kernel<LAW, SYM, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, \
-                     m->ld, flux, ct, bs, *fused)
-    if (fused->kind == 1) { if (sym) DXM_LAUNCH_SS(true, 1); else DXM_LAUNCH_SS(false, 1); }
-    else                  { if (sym) DXM_LAUNCH_SS(true, 2); else DXM_LAUNCH_SS(false, 2); }
-#undef DXM_LAUNCH_SS
-    return;
-  }
   const MeshSource none{};
-  if (sym)
-    hipLaunchKernelGGL((small_strain_kernel<LAW, true, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
-                       grad, s0, s1, m->ld, flux, ct, bs, none);
-  else
-    hipLaunchKernelGGL((small_strain_kernel<LAW, false, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt,
-                       grad, s0, s1, m->ld, flux, ct, bs, none);
+  const MeshSource& src = fused ? *fused : none;
+  const int g = fused ? (fused->kind == 1 ? 1 : 2) : 0;   // where the strain comes from: array / hex8 x 8 / tet4
+#define DXM_LAUNCH_SS(TL, G)                                                                              \
+  hipLaunchKernelGGL((small_strain_kernel<LAW, TL, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, \
+                     m->ld, flux, ct, bs, src)
+#define DXM_LAUNCH_SS_G(TL) do { if (g == 0) DXM_LAUNCH_SS(TL, 0); else if (g == 1) DXM_LAUNCH_SS(TL, 1); else DXM_LAUNCH_SS(TL, 2); } while (0)
+  if (tl == TL_SYM) DXM_LAUNCH_SS_G(TL_SYM);
+  else if (tl == TL_FULL) DXM_LAUNCH_SS_G(TL_FULL);
+  else if constexpr (LAW != LAW_ELASTIC) DXM_LAUNCH_SS_G(TL_COEF);
+#undef DXM_LAUNCH_SS_G
+#undef DXM_LAUNCH_SS
 }
 
-// sym: tangent layout of THIS launch (the host path may ask for the packed form although the handle's
-// layout is the full block: it expands on the host)
+// tl: tangent layout of THIS launch (the host path may ask for the coefficient form although the handle's
+// layout is the full block: it rebuilds the block on the host)
 static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double* grad, double* flux,
                         double* ct, hipStream_t st, int stats_off, int* grid_out,
-                        const MeshSource* fused, bool sym) {
+                        const MeshSource* fused, int tl) {
   if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
     return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
   const int64_t ntiles = (cnt + WAVE - 1) / WAVE;
@@ -662,9 +676,9 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
   if (stats_off + blocks > m->stats_capacity) return fail(-1, "internal: stats buffer too small");
   const int grid = (int)blocks;
   switch (m->law) {
-    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, sym); break;
-    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, sym); break;
-    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, sym); break;
+    case DXM_LAW_ELASTIC_ISO: launch_small_strain<LAW_ELASTIC>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, tl); break;
+    case DXM_LAW_J2_LINEAR: launch_small_strain<LAW_J2_LINEAR>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, tl); break;
+    case DXM_LAW_J2_VOCE: launch_small_strain<LAW_J2_VOCE>(m, grid, st, off, cnt, grad, flux, ct, stats_off, fused, tl); break;
     case DXM_LAW_FEFP_J2_VOCE:
     case DXM_LAW_FEFP_J2_LINEAR: {
       const double* s0 = m->state[0] + off;
@@ -694,7 +708,7 @@ static int launch(dxm_material* m, const double* grad, double* flux, double* ct,
                   const MeshSource* fused = nullptr) {
   if (m->n == 0) { m->last_grid = 0; return 0; }
   int grid = 0;
-  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused, m->sym_tangent)) return rc;
+  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused, m->sym_tangent ? TL_SYM : TL_FULL)) return rc;
   m->last_grid = grid;
   m->launched = true;
   m->s1_alias = false;  // the kernel rewrites every slot of s1
@@ -894,7 +908,7 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 
 // Host-buffer form, shared by dxm_integrate and dxm_integrate_displacement.
 //   upload(off, cnt, stream) enqueues whatever produces m->d_grad[off .. off+cnt) on `stream`.
-// Large batches are cut into up to 16 chunks (multiples of 256 points) issued on two alternating
+// Large batches are cut into up to 64 chunks (multiples of 256 points) issued on two alternating
 // streams: the H2D and the kernel of chunk c+1 overlap the D2H of chunk c (PCIe is full duplex and the
 // bytes coming back dominate).  Each chunk is one launch over a point range; its block-stat records
 // are appended after the previous chunk's.
@@ -902,28 +916,35 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 // What crosses PCIe on the way back, per point: the flux (48 / 72 B), the tangent, and -- only when the
 // caller passes a destination -- the internal state variables (they are consumed at advance(), not per
 // Newton iteration: the Python layer fetches them on demand).  For the small-strain laws with the full
-// (N, 6, 6) tangent requested, the kernel writes the symmetric-packed form, 168 instead of 288 B/point
-// are moved into a page-locked landing area and worker threads rebuild the full block in the caller's
-// array chunk by chunk, behind the transfer of the following chunks (bit-identical to the full kernel).
+// (N, 6, 6) tangent requested, the kernel writes the 9 coefficients of the tangent instead of its 36
+// entries, 72 instead of 288 B/point are moved into a page-locked landing area and worker threads rebuild
+// the block in the caller's array chunk by chunk, behind the transfer of the following chunks
+// (bit-identical to the full kernel; the elastic block is a constant and is only filled in).
 template <class Upload>
 static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
                             double* ct_aos, dxm_stats* stats, const MeshSource* fused = nullptr) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  const bool packed = m->opt_sym_transfer && !m->sym_tangent && d.n_grad == 6 && ct_aos != nullptr;
-  const bool sym = m->sym_tangent || packed;                         // layout of the launches of this call
-  const int nt = sym ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad;   // doubles per point in d_ct
+  // (below ~2.6e5 points waking the worker threads costs more than the bytes saved on the wire)
+  const bool packed = m->opt_packed_transfer && !m->sym_tangent && d.n_grad == 6 && ct_aos != nullptr && n >= 262144;
+  const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
+  const int tl = packed && !constant ? TL_COEF : (m->sym_tangent ? TL_SYM : TL_FULL);   // layout of this call's launches
+  const int nt = tl == TL_COEF ? 9 : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad);   // doubles per point in d_ct
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (packed) {
-    if (!m->h_ct21) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_ct21), sizeof(double) * n * 21, hipHostMallocDefault));
+    if (!constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * 9, hipHostMallocDefault));
     if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
       delete m->pool;
       m->pool = new HostPool(m->opt_host_threads);
     }
+    m->elastic_lm[0] = m->prm.lambda;
+    m->elastic_lm[1] = m->prm.mu;
   }
-  int nchunks = (int)(n / 131072);
+  // the last chunk's host expansion is not hidden behind any transfer: many small chunks keep that tail short
+  int nchunks = (int)(n / (packed ? 65536 : 131072));
   if (nchunks < 1) nchunks = 1;
+  if (!packed && nchunks > 8) nchunks = 8;
   if (nchunks > m->opt_max_chunks) nchunks = m->opt_max_chunks;
   if (!m->opt_pipeline) nchunks = 1;
   for (int c = 0; c < nchunks; ++c)
@@ -931,6 +952,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
   int stats_off = 0, issued = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
+  if (constant) m->pool->submit(m->elastic_lm, ct_aos, n, 0);   // nothing to wait for
   for (int c = 0; c < nchunks; ++c) {
     const int64_t off = (int64_t)c * csize;
     if (off >= n) break;
@@ -941,7 +963,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     MeshSource src{};
     if (fused) { src = *fused; src.point0 = off; }
     if (int rc = launch_range(m, off, cnt, fused ? m->d_flux : m->d_grad + off * d.n_grad, m->d_flux + off * d.n_flux,
-                              m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr, sym))
+                              m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr, tl))
       return rc;
     stats_off += grid;
     if (flux_aos)
@@ -957,8 +979,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
                              hipMemcpyDeviceToHost, st));
     }
-    if (ct_aos) {
-      double* dst = packed ? m->h_ct21 + off * 21 : ct_aos + off * nt;
+    if (ct_aos && !constant) {
+      double* dst = packed ? m->h_coef + off * 9 : ct_aos + off * nt;
       HIP_TRY(hipMemcpyAsync(dst, m->d_ct + off * nt, sizeof(double) * cnt * nt, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(m->chunk_done[c], st));
@@ -967,13 +989,13 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   m->last_grid = stats_off;
   m->launched = true;
   m->s1_alias = false;  // every slot of s1 has been rewritten
-  // the chunks complete in issue order on their two streams; expand each as soon as it has landed
+  // the chunks complete in issue order on their two streams; rebuild each block as soon as it has landed
   for (int c = 0; c < issued; ++c) {
     HIP_TRY(hipEventSynchronize(m->chunk_done[c]));
-    if (packed) {
+    if (packed && !constant) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-      m->pool->submit(m->h_ct21 + off * 21, ct_aos + off * 36, cnt);
+      m->pool->submit(m->h_coef + off * 9, ct_aos + off * 36, cnt, 9);
     }
   }
   HIP_TRY(hipEventRecord(m->last_event, m->own_stream));   // everything of this call is complete already
@@ -1205,6 +1227,14 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
 
 const char* dxm_kernel_name(const dxm_material* m) { return m ? kLaws[m->law].kernel : ""; }
 
+int dxm_notify_replay(dxm_material* m) {
+  if (!m) return fail(-1, "null handle");
+  m->launched = true;
+  m->last_event_recorded = false;   // nothing of the replay is known here: waits fall back to the device
+  m->s1_alias = false;              // the replayed kernel rewrote every slot of s1
+  return 0;
+}
+
 uint64_t dxm_launch_generation(const dxm_material* m) { return m ? (m->epoch << 1) | (uint64_t)m->parity : 0; }
 
 int dxm_set_option(dxm_material* m, const char* name, double value) {
@@ -1212,7 +1242,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   const std::string k(name);
   const bool on = value != 0.0;
   if (k == "pipeline") m->opt_pipeline = on;
-  else if (k == "sym_transfer") m->opt_sym_transfer = on;
+  else if (k == "packed_transfer") m->opt_packed_transfer = on;
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
   else if (k == "tune_verbose") m->opt_tune_verbose = on;
   else if (k == "host_threads") {

@@ -66,7 +66,13 @@ __device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
 // evaluates the isoparametric gradient at its own point -- the strain array (48 B/point written by the
 // gradient kernel and read back here) never exists.  GRAD = 2: tet4 mesh, every lane gathers the 4
 // nodes of its own cell (the gradient is constant per cell).
-template <int LAW, bool SYM, int GRAD = 0>
+// TL: layout of the tangent output.  TL_FULL the 6x6 block, row-major (what jacobian_flatten holds,
+// quadrature_map.py:83-105); TL_SYM its 21 upper-triangle entries; TL_COEF the 9 coefficients
+// (c1, c2, c3, n[6]) of Ct = c1 1x1 + c2 I + c3 n x n themselves (72 B/point: what the host-buffer form moves
+// over PCIe before rebuilding the block on the host with the same expression, dxmat.hip).
+enum { TL_FULL = 0, TL_SYM = 1, TL_COEF = 2 };
+
+template <int LAW, int TL, int GRAD = 0>
 __global__ void __launch_bounds__(BLOCK, 4)  // 4 waves per SIMD; a 5-wave (96 VGPR) build measured 1 % slower
 small_strain_kernel(const LawParams prm, const int64_t n, const double* __restrict__ eps,
                     const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
@@ -295,7 +301,26 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
       }
     }
     // ---- 7. coalesced tangent store: entry pair (i, j..j+1) of point q ---------------------------
-    if constexpr (!SYM) {
+    if constexpr (TL == TL_COEF) {
+      // the staged coefficients as they are: 64 x 9 doubles, contiguous (4.5 KiB per tile)
+      static_assert(LAW != LAW_ELASTIC, "the elastic tangent is a constant: nothing to write");
+      if (npts == WAVE) {
+        double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 9);
+        const double2_t* c2 = reinterpret_cast<const double2_t*>(coef);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int idx = k * WAVE + lane;
+          if (idx < 288) stream_store<0>(gct + idx, c2[idx]);
+        }
+      } else {
+        double* gct = ct + base * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int idx = k * WAVE + lane;
+          if (idx < npts * 9) stream_store<0>(gct + idx, coef[idx]);
+        }
+      }
+    } else if constexpr (TL == TL_FULL) {
       // full 6x6, row-major (quadrature_map.py:83-105): 18 x 1 KiB per tile, 18 pairs per point.
       // The (q, i, j) of a lane's pair advance by a fixed pattern from one iteration to the next
       // (64 pairs = 3 points + 10 pairs), so they are carried instead of re-divided; for a full tile

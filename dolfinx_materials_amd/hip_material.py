@@ -48,23 +48,25 @@ class LazyISV(np.lib.mixins.NDArrayOperatorsMixin):
     converged (``QuadratureMap.advance``, ``quadrature_map.py:350-360``), not in every Newton iteration, and
     they are 56 of the 392 B/point the host-buffer form would otherwise bring back over PCIe per call.
     Anything that looks at the values (``np.isnan(isv)``, ``isv[:, a:b]`` as in ``quadrature_map.py:323, :343-348``,
-    ``np.asarray(isv)``) triggers one download of the state the producing ``integrate`` wrote; after a later
-    ``integrate`` of the same material an un-fetched object raises instead of returning newer values."""
+    ``np.asarray(isv)``) triggers one download.  Like the arrays ``generic.Material.integrate`` returns
+    (``generic.py:185-189``) it is a VIEW of the material's current final state ``s1``: looked at after a later
+    ``integrate`` it shows that call's values."""
 
-    def __init__(self, material, shape, serial):
-        self._m, self.shape, self._serial = material, tuple(shape), serial
-        self._value = None
+    def __init__(self, material, shape):
+        self._m, self.shape = material, tuple(shape)
+        self._seen = -1           # serial of the integrate call whose state was last downloaded through this object
         self.dtype = np.dtype(np.float64)
         self.ndim = 2
 
     def _get(self):
-        if self._value is None:
-            self._value = self._m._fetch_isv(self._serial)
+        if self._seen != self._m._serial:
+            self._value = self._m._fetch_isv()
+            self._seen = self._m._serial
         return self._value
 
     @property
     def fetched(self):
-        return self._value is not None
+        return self._seen == self._m._serial
 
     def __array__(self, dtype=None, copy=None):
         a = self._get()
@@ -428,14 +430,11 @@ class HIPMaterial:
             self._grad[1] = g
             self._flux[1] = flux
             self._serial += 1
-            isv = self._out_isv if eager else LazyISV(self, self._out_isv.shape, self._serial)
+            isv = self._out_isv if eager else LazyISV(self, self._out_isv.shape)
         return flux, isv, self._out_ct
 
-    def _fetch_isv(self, serial):
-        """Download the ISVs of s1 for the :class:`LazyISV` of integrate call number ``serial``."""
-        if serial != self._serial:
-            raise DxmError("this isv array belongs to an earlier integrate() of the material and was never read; "
-                           "read it before the next integrate(), or construct the material with lazy_isv=False")
+    def _fetch_isv(self):
+        """Download the ISVs of the current s1 (for :class:`LazyISV`)."""
         self._chk(self._lib.dxm_isv_host(self._require(), S1, _ptr(self._out_isv)))
         return self._out_isv
 
@@ -473,7 +472,7 @@ class HIPMaterial:
             warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
         self._flux[1] = flux
         self._serial += 1
-        return flux, (self._out_isv if eager else LazyISV(self, self._out_isv.shape, self._serial)), self._out_ct
+        return flux, (self._out_isv if eager else LazyISV(self, self._out_isv.shape)), self._out_ct
 
     def integrate_device(self, grad_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
         """Device-pointer form: asynchronous launch on ``stream`` (a ``hipStream_t`` value, e.g.
@@ -512,8 +511,13 @@ class HIPMaterial:
         changes and ``tune_placement`` re-configure the launch)."""
         return int(self._lib.dxm_launch_generation(self._require()))
 
+    def notify_replay(self):
+        """Call after replaying a HIP graph that contains a launch of this material (the replay rewrote s1,
+        flux, tangent and the stats without the library seeing it): ``dxm_notify_replay``."""
+        self._chk(self._lib.dxm_notify_replay(self._require()))
+
     def set_option(self, name, value):
-        """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"sym_transfer"``, ``"host_threads"``,
+        """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"packed_transfer"``, ``"host_threads"``,
         ``"max_chunks"``, ``"fused_gradient"``, ``"blocks_per_cu"``, ``"tune_verbose"``)."""
         self._chk(self._lib.dxm_set_option(self._require(), name.encode(), float(value)))
 

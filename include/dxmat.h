@@ -188,13 +188,18 @@ const char* dxm_kernel_name(const dxm_material* m);
  * dxm_set_option / dxm_tune_placement (the upper bits increase).  Replay a captured graph only while the
  * value equals the one read at capture time.  dxm_revert does not change it. */
 uint64_t dxm_launch_generation(const dxm_material* m);
+/* Tell the handle that the caller has replayed a HIP graph containing a launch of this handle: the replay
+ * is invisible to the library, but it rewrote state s1 (so the next dxm_advance must swap the buffers) and
+ * the flux / tangent / stats.  Call after every replay, before dxm_advance / dxm_get_stats / dxm_get_state. */
+int dxm_notify_replay(dxm_material* m);
 /* Per-handle options (no environment variables are read by the library):
  *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on two streams (default 1)
- *   "max_chunks"     1..16   upper bound on the chunks of that pipeline (default 16)
- *   "sym_transfer"   1 | 0   host-buffer form, small-strain laws, full tangent layout: move the symmetric
- *                            tangent packed (168 instead of 288 B/point) and rebuild the (N,6,6) block on the
- *                            host, bit-identical (default 1)
- *   "host_threads"   1..256  worker threads of that rebuild (default 8)
+ *   "max_chunks"     1..64   upper bound on the chunks of that pipeline (default 64)
+ *   "packed_transfer" 1 | 0  host-buffer form, small-strain laws, full tangent layout, >= 262144 points: move the
+ *                            9 coefficients of Ct = c1 1x1 + c2 I + c3 n x n (72 instead of 288 B/point; nothing
+ *                            for the elastic law) and rebuild the (N,6,6) block on the host with the kernel's
+ *                            own expression, bit-identical (default 1)
+ *   "host_threads"   1..256  worker threads of that rebuild (default 16)
  *   "fused_gradient" 1 | 0   displacement forms: evaluate the gradient inside the update kernel where the mesh
  *                            allows (default 1)
  *   "blocks_per_cu"  1..256  grid size of the update kernel in workgroups per CU (default 32 small strain,

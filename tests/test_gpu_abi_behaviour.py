@@ -139,6 +139,7 @@ def test_device_path_is_graph_capturable():
             m.integrate_device(x.data_ptr(), f.data_ptr(), c.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert float(f.abs().max()) == 0.0  # nothing ran during capture
     graph.replay()
+    m.notify_replay()
     torch.cuda.synchronize()
     assert torch.equal(f, f_ref) and torch.equal(c, c_ref)
 

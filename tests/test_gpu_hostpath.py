@@ -24,11 +24,12 @@ def _j2(kind="linear", **kw):
 
 @pytest.mark.parametrize("n", [1, 255, 300_001, 2_200_000])
 def test_packed_tangent_transfer_is_bit_identical_to_the_full_download(n):
-    """2.2e6 points = 16 chunks on two streams with 8 expansion threads behind them; 300001 = ragged chunks."""
+    """2.2e6 points = 33 chunks on two streams with 16 expansion threads behind them; 300001 = ragged chunks;
+    the two small sizes take the unpacked route (below 262144 points)."""
     a, b = _j2(), _j2()
     a.set_data_manager(n)
     b.set_data_manager(n)
-    b.set_option("sym_transfer", 0)   # moves the full 36-entry block over PCIe, as in round 1
+    b.set_option("packed_transfer", 0)   # moves the full 36-entry block over PCIe, as in round 1
     for eps in j2_history(n, seed=5)[:3]:
         fa, ia, ca = a.integrate(eps)
         fb, ib, cb = b.integrate(eps)
@@ -67,11 +68,11 @@ def test_isv_is_fetched_on_demand_and_equals_the_eager_download():
     _, ie, _ = eager.integrate(h[2])
     lazy.data_manager.update()
     assert np.array_equal(lazy.get_final_state_dict()["p"][:, 0], ie[:, 0])
-    # ... and an un-fetched array of an older call refuses to return newer values
+    # ... and, like the views generic.Material.integrate returns (generic.py:185-189), the array follows s1
     _, il_old, _ = lazy.integrate(h[3])
-    lazy.integrate(h[3] * 0.9)
-    with pytest.raises(_lib.DxmError, match="earlier integrate"):
-        np.asarray(il_old)
+    first = np.asarray(il_old).copy()
+    _, il_new, _ = lazy.integrate(h[3] * 0.5)   # unloads further: some points yield in reverse
+    assert np.array_equal(np.asarray(il_old), np.asarray(il_new)) and not np.array_equal(first, np.asarray(il_new))
 
 
 def test_results_are_delivered_into_bound_caller_arrays():
@@ -104,14 +105,14 @@ def test_options_replace_environment_variables():
     m = _j2()
     m.set_data_manager(1000)
     g0 = m.launch_generation
-    for name, value in (("pipeline", 0), ("sym_transfer", 0), ("host_threads", 2), ("max_chunks", 4), ("fused_gradient", 0),
+    for name, value in (("pipeline", 0), ("packed_transfer", 0), ("host_threads", 2), ("max_chunks", 4), ("fused_gradient", 0),
                         ("blocks_per_cu", 8), ("tune_verbose", 0)):
         m.set_option(name, value)
     assert m.launch_generation > g0
     sig = m.integrate(j2_history(1000)[2])[0].copy()
     m.set_option("blocks_per_cu", 32)
     assert np.array_equal(m.integrate(j2_history(1000)[2])[0], sig)
-    for name, value in (("no_such_option", 1), ("host_threads", 0), ("max_chunks", 99), ("blocks_per_cu", 1e6)):
+    for name, value in (("no_such_option", 1), ("host_threads", 0), ("max_chunks", 999), ("blocks_per_cu", 1e6)):
         with pytest.raises(_lib.DxmError):
             m.set_option(name, value)
 
@@ -146,8 +147,9 @@ def test_launch_generation_tells_when_a_captured_graph_is_stale():
             graphs[gen] = capture()[0]
         gin.copy_(g[k])
         graphs[gen].replay()
-        torch.cuda.synchronize()
-        rc, stats = m.stats()                      # the last launch went into a capture: falls back to a device sync
+        m.notify_replay()                          # the replay is invisible to the library
+        rc, stats = m.stats()                      # no event of the replay exists: falls back to a device sync
+        assert rc == 0 and stats["n_nan"] == 0
         ref = onp.j2_update(h[k], epsp, p, E, NU, hard)
         safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_LIN
         assert np.abs(f.cpu().numpy()[safe] - ref["sig"][safe]).max() <= 1e-12 * np.abs(ref["sig"]).max()

@@ -1,41 +1,71 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the host-buffer form (what QuadratureMap.update() hands over: numpy
-arrays in, numpy arrays out).  Reported in DESIGN.md; never the headline `value`."""
+arrays in, numpy arrays out).  Reported in DESIGN.md and as `host_path` of the bench line; never
+the headline `value`.
+
+Modes:  r01      full 36-entry tangent and the ISVs downloaded in every call (round-1 behaviour:
+                 option packed_transfer = 0, lazy_isv = False), 440 B/point over PCIe;
+        packed   the 9 tangent coefficients moved and the 6x6 block rebuilt on the host, ISVs on
+                 demand (default), 168 B/point;
+        bound    packed + results delivered straight into caller-owned arrays (bind_outputs)."""
 import argparse
 import json
 import os
 import sys
 import time
 
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--points", type=int, nargs="+", default=[100_000, 1_000_000, 10_000_000])
-    ap.add_argument("--reps", type=int, default=5)
-    a = ap.parse_args()
+def run(n, mode, reps, threads=None):
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
     from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
 
-    for n in a.points:
-        h = j2_history(n)
-        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)))
-        m.set_data_manager(n)
-        m.integrate(h[1])
-        m.data_manager.update()
-        m.integrate(h[2])
+    h = j2_history(n)
+    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)),
+                    lazy_isv=(mode != "r01"))
+    m.set_data_manager(n)
+    if mode == "r01":
+        m.set_option("packed_transfer", 0)
+        m.set_option("max_chunks", 8)
+    if threads:
+        m.set_option("host_threads", threads)
+    if mode == "bound":
+        flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
+        m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+    m.integrate(h[1])
+    m.data_manager.update()
+    m.integrate(h[2])
+    ts = []
+    for _ in range(reps):
         t0 = time.perf_counter()
-        for _ in range(a.reps):
-            m.integrate(h[2])
-        dt = (time.perf_counter() - t0) / a.reps
-        print(json.dumps({"law": "j2_linear", "points": n, "host_path_ms": round(dt * 1e3, 3), "Mpoints_per_s": round(n / dt / 1e6, 2),
-                          "pcie_bytes_per_point": 48 + 48 + 56 + 288, "GBs_over_pcie": round(n * 440 / dt / 1e9, 2)}), flush=True)
-        m.close()
+        m.integrate(h[2])
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    bpp = 48 + 48 + (56 + 288 if mode == "r01" else 72)
+    out = {"law": "j2_linear", "mode": mode, "points": n, "host_threads": threads or 8, "host_path_ms": round(dt * 1e3, 3),
+           "min_ms": round(min(ts) * 1e3, 3), "Mpoints_per_s": round(n / dt / 1e6, 2), "pcie_bytes_per_point": bpp,
+           "GBs_over_pcie": round(n * bpp / dt / 1e9, 2)}
+    m.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, nargs="+", default=[100_000, 1_000_000, 10_000_000])
+    ap.add_argument("--modes", nargs="+", default=["r01", "packed", "bound"])
+    ap.add_argument("--threads", type=int, nargs="+", default=[0])
+    ap.add_argument("--reps", type=int, default=7)
+    a = ap.parse_args()
+    for n in a.points:
+        for mode in a.modes:
+            for t in a.threads:
+                print(json.dumps(run(n, mode, a.reps, t or None)), flush=True)
 
 
 if __name__ == "__main__":
