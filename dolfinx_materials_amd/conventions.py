@@ -85,3 +85,12 @@ def unpack_sym_tangent(ct21):
         out[:, i, j] = ct21[:, t]
         out[:, j, i] = ct21[:, t]
     return out
+
+
+def tangent_from_coefficients(coef):
+    """(N,9) ``(c1, c2, c3, n[6])`` -> (N,6,6): ``Ct = c1 1x1 + c2 I + c3 n x n`` (the ``"coef"`` tangent layout)."""
+    coef = np.asarray(coef, dtype=np.float64).reshape(-1, 9)
+    one = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
+    n = coef[:, 3:]
+    return (coef[:, 0, None, None] * np.outer(one, one)[None] + coef[:, 1, None, None] * np.eye(6)[None]
+            + coef[:, 2, None, None] * n[:, :, None] * n[:, None, :])

@@ -28,6 +28,7 @@
 #include "small_strain.hpp"
 
 using namespace dxm;
+static_assert(TL_FULL == DXM_TANGENT_FULL && TL_SYM == DXM_TANGENT_SYM && TL_COEF == DXM_TANGENT_COEF, "kernel and ABI layout ids");
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -246,7 +247,7 @@ struct dxm_material {
   hipEvent_t chunk_done[DXM_MAX_CHUNKS] = {};
   int num_cu = 256;
   int blocks_per_cu = 5;
-  bool sym_tangent = false;  // symmetric-packed (21) tangent instead of the full 6x6 (36)
+  int tangent_layout = 0;    // DXM_TANGENT_FULL (36 / 81) | DXM_TANGENT_SYM (21) | DXM_TANGENT_COEF (9)
   // host-path staging (device side), allocated on first dxm_integrate
   double* d_grad = nullptr;
   double* d_flux = nullptr;
@@ -299,7 +300,9 @@ static int build_params(dxm_material* m, const double* p, int np) {
 
 static int tangent_size(const dxm_material* m) {
   const LawDesc& d = kLaws[m->law];
-  return m->sym_tangent ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad;
+  if (m->tangent_layout == DXM_TANGENT_SYM) return d.n_flux * (d.n_flux + 1) / 2;
+  if (m->tangent_layout == DXM_TANGENT_COEF) return 9;
+  return d.n_flux * d.n_grad;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -510,10 +513,13 @@ int dxm_set_params(dxm_material* m, const double* params, int n_params) {
 
 int dxm_set_tangent_layout(dxm_material* m, int layout) {
   if (!m) return fail(-1, "null handle");
-  if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_SYM) return fail(-1, "unknown tangent layout %d", layout);
-  if (layout == DXM_TANGENT_SYM && kLaws[m->law].n_grad == 9)
+  if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_SYM && layout != DXM_TANGENT_COEF)
+    return fail(-1, "unknown tangent layout %d", layout);
+  if (layout != DXM_TANGENT_FULL && kLaws[m->law].n_grad == 9)
     return fail(-1, "the FeFp tangent dP/dF is not symmetric: only DXM_TANGENT_FULL is available");
-  m->sym_tangent = (layout == DXM_TANGENT_SYM);
+  if (layout == DXM_TANGENT_COEF && m->law == DXM_LAW_ELASTIC_ISO)
+    return fail(-1, "the elastic tangent is the constant lambda 1x1 + 2 mu I: there are no per-point coefficients");
+  m->tangent_layout = layout;
   ++m->epoch;
   return 0;
 }
@@ -708,7 +714,7 @@ static int launch(dxm_material* m, const double* grad, double* flux, double* ct,
                   const MeshSource* fused = nullptr) {
   if (m->n == 0) { m->last_grid = 0; return 0; }
   int grid = 0;
-  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused, m->sym_tangent ? TL_SYM : TL_FULL)) return rc;
+  if (int rc = launch_range(m, 0, m->n, grad, flux, ct, st, 0, &grid, fused, m->tangent_layout)) return rc;
   m->last_grid = grid;
   m->launched = true;
   m->s1_alias = false;  // the kernel rewrites every slot of s1
@@ -927,9 +933,9 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const int64_t n = m->n;
   const int total = isv_total(d);
   // (below ~2.6e5 points waking the worker threads costs more than the bytes saved on the wire)
-  const bool packed = m->opt_packed_transfer && !m->sym_tangent && d.n_grad == 6 && ct_aos != nullptr && n >= 262144;
+  const bool packed = m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && d.n_grad == 6 && ct_aos != nullptr && n >= 262144;
   const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
-  const int tl = packed && !constant ? TL_COEF : (m->sym_tangent ? TL_SYM : TL_FULL);   // layout of this call's launches
+  const int tl = packed && !constant ? TL_COEF : m->tangent_layout;   // layout of this call's launches
   const int nt = tl == TL_COEF ? 9 : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad);   // doubles per point in d_ct
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (packed) {

@@ -132,12 +132,14 @@ class HIPMaterial:
 
         ``tangent_layout="sym"`` (small-strain laws only) makes ``integrate`` return the 21
         upper-triangle entries per point, ``(N, 21)``, instead of the full ``(N, 6, 6)`` block the
-        reference's ``jacobian_flatten`` expects (``conventions.unpack_sym_tangent`` expands it).
+        reference's ``jacobian_flatten`` expects (``conventions.unpack_sym_tangent`` expands it);
+        ``"coef"`` (J2 laws) the nine coefficients ``(c1, c2, c3, n[6])`` of ``Ct = c1 1x1 + c2 I + c3 n x n``,
+        ``(N, 9)`` (``conventions.tangent_from_coefficients``; an assembly can use the rank structure directly).
 
         ``lazy_isv=True``: the ``isv`` array ``integrate`` returns is a :class:`LazyISV`, downloaded when it
         is first looked at; ``False`` downloads it in every call like the reference."""
-        if tangent_layout not in ("full", "sym"):
-            raise ValueError("tangent_layout must be 'full' or 'sym'")
+        if tangent_layout not in ("full", "sym", "coef"):
+            raise ValueError("tangent_layout must be 'full', 'sym' or 'coef'")
         if not isinstance(jit, (bool, type(None))):
             raise TypeError("the second argument of JAXMaterial / HIPMaterial is `jit` (jaxmat.py:144); pass the GPU index as device=")
         self.jit = bool(jit)
@@ -268,9 +270,9 @@ class HIPMaterial:
             raise DxmError(f"dxm_create failed: {_lib.last_error(self._lib)}")
         self._handle = h
         self._n = int(ngauss)
-        if self.tangent_layout == "sym":
+        if self.tangent_layout != "full":
             try:
-                self._chk(self._lib.dxm_set_tangent_layout(h, 1))
+                self._chk(self._lib.dxm_set_tangent_layout(h, {"sym": 1, "coef": 2}[self.tangent_layout]))
             except Exception:
                 self.close()
                 raise
@@ -280,7 +282,7 @@ class HIPMaterial:
         self._grad = [self._initial_gradient(), self._initial_gradient()]
         self._flux = [np.zeros((self._n, nf)), np.zeros((self._n, nf))]
         # output arrays owned by the material, page-locked so that D2H runs at full PCIe rate
-        ct_shape = (self._n, nf, ng) if self.tangent_layout == "full" else (self._n, nf * (nf + 1) // 2)
+        ct_shape = {"full": (self._n, nf, ng), "sym": (self._n, nf * (nf + 1) // 2), "coef": (self._n, 9)}[self.tangent_layout]
         self._pinned = [_lib.PinnedArray((self._n, nisv)), _lib.PinnedArray(ct_shape),
                         _lib.PinnedArray((self._n, nf)), _lib.PinnedArray((self._n, nf))]
         self._out_isv, self._out_ct = self._pinned[0].array, self._pinned[1].array

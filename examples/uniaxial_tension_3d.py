@@ -3,7 +3,8 @@
 driver ``tests/uniaxial_tension.py:11-118`` (BASELINE.json configs[4]) with the stand-in host FE
 loop of ``examples/hex_fem.py`` (dolfinx is not available) and the GPU constitutive update.
 
-    python examples/uniaxial_tension_3d.py [--n 16] [--steps 10] [--law j2_linear|fefp]
+    python examples/uniaxial_tension_3d.py [--n 16] [--steps 10] [--law j2_linear|fefp] [--layout full|sym|coef]
+    python examples/uniaxial_tension_3d.py --n 64 --steps 3 --layout coef --device-gradient     # the config-5 stand-in
 
 Symmetry planes x=0, y=0, z=0 are clamped in their normal direction and u_x is imposed on x=1, so
 the solution is the homogeneous uniaxial stress state sigma_xx = R(p): a known answer the run
@@ -24,17 +25,19 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 from hex_fem import HexMesh, newton_solve  # noqa: E402
 
 
-def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True, device_gradient=False):
+def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True, device_gradient=False, layout="full", solver="auto"):
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
-    from dolfinx_materials_amd.quadrature_driver import QuadratureFieldMap
+    from dolfinx_materials_amd.field_map import QuadratureFieldMap
 
     E, nu, sig0, H = 70e3, 0.3, 250.0, 5e3
     el = jm.LinearElasticIsotropic(E=E, nu=nu)
     mesh = HexMesh(n)
     u = np.zeros(mesh.ndof)
     if law == "j2_linear":
-        material = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(sig0, H)))
+        # layout: what the host assembly consumes -- the (N,6,6) block, its 21-entry upper triangle, or the nine
+        # coefficients of Ct = c1 1x1 + c2 I + c3 n x n (hex_fem.HexMesh.element_matrices)
+        material = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(sig0, H)), tangent_layout=layout)
         gname, fname, B = "strain", "stress", mesh.B_eps
         evaluator = lambda cells: mesh.strain(u, cells)  # noqa: E731
     else:
@@ -60,14 +63,14 @@ def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True, device_gradi
     for k in range(1, steps + 1):
         exx = exx_max * k / steps
         bc_vals = np.concatenate([np.zeros(len(x0)), np.full(len(x1), exx), np.zeros(len(y0)), np.zeros(len(z0))])
-        norms = newton_solve(mesh, qmap, u, bc_dofs, bc_vals, B, fname, timers=timers)
+        norms = newton_solve(mesh, qmap, u, bc_dofs, bc_vals, B, fname, timers=timers, solver=solver, log=print if verbose else None)
         flux = qmap.fluxes[fname].x.array.reshape(-1, qmap.fluxes[fname].dim)
         p = qmap.internal_state_variables["p"].x.array
         hist.append(dict(exx=exx, sxx=float(flux[:, 0].mean()), sxx_spread=float(np.ptp(flux[:, 0])), p=float(p.mean()), iters=len(norms), norms=norms))
         if verbose:
             print(f"step {k:2d} exx={exx:.4f} <flux_xx>={hist[-1]['sxx']:.4f} p={hist[-1]['p']:.5f} newton={len(norms)} |r|={norms[-1]:.2e}")
     timers["total"] = time.perf_counter() - t_all
-    return dict(n=n, points=mesh.num_cells * 8, ndof=mesh.ndof, law=law, history=hist, timers=timers, E=E, nu=nu, sig0=sig0, H=H)
+    return dict(n=n, points=mesh.num_cells * 8, ndof=mesh.ndof, law=law, layout=layout, history=hist, timers=timers, E=E, nu=nu, sig0=sig0, H=H)
 
 
 if __name__ == "__main__":
@@ -76,10 +79,18 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--law", default="j2_linear")
     ap.add_argument("--device-gradient", action="store_true")
+    ap.add_argument("--layout", default="full", choices=["full", "sym", "coef"])
+    ap.add_argument("--solver", default="auto", choices=["auto", "direct", "krylov"])
+    ap.add_argument("--exx", type=float, default=2e-2)
     a = ap.parse_args()
-    out = run(a.n, a.steps, a.law, device_gradient=a.device_gradient)
+    out = run(a.n, a.steps, a.law, exx_max=a.exx, device_gradient=a.device_gradient, layout=a.layout, solver=a.solver)
     h = out["history"][-1]
     if a.law == "j2_linear":
         # homogeneous uniaxial stress: sigma_xx = sig0 + H p and eps_xx = sigma_xx / E + p
-        expect = (out["sig0"] + out["H"] * (h["exx"] - out["sig0"] / out["E"]) / (1 + out["H"] / out["E"]) * 1.0)
-        print(json.dumps({"sxx": h["sxx"], "closed_form": expect, "timers": out["timers"], "points": out["points"], "ndof": out["ndof"]}))
+        expect = (out["sig0"] + out["H"] * h["exx"]) / (1 + out["H"] / out["E"])
+        t, its = out["timers"], max(out["timers"].get("newton_iterations", 1), 1)
+        print(json.dumps({"n": out["n"], "points": out["points"], "ndof": out["ndof"], "layout": out["layout"], "sxx": h["sxx"],
+                          "closed_form": expect, "rel_err": abs(h["sxx"] - expect) / expect, "sxx_spread": h["sxx_spread"],
+                          "newton_iterations": its,
+                          "seconds_per_newton_iteration": {k: round(t.get(k, 0.0) / its, 4) for k in ("constitutive", "assembly", "solve")},
+                          "timers": t}))

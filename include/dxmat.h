@@ -126,9 +126,13 @@ int dxm_set_params(dxm_material* m, const double* params, int n_params);
  * tangent is symmetric -- the 21 upper-triangle entries (i <= j, row-major).  The packed form
  * cuts the dominant store / D2H / all-gather stream by 42 %; its consumer must index it itself
  * (the reference's UFL side expects the full block). */
-enum { DXM_TANGENT_FULL = 0, DXM_TANGENT_SYM = 1 };
+/* DXM_TANGENT_COEF (J2 laws): the algorithmic tangent of the radial return is Ct = c1 1x1 + c2 I + c3 n x n
+ * (tests/mfront/IsotropicLinearHardeningPlasticity.mfront:66-69 with M expanded); integrate writes the nine
+ * numbers (c1, c2, c3, n[0..5]) per point and a consumer that assembles B^T Ct B can use the rank structure
+ * directly (examples/hex_fem.py): 72 instead of 288 B/point leave the device. */
+enum { DXM_TANGENT_FULL = 0, DXM_TANGENT_SYM = 1, DXM_TANGENT_COEF = 2 };
 int dxm_set_tangent_layout(dxm_material* m, int layout);
-/* doubles per point of the tangent array integrate writes (36 / 21 / 81). */
+/* doubles per point of the tangent array integrate writes (36 / 21 / 9 / 81). */
 int dxm_tangent_size(const dxm_material* m);
 /* Local Newton controls: stop when |r| <= rtol * sig0, at most maxit iterations. */
 int dxm_set_newton(dxm_material* m, int maxit, double rtol);

@@ -1,4 +1,4 @@
-"""CPU tests of the host-side drivers around the hot path (QuadratureFieldMap replaying
+"""CPU tests of the host-side drivers around the hot path (QuadratureFieldMap, the field exchange of
 quadrature_map.py:297-360, and the stand-in FE loop), with the oracle-backed material."""
 import os
 import sys
@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from dolfinx_materials_amd.quadrature_driver import QuadratureFieldMap, _get_vals
+from dolfinx_materials_amd.field_map import QuadratureFieldMap
 from oracle import constitutive_np as onp
 from oracle_material import OracleJ2Material
 
@@ -50,7 +50,7 @@ def test_update_initial_state_layout():
     s = np.arange(6.0)
     m.update_initial_state("stress", s)
     assert np.array_equal(m.fluxes["stress"].x.array, np.tile(s, 12))
-    assert np.array_equal(_get_vals(m.fluxes["stress"]), np.tile(s, (12, 1)))
+    assert np.array_equal(m.fluxes["stress"].values, np.tile(s, (12, 1)))
     with pytest.raises(ValueError):
         m.update_initial_state("strain", 0.0)
     with pytest.raises(ValueError):
@@ -58,7 +58,7 @@ def test_update_initial_state_layout():
 
 
 def test_uniaxial_tension_3d_fe_loop_reaches_closed_form():
-    import dolfinx_materials_amd.quadrature_driver as qd
+    import dolfinx_materials_amd.field_map as qd
     from hex_fem import HexMesh, newton_solve
 
     n = 3
@@ -74,9 +74,58 @@ def test_uniaxial_tension_3d_fe_loop_reaches_closed_form():
         bc_vals = np.concatenate([np.zeros(len(x0)), np.full(len(x1), exx), np.zeros(len(y0)), np.zeros(len(z0))])
         norms = newton_solve(mesh, qmap, u, bc_dofs, bc_vals, mesh.B_eps, "stress")
         assert len(norms) <= 6 and norms[-1] < 1e-6 * norms[0]  # consistent tangent: quadratic convergence
-    sig = _get_vals(qmap.fluxes["stress"])
+    sig = qmap.fluxes["stress"].values
     expect = (SIG0_LIN + H_LIN * exx) / (1 + H_LIN / E)
     assert np.allclose(sig[:, 0], expect, rtol=1e-9)
     assert np.abs(sig[:, 1:]).max() < 1e-6
     p = qmap.internal_state_variables["p"].x.array
     assert np.allclose(p, exx - expect / E, rtol=1e-9)
+
+
+def test_element_matrices_from_every_tangent_layout_agree():
+    """The host assembly consumes the full (N,6,6) block, its 21-entry upper triangle and the nine coefficients of
+    Ct = c1 1x1 + c2 I + c3 n x n (an assembly-side consumer of the packed tangent)."""
+    from dolfinx_materials_amd.conventions import pack_sym_tangent, tangent_from_coefficients
+    from hex_fem import HexMesh
+
+    mesh = HexMesh(3)
+    rng = np.random.default_rng(0)
+    coef = rng.standard_normal((mesh.num_cells * 8, 9))
+    coef[:, :3] = np.abs(coef[:, :3]) * [50e3, 40e3, -30e3]
+    full = tangent_from_coefficients(coef)
+    flux = rng.standard_normal((mesh.num_cells * 8, 6))
+    r0, K0 = mesh.assemble(flux, full.reshape(-1, 36), mesh.B_eps, "full")
+    r1, K1 = mesh.assemble(flux, pack_sym_tangent(full), mesh.B_eps, "sym")
+    r2, K2 = mesh.assemble(flux, coef, mesh.B_eps, "coef")
+    scale = np.abs(K0.data).max()
+    assert np.array_equal(r0, r1) and np.array_equal(r0, r2)
+    assert np.abs((K0 - K1).toarray()).max() < 1e-13 * scale and np.abs((K0 - K2).toarray()).max() < 1e-13 * scale
+    # against a plain dense assembly
+    Kd = np.zeros((mesh.ndof, mesh.ndof))
+    for c in range(mesh.num_cells):
+        Ke = sum(mesh.wdet * mesh.B_eps[q].T @ full[c * 8 + q] @ mesh.B_eps[q] for q in range(8))
+        Kd[np.ix_(mesh.cell_dofs[c], mesh.cell_dofs[c])] += Ke
+    assert np.abs(K0.toarray() - Kd).max() < 1e-12 * scale and np.abs(K0.toarray() - K0.toarray().T).max() < 1e-12 * scale
+
+
+def test_multigrid_preconditioned_cg_solves_the_fe_loop():
+    """n = 8 (2187 dofs) through the Krylov path that the 64^3 run uses: same closed-form answer, CG iteration
+    counts that do not grow with the Newton iteration (the V-cycle is a mesh-independent preconditioner)."""
+    import dolfinx_materials_amd.field_map as qd
+    from hex_fem import HexMesh, newton_solve
+
+    mesh = HexMesh(8)
+    u = np.zeros(mesh.ndof)
+    qmap = qd.QuadratureFieldMap(mesh.num_cells, mesh.nqp, _mat())
+    qmap.register_gradient("strain", lambda cells: mesh.strain(u, cells))
+    x0, x1, y0, z0 = mesh.nodes_on(0, 0.0), mesh.nodes_on(0, 1.0), mesh.nodes_on(1, 0.0), mesh.nodes_on(2, 0.0)
+    bc_dofs = np.concatenate([3 * x0, 3 * x1, 3 * y0 + 1, 3 * z0 + 2])
+    timers = {}
+    for k in range(1, 4):
+        exx = 1.2e-2 * k / 3
+        bc_vals = np.concatenate([np.zeros(len(x0)), np.full(len(x1), exx), np.zeros(len(y0)), np.zeros(len(z0))])
+        norms = newton_solve(mesh, qmap, u, bc_dofs, bc_vals, mesh.B_eps, "stress", timers=timers, solver="krylov")
+        assert len(norms) <= 7
+    expect = (SIG0_LIN + H_LIN * exx) / (1 + H_LIN / E)
+    assert np.allclose(qmap.fluxes["stress"].values[:, 0], expect, rtol=1e-8)
+    assert timers["cg_iterations"] / (timers["newton_iterations"] - 3) < 40

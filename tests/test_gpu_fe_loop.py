@@ -44,3 +44,19 @@ def test_device_gradient_run_equals_host_gradient_run():
     for sa, sb in zip(a["history"], b["history"]):
         assert sa["iters"] == sb["iters"]
         assert abs(sa["sxx"] - sb["sxx"]) < 1e-9 * abs(sa["sxx"]) and abs(sa["p"] - sb["p"]) < 1e-12
+
+
+@pytest.mark.parametrize("layout", ["sym", "coef"])
+def test_assembly_from_the_packed_tangent_layouts_gives_the_same_newton_history(layout):
+    """the host assembly consumes the 21-entry upper triangle / the nine coefficients of the
+    J2 tangent directly (examples/hex_fem.py); same iterates as with the full (N,6,6) block, multigrid-CG solves."""
+    from uniaxial_tension_3d import run
+
+    a = run(n=8, steps=3, law="j2_linear", verbose=False, solver="krylov")
+    b = run(n=8, steps=3, law="j2_linear", verbose=False, solver="krylov", layout=layout, device_gradient=True)
+    for sa, sb in zip(a["history"], b["history"]):
+        assert sa["iters"] == sb["iters"] <= 8
+        assert abs(sa["sxx"] - sb["sxx"]) < 1e-9 * abs(sa["sxx"]) and abs(sa["p"] - sb["p"]) < 1e-12
+    h = b["history"][-1]
+    expect = (b["sig0"] + b["H"] * h["exx"]) / (1 + b["H"] / b["E"])
+    assert abs(h["sxx"] - expect) < 1e-8 * expect
