@@ -6,11 +6,11 @@ back into per-Gauss-point fields, roll the state at the end of an increment -- o
 engine can do, for callers that do not have dolfinx (the FE loop of ``examples/``, the tests) and as the model
 of how a dolfinx ``QuadratureMap`` is wired to it (``INTEGRATION.md``):
 
-* a field is ONE page-locked ``(points, dim)`` array (``.values``; ``.x.array`` is its flat view, the memory
-  layout of a dolfinx quadrature Function: point = cell * nqp + q, component fastest);
+* a field is ONE ``(points, dim)`` array (``.values``; ``.x.array`` is its flat view, the memory layout of a
+  dolfinx quadrature Function: point = cell * nqp + q, component fastest);
 * a map over all cells binds the flux and tangent fields as the material's output arrays
-  (``HIPMaterial.bind_outputs``): ``integrate`` delivers into them, nothing is scattered; a map over a subset
-  of cells scatters rows through a point index built once;
+  (``HIPMaterial.bind_outputs`` page-locks them in place): ``integrate`` delivers into them, nothing is
+  scattered; a map over a subset of cells scatters rows through a point index built once;
 * internal state variables cross PCIe when an increment is accepted (``advance``), not in every Newton
   iteration; NaNs are reported by the kernel's own status record instead of three full-array passes
   (``quadrature_map.py:322-324``);
@@ -40,17 +40,9 @@ class _Flat:
 class Field:
     """Per-Gauss-point field of one quantity: ``values`` is ``(points, dim)``, C-contiguous, fp64."""
 
-    def __init__(self, name, dim, points, pinned=False):
+    def __init__(self, name, dim, points):
         self.name, self.dim = name, max(1, int(dim))
-        self._keep = None
-        if pinned and points > 0:
-            from . import _lib
-
-            self._keep = _lib.PinnedArray((points, self.dim))
-            self.values = self._keep.array
-            self.values[...] = 0.0
-        else:
-            self.values = np.zeros((points, self.dim))
+        self.values = np.zeros((points, self.dim))
         self.x = _Flat(self)
 
 
@@ -67,13 +59,14 @@ class QuadratureFieldMap:
         self.covers_everything = len(self.points) == total and np.array_equal(self.points, np.arange(total))
         material.set_data_manager(len(self.points))
         direct = self.covers_everything and hasattr(material, "bind_outputs")
-        width = sum(int(np.prod(shape)) for shape in material.tangent_blocks.values())   # quadrature_map.py:83-87
-        self.jacobian_flatten = Field("jacobian", width, total, pinned=direct)
-        self.fluxes = {name: Field(name, dim, total, pinned=direct) for name, dim in material.fluxes.items()}
+        # quadrature_map.py:83-87; narrower for the engine's packed tangent layouts
+        width = getattr(material, "tangent_size", None) or sum(int(np.prod(shape)) for shape in material.tangent_blocks.values())
+        self.jacobian_flatten = Field("jacobian", width, total)
+        self.fluxes = {name: Field(name, dim, total) for name, dim in material.fluxes.items()}
         self.internal_state_variables = {name: Field(name, dim, total) for name, dim in material.internal_state_variables.items()}
         self.gradients, self._evaluators, self._on_device = {}, {}, None
         self._bound = False
-        if direct and len(self.fluxes) == 1 and getattr(material, "tangent_layout", "full") == "full":
+        if direct and len(self.fluxes) == 1:
             (flux_field,) = self.fluxes.values()
             material.bind_outputs(flux=flux_field.x.array, tangent=self.jacobian_flatten.x.array)
             self._bound = True

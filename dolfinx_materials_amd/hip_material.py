@@ -215,6 +215,13 @@ class HIPMaterial:
         return list(self.internal_state_variables.keys())
 
     @property
+    def tangent_size(self):
+        """Doubles per point of the tangent array ``integrate`` returns (``dxm_tangent_size``): 36 / 81 for the
+        full block, 21 / 9 for the ``"sym"`` / ``"coef"`` layouts."""
+        nf, ng = int(self._info.n_flux), int(self._info.n_grad)
+        return {"full": nf * ng, "sym": nf * (nf + 1) // 2, "coef": 9}[self.tangent_layout]
+
+    @property
     def algorithmic_bytes_per_point(self):
         return int(self._info.algorithmic_bytes_per_point)
 

@@ -260,6 +260,13 @@ def newton_solve(mesh, qmap, u, bc_dofs, bc_vals, B, flux_name, atol=1e-8, rtol=
     timers = timers if timers is not None else {}
     free = np.ones(mesh.ndof, dtype=bool)
     free[bc_dofs] = False
+    # predictor: scale the last converged field with the load (imposing the whole increment on the boundary
+    # nodes alone starts Newton from a boundary layer of large strains that flips points between the elastic
+    # and the plastic branch for many iterations on fine meshes)
+    old = u[bc_dofs]
+    k = np.abs(old).argmax() if len(old) else 0
+    if len(old) and abs(old[k]) > 0.0 and np.isfinite(bc_vals[k] / old[k]):
+        u *= bc_vals[k] / old[k]
     u[bc_dofs] = bc_vals
     layout = getattr(qmap.material, "tangent_layout", "full")
     norms = []
