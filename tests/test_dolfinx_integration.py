@@ -1,0 +1,111 @@
+"""The engine behind the REAL ``QuadratureMap``.  Needs ``dolfinx`` and the
+reference package ``dolfinx_materials`` (hence jax): neither exists in the build container nor on the GPU box, so
+this module is skipped there; it is the test a maintainer runs after ``pip install`` -- the script of
+``INTEGRATION.md`` section 1 with assertions.
+
+Checked: (i) ``QuadratureMap.update()`` drives ``HIPMaterial.integrate`` and the quadrature Functions receive
+the oracle's stress / tangent / state; (ii) ``NonlinearMaterialProblem.solve()`` reproduces the closed-form
+uniaxial answer in 3-D (the analogue of ``tests/mfront/test_elastoplasticity.py:14-36``); (iii)
+``Hex8Mesh.from_dolfinx`` evaluates the same strain at the same Gauss points as the compiled UFL expression."""
+import numpy as np
+import pytest
+
+dolfinx = pytest.importorskip("dolfinx")
+pytest.importorskip("dolfinx_materials")
+pytestmark = pytest.mark.gpu
+
+E, NU, SIG0, H = 70e3, 0.3, 250.0, 5e3
+
+
+def _setup(n=3, deg_quad=2):
+    import ufl
+    from dolfinx import fem, mesh
+    from dolfinx_materials.quadrature_map import QuadratureMap
+    from dolfinx_materials.utils import symmetric_tensor_to_vector
+    from mpi4py import MPI
+
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+
+    domain = mesh.create_unit_cube(MPI.COMM_WORLD, n, n, n, mesh.CellType.hexahedron)
+    V = fem.functionspace(domain, ("P", 1, (3,)))
+    u = fem.Function(V, name="Displacement")
+    material = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)))
+    qmap = QuadratureMap(domain, deg_quad, material)
+    strain = lambda w: symmetric_tensor_to_vector(ufl.sym(ufl.grad(w)))   # noqa: E731  (Mandel: utils.py:146-165)
+    qmap.register_gradient(material.gradient_names[0], strain(u))
+    return domain, V, u, material, qmap, strain
+
+
+def test_update_fills_the_quadrature_functions_with_the_oracle_result():
+    from oracle import constitutive_np as onp
+
+    domain, V, u, material, qmap, _ = _setup()
+    rng = np.random.default_rng(0)
+    A = 4e-3 * rng.standard_normal((3, 3))
+    x = V.tabulate_dof_coordinates()
+    u.x.array[:] = (x @ A.T).reshape(-1)                     # homogeneous displacement gradient A
+    qmap.update()
+    npts = len(qmap.dofs)
+    eps = np.tile(onp.tensor_to_mandel(0.5 * (A + A.T)[None])[0], (npts, 1))
+    ref = onp.j2_update(eps, np.zeros((npts, 6)), np.zeros(npts), E, NU, onp.LinearHardening(SIG0, H))
+    assert ref["plastic"].all()
+    sig = qmap.fluxes["stress"].x.array.reshape(-1, 6)
+    assert np.abs(sig - ref["sig"]).max() < 1e-9 * np.abs(ref["sig"]).max()
+    ct = qmap.jacobian_flatten.x.array.reshape(-1, 36)
+    assert np.abs(ct - ref["Ct"].reshape(-1, 36)).max() < 1e-9 * np.abs(ref["Ct"]).max()
+    qmap.advance()
+    assert np.abs(qmap.internal_state_variables["p"].x.array - ref["p"]).max() < 1e-12
+
+
+def test_snes_solve_reaches_the_closed_form_uniaxial_answer():
+    import ufl
+    from dolfinx import fem
+    from dolfinx_materials.solvers import NonlinearMaterialProblem
+
+    domain, V, u, material, qmap, strain = _setup(n=3)
+    du, v = ufl.TrialFunction(V), ufl.TestFunction(V)
+    sig = qmap.fluxes["stress"]
+    Res = ufl.dot(sig, strain(v)) * qmap.dx
+    Jac = qmap.derivative(Res, u, du)
+    fdim = domain.topology.dim - 1
+
+    def face(axis, value):
+        facets = dolfinx.mesh.locate_entities_boundary(domain, fdim, lambda x: np.isclose(x[axis], value))
+        Vs, _ = V.sub(axis).collapse()
+        return fem.locate_dofs_topological((V.sub(axis), Vs), fdim, facets), Vs
+
+    ux = None
+    bcs = []
+    for axis, value in ((0, 0.0), (1, 0.0), (2, 0.0), (0, 1.0)):
+        dofs, Vs = face(axis, value)
+        g = fem.Function(Vs)
+        if value == 1.0:
+            ux = g
+        bcs.append(fem.dirichletbc(g, dofs, V.sub(axis)))
+    opts = {"snes_type": "newtonls", "snes_linesearch_type": "none", "snes_atol": 1e-10, "snes_rtol": 1e-10,
+            "ksp_type": "preonly", "pc_type": "lu"}   # tests/uniaxial_tension.py:74-82
+    problem = NonlinearMaterialProblem(qmap, Res, u, bcs=bcs, J=Jac, petsc_options_prefix="amd", petsc_options=opts)
+    qmap.update()
+    for k in range(1, 9):
+        exx = 2e-2 * k / 8
+        ux.x.array[:] = exx
+        problem.solve()
+    expect = (SIG0 + H * exx) / (1 + H / E)
+    sxx = qmap.fluxes["stress"].x.array.reshape(-1, 6)[:, 0]
+    assert np.allclose(sxx, expect, rtol=1e-7)
+
+
+def test_device_gradient_adapter_matches_the_ufl_expression():
+    from dolfinx_materials_amd.gradient import Hex8Mesh
+
+    domain, V, u, material, qmap, _ = _setup(n=3)
+    rng = np.random.default_rng(1)
+    u.x.array[:] = 1e-3 * rng.standard_normal(u.x.array.size)
+    qmap.update()                                            # fills the strain Function through fem.Expression
+    eps_ufl = qmap.gradients["strain"].function.x.array.reshape(-1, 6)
+    dmesh = Hex8Mesh.from_dolfinx(V, 2)
+    assert dmesh.npoints == eps_ufl.shape[0]
+    sig_dev, _, _ = material.integrate_displacement(dmesh, u.x.array)
+    sig_ufl = qmap.fluxes["stress"].x.array.reshape(-1, 6)
+    assert np.abs(np.asarray(sig_dev) - sig_ufl).max() < 1e-9 * np.abs(sig_ufl).max()
