@@ -15,9 +15,11 @@ solve (reference solvers.py:72, quadrature_map.py:297-334).  Inputs and outputs 
 resident in the AoS layout of the dolfinx quadrature Functions.
 
 Setup (untimed, before the W warm-up steps): the three load-step contexts are built by integrating the
-earlier increments, and every handle runs ``tune_placement`` once with the real arrays -- the kernel has a
-fast and a slow mode in where the resident state sits relative to them (DESIGN.md section 3);
-``config.placement_tuning`` reports what that did, ``--no-tune`` skips it.
+earlier increments, and every handle runs ``tune_placement`` once with the real arrays (the library's
+recommended budget: 4 candidate allocations, at most 2 GiB of skip blocks) -- the kernel has a fast and a
+slow mode in where the resident state sits relative to them (DESIGN.md section 3);
+``config.placement_tuning`` reports what that did, ``roofline.untuned`` carries the figure of the same
+launches before it, ``--no-tune`` skips it, ``--tune-candidates 24 --tune-skip-gib 16`` is round 1's deep search.
 
 The JSON line also carries
   roofline      achieved algorithmic HBM GB/s of the constitutive kernel (496 B/point x points
@@ -261,6 +263,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true",
                     help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
+    ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle")
+    ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
     ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -346,7 +350,8 @@ def main():
     if not args.no_tune:
         for j, m in enumerate(mats):
             try:
-                info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr())
+                m.set_option("tune_max_skip_bytes", args.tune_skip_gib * 2**30)
+                info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
                 tuning.append({"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4),
                                "candidates_tried": info["candidates_tried"]})
             except Exception as exc:  # an optimisation of the setup: never lose the run over it

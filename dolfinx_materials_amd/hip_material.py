@@ -501,8 +501,9 @@ class HIPMaterial:
         self._chk(self._lib.dxm_integrate_displacement_device(
             self._require(), mesh._handle, int(u_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None))
 
-    def tune_placement(self, grad_ptr, flux_ptr, ct_ptr, max_candidates=24):
-        """Optional, synchronous: measure the update on up to ``max_candidates`` fresh allocations of
+    def tune_placement(self, grad_ptr, flux_ptr, ct_ptr, max_candidates=4):
+        """Optional, synchronous: measure the update on up to ``max_candidates`` (default 4; at most four state
+        blocks and 2 GiB of skip blocks are held meanwhile) fresh allocations of
         the resident state with the caller's real device arrays and keep the fastest (the kernel time
         is bimodal, up to 13 %, in where the state sits relative to those arrays: DESIGN.md section 3).
         Acts like ``integrate_device(grad_ptr, flux_ptr, ct_ptr)``: the initial state is preserved,
@@ -558,6 +559,11 @@ class HIPMaterial:
             arr = self._bound.pop(k, None)
             if arr is not None and arr.nbytes:
                 self._lib.dxm_host_unregister(_ptr(arr))
+
+    def place_state(self, mode, chunk_bytes=2 << 20, seed=0):
+        """``dxm_place_state``: rebuild the resident state in a fresh block (0) or from physical chunks mapped in
+        order (1) / in a permuted order (2)."""
+        self._chk(self._lib.dxm_place_state(self._require(), int(mode), int(chunk_bytes), int(seed)))
 
     def isv_device(self, which, isv_ptr, stream=0):
         self._chk(self._lib.dxm_isv_device(self._require(), which, int(isv_ptr), int(stream) or None))

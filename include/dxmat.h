@@ -171,19 +171,30 @@ int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_st
 const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp);
 /* Placement tuning (optional, synchronous; not capturable).  The update kernel's time depends on
  * where the handle's resident state sits relative to the caller's gradient / flux / tangent arrays
- * (bimodal, up to +13 % at 1e7 J2 points; physical placement, not steerable: DESIGN.md section 3).
+ * (bimodal, up to +13 % at 1e7 J2 points; physical placement, not steerable from user space -- neither
+ * by offsets, strides or alignment (round 1) nor by assembling the state from permuted 2 MiB ... 256 MiB
+ * physical chunks with the virtual-memory API (round 2, dxm_place_state): DESIGN.md section 3).
  * This call measures instead: it runs the update (exactly as dxm_integrate_device would, on the
  * handle's own stream) with the caller's real device arrays on up to max_candidates fresh state
  * allocations and keeps the fastest; s0 is preserved, s1 / flux_dev / ct_dev / the stats end up as
  * after one dxm_integrate_device(grad_dev, ...).  Stops six candidates after both modes have been seen.
  * The first half of the candidates are consecutive allocations, the second half jump ahead by skip
- * blocks of 1, 2, 4 ... 16 GiB (fast regions can be tens of GB apart); everything but the winner is
- * freed before returning; at most half of the free device memory is held meanwhile.  10 ms to a few
- * seconds.  Option "tune_verbose" logs every candidate to stderr.  No-op for laws without state.
- * ms_before / ms_after: kernel time (ms) on the initial / chosen placement; n_tried: candidates
- * measured (any may be NULL).  No counterpart in the reference (its state lives in jax arrays). */
+ * blocks of 1, 2, 4 ... GiB that together stay below option "tune_max_skip_bytes" (default 2 GiB);
+ * everything but the winner is freed before returning.  The recommended budget is max_candidates = 4
+ * (what HIPMaterial.tune_placement and bench.py use): ~10-50 ms, at most four state blocks + 2 GiB held
+ * meanwhile; on a box where the first candidates are all in the slow mode the handle simply stays there
+ * (a deeper search -- 24 candidates, 16 GiB skips -- found a fast region on every box of round 1, at up to
+ * 2.5 s and tens of GB held).  Option "tune_verbose" logs every candidate to stderr.  No-op for laws
+ * without state.  ms_before / ms_after: kernel time (ms) on the initial / chosen placement; n_tried:
+ * candidates measured (any may be NULL).  No counterpart in the reference (its state lives in jax arrays). */
 int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
                        int max_candidates, double* ms_before, double* ms_after, int* n_tried);
+/* Experimental placement control: rebuild the resident state (contents preserved) in mode 0 a fresh hipMalloc
+ * block, 1 separately created physical chunks of chunk_bytes (rounded up to the allocation granularity) mapped in
+ * creation order, 2 the same chunks mapped in a pseudo-random order (seed) -- HIP virtual memory management
+ * (hipMemCreate / hipMemMap).  Measured in round 2 as a deterministic alternative to dxm_tune_placement
+ * (DESIGN.md section 3). */
+int dxm_place_state(dxm_material* m, int mode, uint64_t chunk_bytes, uint64_t seed);
 /* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
 const char* dxm_kernel_name(const dxm_material* m);
 /* Identity of the launch configuration: changes whenever a launch captured into a HIP graph before would
@@ -208,7 +219,8 @@ int dxm_notify_replay(dxm_material* m);
  *                            allows (default 1)
  *   "blocks_per_cu"  1..256  grid size of the update kernel in workgroups per CU (default 32 small strain,
  *                            the resident 2 for FeFp)
- *   "tune_verbose"   1 | 0   dxm_tune_placement logs every candidate to stderr (default 0) */
+ *   "tune_verbose"   1 | 0   dxm_tune_placement logs every candidate to stderr (default 0)
+ *   "tune_max_skip_bytes"    upper bound on the skip blocks dxm_tune_placement may hold (default 2 GiB) */
 int dxm_set_option(dxm_material* m, const char* name, double value);
 /* get_initial_state_dict / get_final_state_dict without a device array of the caller: packs the
  * user-visible ISVs of state `which` and downloads them into host memory (npoints, n_isv_total).  This is
