@@ -206,6 +206,92 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True):
     return out
 
 
+def source_hash():
+    """Identity of the device code the numbers belong to: sha1 over the kernel sources and the ABI header (what
+    `make` compiles into libdxmat.so); stamped into profiles/pmc_traffic.json by tools/summarize_profile.py."""
+    import hashlib
+
+    d = os.path.join(ROOT, "dolfinx_materials_amd", "csrc")
+    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".hpp"))) + [os.path.join(ROOT, "include", "dxmat.h")]
+    h = hashlib.sha1()
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_child(args):
+    """`bench.py --pmc-child`: the few launches of the headline kernel a `rocprofv3 --pmc` pass is wrapped around
+    (same points per launch as the bench, the state of load increment 3, no tuning, nothing else on the GPU)."""
+    import torch
+
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+
+    n = args.points
+    dev = torch.device("cuda", 0)
+    hist = history(n, 1234)
+    eps = [torch.from_numpy(h).to(dev) for h in hist[:3]]
+    flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+    hard = jm.LinearHardening(SIG0, H) if args.law == "j2_linear" else jm.VoceHardening(350.0, 500.0, 1e3)
+    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard))
+    m.set_data_manager(n)
+    st = torch.cuda.current_stream().cuda_stream
+    for k in range(2):
+        m.integrate_device(eps[k].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+        m.data_manager.update()
+    for _ in range(6):
+        m.integrate_device(eps[2].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+    torch.cuda.synchronize()
+    m.close()
+
+
+def live_traffic(args, kernel_prefix="small_strain_kernel<1"):
+    """HBM bytes per launch of the headline kernel, measured in THIS run: two `rocprofv3 --pmc` passes (FETCH_SIZE,
+    WRITE_SIZE: separate passes, counters only besides --kernel-trace) around `bench.py --pmc-child`, started
+    before this process touches the GPU.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM: on gfx950 it reports
+    half the bytes of wide coalesced streaming reads); both are KiB.  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler: no nested pass"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if args.law == "j2_voce":
+        kernel_prefix = "small_strain_kernel<2"
+    means = {}
+    tmp = tempfile.mkdtemp(prefix="dxm_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--points", str(args.points), "--law", args.law]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+            env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_prefix in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None, f"{counter} pass failed (rc {r.returncode}, {len(vals)} samples): {r.stderr[-200:]}"
+            means[counter] = (sum(vals) / len(vals), len(vals))
+    except Exception as exc:
+        return None, repr(exc)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    read_b = 2.0 * means["FETCH_SIZE"][0] * 1024.0
+    write_b = means["WRITE_SIZE"][0] * 1024.0
+    return read_b + write_b, {"source": "two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE; KiB) around `bench.py --pmc-child` in this run",
+                              "hbm_read_bytes": read_b, "hbm_write_bytes": write_b, "launches_sampled": means["FETCH_SIZE"][1]}
+
+
 def launch_ranks(args, argv):
     """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves.
 
@@ -268,11 +354,20 @@ def main():
     ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes for roofline.traffic (falls back to the stamped profiles/pmc_traffic.json)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
     if os.environ.get("DXM_BENCH_SHARE_GPU") == "1":
         args.share_gpu = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    # roofline.traffic: measured now, before this process initialises the GPU (rank 0 of a 1-GPU run only)
+    traffic, traffic_detail = None, None
+    if args.gpus == 1 and not args.no_live_traffic and "WORLD_SIZE" not in os.environ:
+        traffic, traffic_detail = live_traffic(args)
 
     import torch
     import torch.distributed as dist
@@ -466,15 +561,17 @@ def main():
     if rank == 0:
         value = n * world * K / elapsed / 1e6
         achieved = ALG_BYTES * n / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
+        if traffic is None:   # no live pass: the figure of the last committed profile, if it is of THIS code
+            why = traffic_detail
+            traffic_detail = {"source": None, "live_pass": why}
+            tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             try:
                 t = json.load(open(tfile))
-                if t.get("points") == n and t.get("law") == args.law:
+                if t.get("points") == n and t.get("law") == args.law and t.get("source_hash") == source_hash():
                     traffic = t.get("hbm_bytes_per_launch")
+                    traffic_detail["source"] = f"profiles/pmc_traffic.json ({t.get('source')}), stamped with the source hash of this build"
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "M quadrature-point updates/s (stress+tangent, fp64)",
             "value": round(value, 3),
@@ -508,6 +605,9 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_over_algorithmic": round(traffic / (ALG_BYTES * n), 4) if traffic else None,
+                "traffic_measurement": traffic_detail,
+                "source_hash": source_hash(),
                 "kernel": mats[0].kernel_name,
                 "kernel_ms": round(kern_ms, 4),
                 "untuned": {"kernel_ms": round(untuned_ms, 4), "frac": round(ALG_BYTES * n / (untuned_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

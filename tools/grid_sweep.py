@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel time against the grid size (DXM_BLOCKS_PER_CU; the default is the number of RESIDENT
+"""Kernel time against the grid size (option "blocks_per_cu"; the default is the number of RESIDENT
 workgroups per CU, i.e. a persistent grid), every handle with its state placement tuned first.
 
     python tools/grid_sweep.py [j2_linear|j2_voce|elastic|fefp] [bpc ...]
@@ -47,16 +47,14 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     mats = []
     for v in variants:
-        os.environ.pop("DXM_BLOCKS_PER_CU", None)
-        if v != "0":
-            os.environ["DXM_BLOCKS_PER_CU"] = v
         m = JAXMaterial(mk())
         m.set_data_manager(n)
+        if v != "0":
+            m.set_option("blocks_per_cu", int(v))
         m.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
         info = m.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr())
         mats.append((v, m, info))
-    os.environ.pop("DXM_BLOCKS_PER_CU", None)
     times = [[] for _ in mats]
     for _ in range(6):
         for k, (_, m, _) in enumerate(mats):

@@ -21,6 +21,16 @@ import os
 import shutil
 
 
+def _source_hash():
+    """bench.py::source_hash: the stamp that ties the traffic figure to the code it was measured on."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    return bench.source_hash()
+
+
 def counters(path, match):
     agg = collections.defaultdict(list)
     files = glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
@@ -41,8 +51,8 @@ def main():
     ap.add_argument("--alg-bytes", type=int, default=496)
     ap.add_argument("--no-traffic-json", action="store_true")
     ap.add_argument("--command-text", default="`bash tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around\n"
-                    "`python3 bench.py --steps 30 --warmup 6 --no-cpu-baseline` (the default bench command without its CPU leg).")
-    ap.add_argument("--steps", type=int, default=30, help="timed steps of the bench command = the LAST dispatches of the kernel")
+                    "`python3 bench.py --no-cpu-baseline --no-other-laws --no-host-path --no-live-traffic` (the default bench command: 200 steps, 10 warm-up, without its context legs).")
+    ap.add_argument("--steps", type=int, default=200, help="timed steps of the bench command = the LAST dispatches of the kernel")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.prefix) or ".", exist_ok=True)
 
@@ -99,7 +109,8 @@ def main():
     json.dump(out, open(a.prefix + "_pmc.json", "w"), indent=1)
     if not a.no_traffic_json:
         json.dump(
-            {"points": a.points, "law": a.law, "hbm_bytes_per_launch": traffic, "source": os.path.basename(a.prefix) + "_pmc.json"},
+            {"points": a.points, "law": a.law, "hbm_bytes_per_launch": traffic, "source": os.path.basename(a.prefix) + "_pmc.json",
+             "source_hash": _source_hash()},
             open(os.path.join(os.path.dirname(a.prefix) or ".", "pmc_traffic.json"), "w"),
         )
 
