@@ -200,6 +200,11 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True):
             "GBs": round(ab * n / ms / 1e6, 1), "frac": round(ab * n / ms / 1e6 / HBM_PEAK_GBS, 4),
             "plastic_fraction": round(stats["n_plastic"] / n, 4), "not_converged": stats["n_not_converged"],
         }
+        if name.startswith("fefp"):
+            # SURVEY 8(d) counts an F_n read (976 B/point) that this kernel does not need: its state is the material
+            # tensor Cp^-1, so 952 B/point actually cross the HBM interface
+            out[name].update(bytes_moved_per_point=952, GBs_moved=round(952 * n / ms / 1e6, 1),
+                             frac_moved=round(952 * n / ms / 1e6 / HBM_PEAK_GBS, 4))
         m.close()
         del g0, g1, flux, ct
         torch.cuda.empty_cache()
