@@ -153,9 +153,14 @@ def load() -> C.CDLL:
     return _lib
 
 
-def _bind(lib: C.CDLL) -> C.CDLL:
+def _bind(lib: C.CDLL, strict: bool = True) -> C.CDLL:
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        except AttributeError:
+            if strict:
+                raise
+            continue  # tools/ab_inproc.py: older builds of the library beside the current one
         fn.restype = res
         fn.argtypes = args
     return lib

@@ -125,7 +125,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
   __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * F2_LDS_PER_WAVE];
 
   const int lane0 = threadIdx.x & (WAVE - 1);
-  const int wid = threadIdx.x >> 6;
+  // wave-uniform by construction: told to the compiler, so that the tile index, the point count of the tile and
+  // every branch on them live in scalar registers (as a VGPR value each "uniform" branch costs an exec-mask dance)
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* stage = lds_all + wid * F2_LDS_PER_WAVE;   // F in / PK1 out staging ...
   double* outt = stage;                              // ... reused as the tangent out-tile
   double* coef = stage + F2_OUT;
@@ -310,9 +312,10 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       const double delta = sh[0] * cs[0] + sh[3] * cs[3] + sh[4] * cs[4];
       const double tol1 = (prm.tol / fabs(prm.sig0)) * fmax(fabs(prm.sig0), SQ32 * mu * atr);
       unsigned iters = 0;
+      // the hardening law (an exp for Voce, anything for a traced law) is evaluated once per iterate: the first
+      // iterate (dp = 0) reuses the values of the yield test, the converged ones are reused after the loop
+      double R_k = R_n, dR_k = dR_n;
       for (int it = 0;; ++it) {
-        double R_k, dR_k;
-        hardening<HARD>(prm, p_n + dp, R_k, dR_k);
         const double aa = SQ23 * R_k * imu;
         const double r1 = atr - aa - SQ6 * dp * Ie;
         const double r2 = Ie * Ie * Ie - 0.5 * aa * aa * Ie + aa * aa * aa * delta - 1.0;
@@ -327,9 +330,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         dp += (-r1 * j22 + r2 * j12) * idet;
         Ie += (-j11 * r2 + j21 * r1) * idet;
         ++iters;
+        hardening<HARD>(prm, p_n + dp, R_k, dR_k);
       }
-      double R_1, dR_1;
-      hardening<HARD>(prm, p_n + dp, R_1, dR_1);
+      const double R_1 = R_k, dR_1 = dR_k;
       const double a = SQ23 * R_1 * imu;
       const double ap = SQ23 * dR_1 * imu;
       theta = a * iatr;

@@ -82,6 +82,8 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
   __shared__ unsigned long long red[4 * WAVES_PER_BLOCK];
 
   int lane = threadIdx.x & (WAVE - 1);
+  // (not made scalar with readfirstlane as in fefp.hpp: measured in one process, three handles each, that build is
+  // 0.45 % slower -- 96 instead of 103 VGPRs makes a fifth wave per SIMD resident, which this kernel does not like)
   const int wid = threadIdx.x >> 6;
   double* stage = lds_all + wid * SS_LDS_PER_WAVE;
   double* coef = stage + SS_STAGE;

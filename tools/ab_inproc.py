@@ -54,7 +54,7 @@ def main():
     mats = []
     flux = ct = None
     for path in a.libs:
-        lib = _lib._bind(ctypes.CDLL(os.path.abspath(path)))
+        lib = _lib._bind(ctypes.CDLL(os.path.abspath(path)), strict=False)
         orig = _lib.load
         _lib.load = lambda lib=lib: lib
         try:
