@@ -20,11 +20,11 @@ from dolfinx_materials_amd.jaxmat import JAXMaterial  # reference: from dolfinx_
 def main(Nbatch=10):
     E, nu, sig0, b, sigu = 70e3, 0.3, 500.0, 1000, 750.0
     elastic_model = jm.LinearElasticIsotropic(E=E, nu=nu)
-    # the reference passes a Python function `yield_stress(p)` (tests/test_FeFp_jax.py:14-15); here the same law
-    # is either the built-in jm.VoceHardening(sig0, sigu, b) or, as below, C expressions compiled on first use
-    yield_stress = jm.CustomHardening(
-        "sig0 + (sigu - sig0) * (1.0 - exp(-b * p))", "(sigu - sig0) * b * exp(-b * p)", sig0=sig0, sigu=sigu, b=b
-    )
+    # exactly what the reference passes (tests/test_FeFp_jax.py:14-15), with np for jnp: the callable is traced and
+    # compiled into the kernels on construction; jm.VoceHardening(sig0, sigu, b) is the built-in equivalent
+    def yield_stress(p):
+        return sig0 + (sigu - sig0) * (1 - np.exp(-b * p))
+
     behavior = jm.FeFpJ2Plasticity(elasticity=elastic_model, yield_stress=yield_stress)
     material = JAXMaterial(behavior)
     material.set_data_manager(Nbatch)
@@ -37,7 +37,8 @@ def main(Nbatch=10):
         P, isv, Ct = material.integrate(F, dt)
         material.data_manager.update()
         print(f"t={t:.3f}  P11={P[0, 0]:9.4f}  p={isv[0, 0]:.6f}  plastic points={material.last_stats['n_plastic']}")
-    return P, isv, Ct
+    # P and Ct own their (page-locked) memory and outlive the material; isv is a lazy view of its state: materialise it
+    return P, np.array(isv), Ct
 
 
 if __name__ == "__main__":

@@ -185,3 +185,35 @@ def test_stats_after_the_launch_stream_is_gone():
     gc.collect()
     rc, stats = m.stats()
     assert rc == 0 and stats["n_plastic"] > 0 and m.get_final_state_dict()["p"].max() > 0
+
+
+def test_returned_arrays_outlive_the_material():
+    """The arrays integrate() / the state dicts hand out own their page-locked memory: close(), a second
+    set_data_manager() (QuadratureMap re-binding cells) or dropping the material must not invalidate them
+    (round 1 freed the buffers under live numpy views)."""
+    import gc
+    import sys
+    import os
+
+    n = 3000
+    m = _j2(lazy_isv=False)
+    m.set_data_manager(n)
+    eps = j2_history(n, seed=2)[2]
+    sig, isv, ct = m.integrate(eps)
+    keep = (sig.copy(), isv.copy(), ct.copy())
+    fin = m.get_final_state_dict()["epsp"]
+    fin_copy = fin.copy()
+    m.set_data_manager(2 * n)             # frees the old handle and drops the old buffers
+    m.integrate(np.concatenate([eps, eps]))
+    m.close()
+    del m
+    gc.collect()
+    junk = [np.full(50_000, 7.0) for _ in range(20)]   # churn the allocator
+    assert np.array_equal(sig, keep[0]) and np.array_equal(isv, keep[1]) and np.array_equal(ct, keep[2])
+    assert np.array_equal(fin, fin_copy) and len(junk) == 20
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from standalone_batch import main
+
+    P, isv2, Ct2 = main(6)                # returns after its material went out of scope
+    gc.collect()
+    assert P.shape == (6, 9) and Ct2.shape == (6, 9, 9) and np.isfinite(P).all() and np.isfinite(Ct2).all() and isv2[0, 0] > 1e-2
