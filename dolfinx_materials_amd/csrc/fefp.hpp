@@ -107,15 +107,19 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
 // GRAD: 0 = F comes from the (N,9) array Fin; 1 / 2 = F = I + grad u is evaluated in the kernel from the
 //       displacement vector of a hex8 mesh with 8 Gauss points per cell / of a tet4 mesh (`src`, see small_strain.hpp)
 //
-// What was measured for this kernel in round 2 (profiles/r02_fefp_ab_prefetch_ppr.jsonl, one process, interleaved):
+// What was measured for this kernel in round 2 (profiles/r02_fefp_ab_*.jsonl; builds side by side in one process,
+// five handles each, every handle with its state placement searched: the kernel is placement-sensitive like the J2
+// one and comparisons of single un-tuned handles are dominated by that):
 //   * register diet (symmetric storage, Q = h M form of the tangent coefficients, per-tile re-derivation of the
-//     lane invariants): 256 VGPRs + 27 spilled -> 255 VGPRs, no scratch; same time (2.06 vs 2.05 ms): the spill
-//     traffic was never on the critical path;
-//   * requesting the next tile's inputs ahead of this tile's stores by LDS-DMA (global_load_lds into a spare LDS
-//     region, counted s_waitcnt at the top of the next tile; needs 7-point rounds to make room): +6 % time, of
-//     which +5 % is the 7-point rounds alone (16 % more instructions per tile) -- the kernel is bound by the
-//     instructions each of its two resident waves per SIMD has to issue (VALU + LDS), not by load latency or by
-//     the in-order completion of its memory operations.  Not shipped.
+//     lane invariants): 256 VGPRs + 27 spilled -> 255 VGPRs, no scratch                                   1.90 -> 1.85 ms
+//   * tile bookkeeping in scalar registers (readfirstlane of the wave index: every "uniform" branch had been an
+//     exec-mask sequence), one hardening evaluation per Newton iterate                                       -> 1.76 ms
+//   * record / out-tile bases as opaque indices (LDS accesses become base + immediate), straight-line copy-out for
+//     the two round shapes of a full tile                                                                      -> 1.74 ms
+//   * NOT shipped: requesting the next tile's inputs ahead of this tile's stores by LDS-DMA (global_load_lds into a
+//     spare LDS region, counted s_waitcnt at the top of the next tile; needs 7-point rounds to make room): +6 %, of
+//     which +5 % is the 7-point rounds alone -- load latency and the in-order completion of a wave's memory
+//     operations are not what the kernel waits for; unrolling the two steps of a round: no gain.
 template <int HARD, int GRAD = 0>
 __global__ void __launch_bounds__(BLOCK, 2)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
@@ -468,7 +472,11 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       const int p0 = rd * F2_PPR;                               // first point of the round
       const int cnt = (WAVE - p0) < F2_PPR ? (WAVE - p0) : F2_PPR;  // points staged this round
       if (lane >= p0 && lane < p0 + cnt) {
-        double* rec = coef + (lane - p0) * F2_REC;
+        // record base as an opaque index: every access below is base + small immediate (as a foldable constant the
+        // 9 KiB offset of the record region exceeds the offset field of ds_write2_b64 and costs one v_add per pair)
+        int ro = F2_OUT + (lane - p0) * F2_REC;
+        asm volatile("" : "+v"(ro));
+        double* rec = stage + ro;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           rec[t] = Fi[t];
@@ -480,11 +488,13 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         }
       }
       wave_lds_order();
-#pragma unroll 1
+#pragma unroll 1   // (unrolled: no spill, no gain: 1.758 vs 1.755 ms)
       for (int st = 0; st < F2_PPR / 7; ++st) {
         const int ql = st * 7 + ps;                              // point inside the round
         if (lane < 63 && ql < cnt) {
-          const double* rec = coef + ql * F2_REC;
+          int ro = F2_OUT + ql * F2_REC;
+          asm volatile("" : "+v"(ro));
+          const double* rec = stage + ro;
           // all LDS reads first (the out-tile writes below may alias them for the compiler)
           double fi[9], sr[9];
 #pragma unroll
@@ -525,15 +535,34 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         double2_t v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) v[it] = o2[it * WAVE + lane];   // out-tile is padded to NIT KiB
+        double2_t* g2p = reinterpret_cast<double2_t*>(gct) + lane;
+        // the two shapes every full tile consists of: straight-line stores, no per-KiB bookkeeping
+        constexpr int E_FULL = F2_PPR * 81, E_LAST = (WAVE % F2_PPR) * 81;
+        if (nent == E_FULL) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int e0 = (it * WAVE + lane) * 2;
-          if ((it + 1) * 2 * WAVE <= nent) {                     // scalar branch: whole KiB valid
-            stream_store<0>(reinterpret_cast<double2_t*>(gct + e0), v[it]);
-          } else if (e0 + 1 < nent) {
-            stream_store<0>(reinterpret_cast<double2_t*>(gct + e0), v[it]);
-          } else if (e0 < nent) {
-            stream_store<0>(gct + e0, v[it].x);
+          for (int it = 0; it < E_FULL / (2 * WAVE); ++it) stream_store<0>(g2p + it * WAVE, v[it]);
+          if constexpr (E_FULL % (2 * WAVE) != 0) {
+            static_assert(E_FULL % 2 == 0, "whole 16 B elements");
+            if (lane < (E_FULL % (2 * WAVE)) / 2) stream_store<0>(g2p + (E_FULL / (2 * WAVE)) * WAVE, v[E_FULL / (2 * WAVE)]);
+          }
+        } else if (E_LAST > 0 && nent == E_LAST) {
+#pragma unroll
+          for (int it = 0; it < E_LAST / (2 * WAVE); ++it) stream_store<0>(g2p + it * WAVE, v[it]);
+          if constexpr (E_LAST % (2 * WAVE) != 0) {
+            static_assert(E_LAST % 2 == 0, "whole 16 B elements");
+            if (lane < (E_LAST % (2 * WAVE)) / 2) stream_store<0>(g2p + (E_LAST / (2 * WAVE)) * WAVE, v[E_LAST / (2 * WAVE)]);
+          }
+        } else {   // ragged tile: element-wise bounds
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int e0 = (it * WAVE + lane) * 2;
+            if ((it + 1) * 2 * WAVE <= nent) {                     // scalar branch: whole KiB valid
+              stream_store<0>(reinterpret_cast<double2_t*>(gct + e0), v[it]);
+            } else if (e0 + 1 < nent) {
+              stream_store<0>(reinterpret_cast<double2_t*>(gct + e0), v[it]);
+            } else if (e0 < nent) {
+              stream_store<0>(gct + e0, v[it].x);
+            }
           }
         }
       }

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--advance", action="store_true", help="advance after every update (the new state is read back by the next one)")
+    ap.add_argument("--tune", type=int, default=0, help="let every handle search this many state placements first (best-vs-best comparison)")
     a = ap.parse_args()
     import torch
 
@@ -70,6 +71,12 @@ def main():
         m.data_manager.update()
         for _ in range(3):
             m.integrate_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+        if a.tune:
+            try:
+                m.set_option("tune_max_skip_bytes", 16 * 2**30)
+            except Exception:
+                pass  # older builds search deep by default
+            m.tune_info = m.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=a.tune)
         mats.append(m)
     times = [[] for _ in mats]
     for _ in range(a.rounds):
