@@ -979,6 +979,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
   int stats_off = 0, issued = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
+  // no worker may still be writing into the caller's array when this function returns, error paths included
+  struct PoolDrain {
+    HostPool* p;
+    ~PoolDrain() { if (p) p->wait(); }
+  } drain{packed ? m->pool : nullptr};
   if (constant) m->pool->submit(m->elastic_lm, ct_aos, n, 0);   // nothing to wait for
   for (int c = 0; c < nchunks; ++c) {
     const int64_t off = (int64_t)c * csize;
