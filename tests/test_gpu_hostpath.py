@@ -217,3 +217,19 @@ def test_returned_arrays_outlive_the_material():
     P, isv2, Ct2 = main(6)                # returns after its material went out of scope
     gc.collect()
     assert P.shape == (6, 9) and Ct2.shape == (6, 9, 9) and np.isfinite(P).all() and np.isfinite(Ct2).all() and isv2[0, 0] > 1e-2
+
+
+def test_elastic_host_path_fills_the_constant_block_without_moving_it():
+    """Elastic law, full layout, >= 262144 points: no tangent bytes cross PCIe, worker threads fill the constant block;
+    equal to the device-computed block and to python_materials/elasticity.py:15-19."""
+    n = 300_001
+    el = jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU))
+    a, b = JAXMaterial(el), JAXMaterial(el)
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    b.set_option("packed_transfer", 0)
+    eps = j2_history(n, seed=3)[2]
+    fa, ia, ca = a.integrate(eps)
+    fb, ib, cb = b.integrate(eps)
+    assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.asarray(ia).shape == (n, 0)
+    assert np.array_equal(ca[12345], onp.elastic_matrix(E, NU))
