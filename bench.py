@@ -379,7 +379,7 @@ def main():
 
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
-    from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p
+    from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p, allgather_tangent
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -562,6 +562,45 @@ def main():
                 gather["p2p_schedule"] = timed_gather(allgather_rows_p2p, G)
             except Exception as exc:
                 gather["p2p_schedule"] = {"error": repr(exc)}
+        if "error" not in gather:
+            # ... and with the tangent travelling as its 9 coefficients (72 instead of 288 B/point on the links) and
+            # rebuilt on every rank by dxm_expand_tangent_device (bit-identical): kernels with tangent_layout="coef"
+            try:
+                hard = jm.LinearHardening(SIG0, H) if args.law == "j2_linear" else jm.VoceHardening(350.0, 500.0, 1e3)
+                cmats = []
+                ct9 = torch.empty((n, 9), dtype=torch.float64, device=dev)
+                for k in (2, 3, 4):
+                    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard), device=dev_index, tangent_layout="coef")
+                    m.set_data_manager(n)
+                    for i in range(k - 1):
+                        m.integrate_device(eps[i].data_ptr(), flux.data_ptr(), ct9.data_ptr(), stream)
+                        m.data_manager.update()
+                    cmats.append(m)
+                coef_all = torch.empty((n * world, 9), dtype=torch.float64, device=cdev)
+
+                def cstep(i):
+                    j = i % 3
+                    cmats[j].integrate_device(eps[j + 1].data_ptr(), flux.data_ptr(), ct9.data_ptr(), stream)
+                    allgather_rows(flux.to(cdev), plan, out=g_flux)
+                    allgather_tangent(ct9.to(cdev), plan, out=g_ct, coef_all=coef_all)
+
+                cstep(0)
+                barrier()
+                g0 = time.perf_counter()
+                for i in range(G):
+                    cstep(i)
+                barrier()
+                gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=cdev)
+                dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+                gather["coefficient_gather"] = {
+                    "value": round(n * world * G / float(gt.item()) / 1e6, 3), "unit": "Mpoints/s",
+                    "ms_per_step": round(float(gt.item()) / G * 1e3, 4), "steps": G,
+                    "bytes_received_per_rank": int((world - 1) * n * 15 * 8),
+                    "note": "stress (N,6) + tangent coefficients (N,9) all-gathered, (N,36) tangent rebuilt locally on every rank"}
+                for m in cmats:
+                    m.close()
+            except Exception as exc:
+                gather["coefficient_gather"] = {"error": repr(exc)}
 
     if rank == 0:
         value = n * world * K / elapsed / 1e6

@@ -1334,6 +1334,21 @@ int dxm_place_state(dxm_material* m, int mode, uint64_t chunk_bytes, uint64_t se
   return 0;
 }
 
+int dxm_expand_tangent_device(const double* coef_dev, int64_t npoints, double* ct_dev, int device, void* hip_stream) {
+  if (npoints < 0) return fail(-1, "negative point count");
+  if (npoints == 0) return 0;
+  if (!coef_dev || !ct_dev) return fail(-1, "null device pointer");
+  if (((uintptr_t)coef_dev | (uintptr_t)ct_dev) & 15) return fail(-1, "coefficient / tangent device arrays must be 16-byte aligned");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(-2, "hipSetDevice(%d) failed", device);
+  const int64_t tiles = (npoints + WAVE - 1) / WAVE;
+  int64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(expand_tangent_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, npoints, coef_dev, ct_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int dxm_notify_replay(dxm_material* m) {
   if (!m) return fail(-1, "null handle");
   m->launched = true;

@@ -66,6 +66,21 @@ __device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
 // evaluates the isoparametric gradient at its own point -- the strain array (48 B/point written by the
 // gradient kernel and read back here) never exists.  GRAD = 2: tet4 mesh, every lane gathers the 4
 // nodes of its own cell (the gradient is constant per cell).
+// Entries (i, j) and (i, j+1) of Ct = c1 1x1 + c2 I + c3 n x n from the nine staged numbers cf = (c1, c2, c3, n[6]).
+// k3 (ni nj), not (k3 ni) nj: the product ni nj commutes bit for bit, so the block is EXACTLY symmetric and can be
+// rebuilt from its coefficients with this very expression elsewhere (host path: dxmat.hip::expand_coef_tangent;
+// after an all-gather of coefficients: expand_tangent_kernel below).
+__device__ __forceinline__ double2_t tangent_pair(const double* cf, int i, int j) {
+  const double k1 = cf[0], k2 = cf[1], k3 = cf[2];
+  const double ni = cf[3 + i], nj0 = cf[3 + j], nj1 = cf[4 + j];
+  const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
+  const double t1 = ((i < 3 && j + 1 < 3) ? k1 : 0.0) + ((i == j + 1) ? k2 : 0.0);
+  double2_t v;
+  v.x = t0 + k3 * (ni * nj0);
+  v.y = t1 + k3 * (ni * nj1);
+  return v;
+}
+
 // TL: layout of the tangent output.  TL_FULL the 6x6 block, row-major (what jacobian_flatten holds,
 // quadrature_map.py:83-105); TL_SYM its 21 upper-triangle entries; TL_COEF the 9 coefficients
 // (c1, c2, c3, n[6]) of Ct = c1 1x1 + c2 I + c3 n x n themselves (72 B/point: what the host-buffer form moves
@@ -335,15 +350,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           v.x = ((i < 3 && j < 3) ? lambda : 0.0) + ((i == j) ? 2.0 * mu : 0.0);
           v.y = ((i < 3 && j + 1 < 3) ? lambda : 0.0) + ((i == j + 1) ? 2.0 * mu : 0.0);
         } else {
-          const double* cf = coef + q * 9;
-          const double k1 = cf[0], k2 = cf[1], k3 = cf[2];
-          const double ni = cf[3 + i], nj0 = cf[3 + j], nj1 = cf[4 + j];
-          const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
-          const double t1 = ((i < 3 && j + 1 < 3) ? k1 : 0.0) + ((i == j + 1) ? k2 : 0.0);
-          // k3 (ni nj), not (k3 ni) nj: the product ni nj commutes bit for bit, so the block is EXACTLY
-          // symmetric and the host path may rebuild it from its upper triangle (dxmat.hip: run_and_download)
-          v.x = t0 + k3 * (ni * nj0);
-          v.y = t1 + k3 * (ni * nj1);
+          v = tangent_pair(coef + q * 9, i, j);
         }
         return v;
       };
@@ -413,6 +420,58 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
   }
 
   store_block_stats(stats, c_plastic, c_notconv, c_nan, c_maxit, red);
+}
+
+// coefficients (N, 9) -> full tangent (N, 36), both in HBM: what a rank runs after all-gathering the 72 B/point
+// coefficient form of the J2 tangent instead of its 288 B/point block (sharding.allgather_tangent): 360 B/point of
+// HBM traffic buy 216 B/point less on the xGMI links.  Same staging and store loops as step 7 of the update kernel.
+__global__ void __launch_bounds__(BLOCK, 4)
+expand_tangent_kernel(const int64_t n, const double* __restrict__ cin, double* __restrict__ ct) {
+  __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * SS_COEF];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x >> 6;
+  double* coef = lds_all + wid * SS_COEF;
+  const int64_t ntiles = (n + WAVE - 1) / WAVE;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; tile < ntiles; tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+    const int64_t base = tile * WAVE;
+    const int npts = (n - base) < WAVE ? (int)(n - base) : WAVE;
+    if (npts == WAVE) {
+      const double2_t* g = reinterpret_cast<const double2_t*>(cin + base * 9);
+      double2_t v[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] = (k * WAVE + lane < 288) ? g[k * WAVE + lane] : double2_t{0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if (k * WAVE + lane < 288) reinterpret_cast<double2_t*>(coef)[k * WAVE + lane] = v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int idx = k * WAVE + lane;
+        coef[idx] = idx < npts * 9 ? cin[base * 9 + idx] : 0.0;
+      }
+    }
+    wave_lds_sync();
+    double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 36);
+    const int lim = npts * 18;
+#pragma unroll 1
+    for (int g = 0; g < 6; ++g) {
+      double2_t v[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = (g * 3 + u) * WAVE + lane;
+        const int q = k / 18;
+        const int r = k - q * 18;
+        const int i = r / 3;
+        v[u] = tangent_pair(coef + q * 9, i, (r - i * 3) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = (g * 3 + u) * WAVE + lane;
+        if (k < lim) stream_store<0>(gct + k, v[u]);
+      }
+    }
+    wave_lds_sync();
+  }
 }
 
 }  // namespace dxm

@@ -195,6 +195,11 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
  * (hipMemCreate / hipMemMap).  Measured in round 2 as a deterministic alternative to dxm_tune_placement
  * (DESIGN.md section 3). */
 int dxm_place_state(dxm_material* m, int mode, uint64_t chunk_bytes, uint64_t seed);
+/* Rebuild full tangents from their coefficient form on the device: coef_dev (npoints, 9) as written with
+ * DXM_TANGENT_COEF -> ct_dev (npoints, 36), the block DXM_TANGENT_FULL writes, bit for bit; asynchronous on
+ * hip_stream of `device`.  For consumers that move the 72 B/point form (e.g. across xGMI: an all-gather of
+ * coefficients followed by this kernel instead of an all-gather of 288 B/point blocks) and need the full block. */
+int dxm_expand_tangent_device(const double* coef_dev, int64_t npoints, double* ct_dev, int device, void* hip_stream);
 /* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
 const char* dxm_kernel_name(const dxm_material* m);
 /* Identity of the launch configuration: changes whenever a launch captured into a HIP graph before would

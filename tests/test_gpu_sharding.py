@@ -111,3 +111,37 @@ def test_bench_starts_its_own_ranks(gpu_available):
     assert pg["ranks_in_group"] == 2 and pg["ranks_counted_by_all_reduce"] == 2 and pg["launcher"] == "self"
     assert out["gather_inclusive"]["value"] > 0 and out["gather_inclusive"]["p2p_schedule"]["value"] > 0
     assert out["value"] > out["gather_inclusive"]["value"]
+
+
+@pytest.mark.parametrize("n", [64, 1000, 250_007])
+def test_coefficient_gather_payload_is_rebuilt_bit_for_bit_on_the_device(gpu_available, n):
+    """`sharding.allgather_tangent`: ranks exchange the 72 B/point coefficient form and rebuild the (N,36) blocks with
+    `dxm_expand_tangent_device`; here the rebuild alone (single process), against the full-layout kernel."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    import torch
+
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd import _lib
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+
+    dev = torch.device("cuda:0")
+    beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
+    full, coef = JAXMaterial(beh), JAXMaterial(beh, tangent_layout="coef")
+    full.set_data_manager(n)
+    coef.set_data_manager(n)
+    st = torch.cuda.current_stream().cuda_stream
+    f = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    c36, c9, out = (torch.empty((n, k), dtype=torch.float64, device=dev) for k in (36, 9, 36))
+    lib = _lib.load()
+    for eps in j2_history(n, seed=8, sig0=SIG0_V)[:3]:
+        g = torch.from_numpy(eps).to(dev)
+        full.integrate_device(g.data_ptr(), f.data_ptr(), c36.data_ptr(), st)
+        coef.integrate_device(g.data_ptr(), f.data_ptr(), c9.data_ptr(), st)
+        out.fill_(float("nan"))
+        _lib.check(lib.dxm_expand_tangent_device(c9.data_ptr(), n, out.data_ptr(), 0, st or None), lib)
+        torch.cuda.synchronize()
+        assert torch.equal(out, c36)
+        full.data_manager.update()
+        coef.data_manager.update()
+    assert full.stats()[1]["n_plastic"] == 0 and float(c9[:, 2].abs().max()) == 0.0   # last increment unloads

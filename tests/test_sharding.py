@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p
+from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p, allgather_tangent
 from oracle import constitutive_np as onp
 
 from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
@@ -49,6 +49,23 @@ def _worker(rank, world, port, n, q):
         sig2 = allgather_rows_p2p(torch.from_numpy(r["sig"]), plan)
         ct2 = allgather_rows_p2p(torch.from_numpy(r["Ct"].reshape(-1, 36)), plan)
         assert torch.equal(sig, sig2) and torch.equal(ct, ct2)
+        # coefficient form: 9 instead of 36 doubles per point on the wire, rebuilt locally
+        one = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
+        nrm = np.zeros((hi - lo, 6))                            # (c1, c2, c3, n) from the oracle's pieces
+        from oracle.constitutive_np import lame
+        lmbda, mu = lame(E, NU)
+        eel = eps[lo:hi]
+        se = 2 * mu * (eel - eel[:, :3].sum(1)[:, None] / 3 * one)
+        seq = np.sqrt(1.5 * (se * se).sum(1))
+        pl = r["plastic"]
+        nrm[pl] = 1.5 * se[pl] / seq[pl, None]
+        dp = r["p"]
+        beta = np.where(pl, dp / np.where(pl, seq, 1.0), 0.0)
+        gamma = np.where(pl, 1.0 / (H_LIN + 3 * mu), 0.0)
+        coef = np.column_stack([lmbda + 2 * mu * mu * beta, 2 * mu - 6 * mu * mu * beta, 4 * mu * mu * (beta - gamma), nrm])
+        for p2p in (False, True):
+            full = allgather_tangent(torch.from_numpy(coef), plan, p2p=p2p)
+            assert (full - ct).abs().max() <= 1e-12 * ct.abs().max()
         if rank == 0:
             q.put((sig.numpy(), ct.numpy()))
     finally:
