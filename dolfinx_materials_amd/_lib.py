@@ -98,8 +98,13 @@ SYMBOLS = {
     "dxm_host_free": (C.c_int, [C.c_void_p]),
     "dxm_mesh_create_hex8": (_h, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     "dxm_mesh_create_tet4": (_h, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "dxm_mesh_create_simplex": (
+        _h,
+        [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int],
+    ),
     "dxm_mesh_destroy": (C.c_int, [_h]),
     "dxm_mesh_npoints": (C.c_int64, [_h]),
+    "dxm_mesh_displacement_size": (C.c_int64, [_h]),
     "dxm_mesh_gradient_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dxm_integrate_displacement": (
         C.c_int,

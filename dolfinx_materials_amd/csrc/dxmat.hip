@@ -673,11 +673,12 @@ static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64
   BlockStats* bs = m->d_stats + stats_off;
   const MeshSource none{};
   const MeshSource& src = fused ? *fused : none;
-  const int g = fused ? (fused->kind == 1 ? 1 : 2) : 0;   // where the strain comes from: array / hex8 x 8 / tet4
+  const int g = fused ? fused->kind : 0;   // where the strain comes from: array / hex8 x 8 / tet4 / Lagrange simplex
 #define DXM_LAUNCH_SS(TL, G)                                                                              \
   hipLaunchKernelGGL((small_strain_kernel<LAW, TL, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, \
                      m->ld, flux, ct, bs, src)
-#define DXM_LAUNCH_SS_G(TL) do { if (g == 0) DXM_LAUNCH_SS(TL, 0); else if (g == 1) DXM_LAUNCH_SS(TL, 1); else DXM_LAUNCH_SS(TL, 2); } while (0)
+#define DXM_LAUNCH_SS_G(TL) do { if (g == 0) DXM_LAUNCH_SS(TL, 0); else if (g == 1) DXM_LAUNCH_SS(TL, 1); \
+                                 else if (g == 2) DXM_LAUNCH_SS(TL, 2); else DXM_LAUNCH_SS(TL, 3); } while (0)
   if (tl == TL_SYM) DXM_LAUNCH_SS_G(TL_SYM);
   else if (tl == TL_FULL) DXM_LAUNCH_SS_G(TL_FULL);
   else if constexpr (LAW != LAW_ELASTIC) DXM_LAUNCH_SS_G(TL_COEF);
@@ -712,7 +713,8 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
 #define DXM_LAUNCH_FEFP(HARD, G) \
   hipLaunchKernelGGL((fefp_kernel<HARD, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, *fused)
       if (fused && fused->kind == 1) { if (voce) DXM_LAUNCH_FEFP(1, 1); else DXM_LAUNCH_FEFP(0, 1); }
-      else if (fused)                { if (voce) DXM_LAUNCH_FEFP(1, 2); else DXM_LAUNCH_FEFP(0, 2); }
+      else if (fused && fused->kind == 2) { if (voce) DXM_LAUNCH_FEFP(1, 2); else DXM_LAUNCH_FEFP(0, 2); }
+      else if (fused)                { if (voce) DXM_LAUNCH_FEFP(1, 3); else DXM_LAUNCH_FEFP(0, 3); }
       else if (voce)
         hipLaunchKernelGGL((fefp_kernel<1, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, none);
       else
@@ -1079,14 +1081,20 @@ int dxm_host_free(void* p) {
 
 // ---- gradient evaluation on device ----------------------------------------------------------
 struct dxm_mesh {
-  int nodes_per_cell = 8;   // 8: trilinear hexahedron, 4: linear tetrahedron
+  int nodes_per_cell = 8;   // 8: trilinear hexahedron, 4: linear tetrahedron, 0: Lagrange simplex (fields below)
   int device = 0;
   int64_t n_nodes = 0, n_cells = 0;
+  int64_t u_len = 0;        // doubles in the displacement vector (3 per node; tdim per dof for a Lagrange simplex)
   QuadPoints qp{};
   double* d_coords = nullptr;
   int32_t* d_conn = nullptr;
   double* d_u = nullptr;
   hipEvent_t grad_done = nullptr;
+  // Lagrange simplex: geometry through d_conn (tdim + 1 vertices per cell), displacement through its own dofmap
+  int tdim = 3, nd = 0;
+  int64_t n_dofs = 0;
+  int32_t* d_dofmap = nullptr;
+  double* d_dphi = nullptr;
 };
 
 static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, const int32_t* conn,
@@ -1107,6 +1115,7 @@ static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, con
   mesh->device = device;
   mesh->n_nodes = n_nodes;
   mesh->n_cells = n_cells;
+  mesh->u_len = 3 * n_nodes;
   mesh->qp.nqp = nqp;
   if (qpoints)
     for (int q = 0; q < nqp; ++q)
@@ -1136,18 +1145,82 @@ dxm_mesh* dxm_mesh_create_tet4(const double* coords, int64_t n_nodes, const int3
   return mesh_create(4, coords, n_nodes, conn, n_cells, nullptr, nqp, device);
 }
 
+dxm_mesh* dxm_mesh_create_simplex(int tdim, const double* coords, int64_t n_vertices, const int32_t* geom_conn,
+                                  int64_t n_cells, const int32_t* dofmap, int nd, int64_t n_dofs,
+                                  const double* dphi, int nqp, int device) {
+  if ((tdim != 2 && tdim != 3) || !coords || !geom_conn || !dofmap || !dphi || n_vertices <= 0 || n_cells <= 0 ||
+      nd < tdim + 1 || nd > 64 || n_dofs <= 0 || nqp <= 0 || nqp > 64) {
+    fail(-1, "invalid simplex mesh arguments");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    fail(-2, "no usable HIP device %d (libdxmat has no CPU fallback)", device);
+    return nullptr;
+  }
+  const int nv = tdim + 1;
+  for (int64_t k = 0; k < n_cells * nv; ++k)
+    if (geom_conn[k] < 0 || geom_conn[k] >= n_vertices) { fail(-1, "geometry connectivity entry %lld out of range", (long long)k); return nullptr; }
+  for (int64_t k = 0; k < n_cells * nd; ++k)
+    if (dofmap[k] < 0 || dofmap[k] >= n_dofs) { fail(-1, "dofmap entry %lld out of range", (long long)k); return nullptr; }
+  // a flat or inverted reference map would put Inf / NaN into every gradient of the cell
+  for (int64_t c = 0; c < n_cells; ++c) {
+    const double* X0 = coords + 3 * (int64_t)geom_conn[c * nv];
+    double A[9];
+    for (int d = 0; d < tdim; ++d) {
+      const double* Xd = coords + 3 * (int64_t)geom_conn[c * nv + d + 1];
+      for (int a = 0; a < tdim; ++a) A[a * 3 + d] = Xd[a] - X0[a];
+    }
+    const double det = tdim == 2 ? A[0] * A[4] - A[1] * A[3]
+                                 : A[0] * (A[4] * A[8] - A[5] * A[7]) + A[1] * (A[5] * A[6] - A[3] * A[8]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    if (!(det != 0.0) || !std::isfinite(det)) { fail(-1, "cell %lld is degenerate (zero volume)", (long long)c); return nullptr; }
+  }
+  dxm_mesh* mesh = new dxm_mesh();
+  mesh->nodes_per_cell = 0;
+  mesh->device = device;
+  mesh->n_nodes = n_vertices;
+  mesh->n_cells = n_cells;
+  mesh->qp.nqp = nqp;
+  mesh->tdim = tdim;
+  mesh->nd = nd;
+  mesh->n_dofs = n_dofs;
+  mesh->u_len = (int64_t)tdim * n_dofs;
+  DeviceGuard guard(device);
+  bool ok = guard.ok;
+  ok = ok && hipMalloc(&mesh->d_coords, sizeof(double) * 3 * n_vertices) == hipSuccess;
+  ok = ok && hipMalloc(&mesh->d_conn, sizeof(int32_t) * nv * n_cells) == hipSuccess;
+  ok = ok && hipMalloc(&mesh->d_dofmap, sizeof(int32_t) * nd * n_cells) == hipSuccess;
+  ok = ok && hipMalloc(&mesh->d_dphi, sizeof(double) * nqp * nd * tdim) == hipSuccess;
+  ok = ok && hipMalloc(&mesh->d_u, sizeof(double) * mesh->u_len) == hipSuccess;
+  ok = ok && hipMemcpy(mesh->d_coords, coords, sizeof(double) * 3 * n_vertices, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(mesh->d_conn, geom_conn, sizeof(int32_t) * nv * n_cells, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(mesh->d_dofmap, dofmap, sizeof(int32_t) * nd * n_cells, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(mesh->d_dphi, dphi, sizeof(double) * nqp * nd * tdim, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    fail(-3, "device allocation / upload of the mesh failed");
+    dxm_mesh_destroy(mesh);
+    return nullptr;
+  }
+  return mesh;
+}
+
 int dxm_mesh_destroy(dxm_mesh* mesh) {
   if (!mesh) return 0;
   DeviceGuard guard(mesh->device);
   if (mesh->d_coords) (void)hipFree(mesh->d_coords);
   if (mesh->d_conn) (void)hipFree(mesh->d_conn);
   if (mesh->d_u) (void)hipFree(mesh->d_u);
+  if (mesh->d_dofmap) (void)hipFree(mesh->d_dofmap);
+  if (mesh->d_dphi) (void)hipFree(mesh->d_dphi);
   if (mesh->grad_done) (void)hipEventDestroy(mesh->grad_done);
   delete mesh;
   return 0;
 }
 
 int64_t dxm_mesh_npoints(const dxm_mesh* mesh) { return mesh ? mesh->n_cells * mesh->qp.nqp : -1; }
+int64_t dxm_mesh_displacement_size(const dxm_mesh* mesh) { return mesh ? mesh->u_len : -1; }
+
+static MeshSource mesh_source(const dxm_mesh* mesh, const double* u_dev);
 
 int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, double* grad_dev,
                              void* hip_stream) {
@@ -1157,7 +1230,11 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
   const int64_t npts = mesh->n_cells * mesh->qp.nqp;
   const int blocks = (int)((npts + 255) / 256);
   hipStream_t st = (hipStream_t)hip_stream;
-  if (mesh->nodes_per_cell == 4) {
+  if (mesh->nodes_per_cell == 0) {
+    const MeshSource src = mesh_source(mesh, u_dev);
+    if (kind == 0) hipLaunchKernelGGL(simplex_gradient_kernel<0>, dim3(blocks), dim3(256), 0, st, src, grad_dev);
+    else hipLaunchKernelGGL(simplex_gradient_kernel<1>, dim3(blocks), dim3(256), 0, st, src, grad_dev);
+  } else if (mesh->nodes_per_cell == 4) {
     if (kind == 0)
       hipLaunchKernelGGL(tet4_gradient_kernel<0>, dim3(blocks), dim3(256), 0, st, mesh->d_coords, mesh->d_conn,
                          u_dev, mesh->n_cells, mesh->qp.nqp, grad_dev);
@@ -1182,15 +1259,17 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
   return 0;
 }
 
-// kind of in-kernel gradient evaluation this mesh allows: 1 hex8 x 8 points, 2 tet4, 0 none
+// kind of in-kernel gradient evaluation this mesh allows: 1 hex8 x 8 points, 2 tet4, 3 Lagrange simplex, 0 none
 static int fused_kind(const dxm_mesh* mesh) {
   if (mesh->nodes_per_cell == 8) return mesh->qp.nqp == 8 ? 1 : 0;
+  if (mesh->nodes_per_cell == 0) return 3;
   return mesh->nodes_per_cell == 4 ? 2 : 0;
 }
 static MeshSource mesh_source(const dxm_mesh* mesh, const double* u_dev) {
   MeshSource src{};
   src.coords = mesh->d_coords; src.conn = mesh->d_conn; src.u = u_dev; src.ncells = mesh->n_cells; src.point0 = 0;
   src.kind = fused_kind(mesh); src.nqp = mesh->qp.nqp;
+  src.dofmap = mesh->d_dofmap; src.dphi = mesh->d_dphi; src.nd = mesh->nd; src.tdim = mesh->tdim;
   if (src.kind == 1)
     for (int q = 0; q < 8; ++q)
       for (int a = 0; a < 3; ++a) src.xi[q][a] = mesh->qp.xi[q][a];
@@ -1210,7 +1289,7 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
   if (int rc = ensure_host_path_buffers(m, !fuse)) return rc;
   hipStream_t st = m->own_stream;
   if (int rc = sync_last(m)) return rc;
-  HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * 3 * mesh->n_nodes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * mesh->u_len, hipMemcpyHostToDevice, st));
   MeshSource src{};
   if (fuse) {
     src = mesh_source(mesh, mesh->d_u);

@@ -104,8 +104,9 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
 #define DXM_SYM(i, j) ((i) == (j) ? (i) : ((i) + (j) + 2))
 
 // HARD: 0 = linear hardening R = sig0 + H p (prm.h1 = H), 1 = Voce (prm.h1 = sigu, prm.h2 = b)
-// GRAD: 0 = F comes from the (N,9) array Fin; 1 / 2 = F = I + grad u is evaluated in the kernel from the
-//       displacement vector of a hex8 mesh with 8 Gauss points per cell / of a tet4 mesh (`src`, see small_strain.hpp)
+// GRAD: 0 = F comes from the (N,9) array Fin; 1 / 2 / 3 = F = I + grad u is evaluated in the kernel from the
+//       displacement vector of a hex8 mesh with 8 Gauss points per cell / of a tet4 mesh / of a straight-sided
+//       simplex mesh with a Lagrange displacement of any order (`src`, see small_strain.hpp)
 //
 // What was measured for this kernel in round 2 (profiles/r02_fefp_ab_*.jsonl; builds side by side in one process,
 // five handles each, every handle with its state placement searched: the kernel is placement-sensitive like the J2
@@ -242,7 +243,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         wave_lds_order();  // the coefficient region is rewritten by the tangent rounds
       } else {
         if (valid) {
-          tet4_cell_disp_grad(src.coords, src.conn, src.u, (src.point0 + gi) / src.nqp, F);
+          const int64_t cell = (src.point0 + gi) / src.nqp;
+          if constexpr (GRAD == 2) tet4_cell_disp_grad(src.coords, src.conn, src.u, cell, F);
+          else simplex_disp_grad(src, cell, (int)(src.point0 + gi - cell * src.nqp), F);
         } else {
 #pragma unroll
           for (int k = 0; k < 9; ++k) F[k] = 0.0;

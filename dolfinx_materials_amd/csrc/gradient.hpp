@@ -1,4 +1,5 @@
-// Gradient evaluation at the Gauss points on the device, for first-order hexahedra and tetrahedra: the step
+// Gradient evaluation at the Gauss points on the device, for first-order hexahedra and tetrahedra and for
+// Lagrange elements of any order on straight-sided simplices (tet10 / tri6 of the reference's demos): the step
 // immediately BEFORE the hot path (reference: QuadratureExpression.eval -> fem.Expression.eval,
 // dolfinx_materials/quadrature_function.py:45-51, called from quadrature_map.py:247-253), so that
 // only the displacement vector (24 B/node) crosses PCIe instead of the strain array (48 B/point).
@@ -25,6 +26,9 @@ struct QuadPoints { int nqp; double xi[27][3]; };
 // What the fused displacement -> update kernels read instead of a gradient array.
 //   kind 1: hex8 mesh with exactly 8 Gauss points per cell (one 64-point tile = 8 cells, one (cell, corner) per lane)
 //   kind 2: tet4 mesh, any number of points per cell (every lane gathers the 4 nodes of its own cell)
+//   kind 3: straight-sided simplices (tdim 2 or 3) with a Lagrange displacement of any order: geometry from the
+//           tdim+1 vertices (`conn`), displacement through its own dofmap (nd dofs per cell) and the tabulated
+//           reference derivatives of the nd shape functions at the nqp points (`dphi`, in device memory)
 struct MeshSource {
   const double* coords;
   const int32_t* conn;
@@ -34,6 +38,9 @@ struct MeshSource {
   int32_t kind;
   int32_t nqp;
   double xi[8][3];  // hex8 only
+  const int32_t* dofmap;   // kind 3: (ncells, nd)
+  const double* dphi;      // kind 3: (nqp, nd, tdim), dphi[q][m][d] = d N_m / d xi_d at point q
+  int32_t nd, tdim;
 };
 constexpr int HEX_FUSED_REC = 50;   // doubles per staged cell record (8 corners x 6, padded: see the staged kernel)
 
@@ -221,6 +228,99 @@ __device__ __forceinline__ void tet4_cell_disp_grad(const double* __restrict__ c
     for (int a = 0; a < 3; ++a) { X[m][a] = coords[3 * nd + a]; U[m][a] = u[3 * nd + a]; }
   }
   tet4_disp_grad(X, U, H);
+}
+
+// Lagrange element of any order on a straight-sided simplex: the geometry map is affine (vertices only), so
+//   H[i][a] = sum_m u_m[i] * sum_d dphi[q][m][d] * Ai[d][a],   Ai = inverse of the edge matrix,
+// with dphi the tabulated reference derivatives (what basix hands out as element.tabulate(1, points)[1:]).
+// tdim = 2: u has two components per dof, H is embedded in 3x3 with zeros (plane strain: eps_zz = 0, F_zz = 1).
+// Every lane gathers its own cell; the nqp lanes of a cell ask for the same addresses (merged by the
+// texture addresser), the table is a few hundred bytes and stays in the vector L1.
+__device__ __forceinline__ void simplex_disp_grad(const MeshSource& s, const int64_t cell, const int q,
+                                                  double* __restrict__ H) {
+  double Ai[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // Ai[d][a] = dxi_d / dX_a
+  if (s.tdim == 3) {
+    double X[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int64_t v = s.conn[cell * 4 + m];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) X[m][a] = s.coords[3 * v + a];
+    }
+    double A[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) A[a * 3 + d] = X[d + 1][a] - X[0][a];
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double idet = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    Ai[0] = c00 * idet; Ai[3] = c01 * idet; Ai[6] = c02 * idet;
+    Ai[1] = (A[2] * A[7] - A[1] * A[8]) * idet;
+    Ai[4] = (A[0] * A[8] - A[2] * A[6]) * idet;
+    Ai[7] = (A[1] * A[6] - A[0] * A[7]) * idet;
+    Ai[2] = (A[1] * A[5] - A[2] * A[4]) * idet;
+    Ai[5] = (A[2] * A[3] - A[0] * A[5]) * idet;
+    Ai[8] = (A[0] * A[4] - A[1] * A[3]) * idet;
+  } else {
+    double X[3][2];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int64_t v = s.conn[cell * 3 + m];
+      X[m][0] = s.coords[3 * v]; X[m][1] = s.coords[3 * v + 1];
+    }
+    const double a00 = X[1][0] - X[0][0], a01 = X[2][0] - X[0][0], a10 = X[1][1] - X[0][1], a11 = X[2][1] - X[0][1];
+    const double idet = 1.0 / (a00 * a11 - a01 * a10);
+    Ai[0] = a11 * idet; Ai[1] = -a01 * idet;
+    Ai[3] = -a10 * idet; Ai[4] = a00 * idet;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) H[k] = 0.0;
+  const int32_t* dofs = s.dofmap + cell * s.nd;
+  const double* tab = s.dphi + (int64_t)q * s.nd * s.tdim;
+  if (s.tdim == 3) {
+    for (int m = 0; m < s.nd; ++m) {
+      const int64_t dof = dofs[m];
+      const double t0 = tab[3 * m], t1 = tab[3 * m + 1], t2 = tab[3 * m + 2];
+      const double U0 = s.u[3 * dof], U1 = s.u[3 * dof + 1], U2 = s.u[3 * dof + 2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double g = t0 * Ai[a] + t1 * Ai[3 + a] + t2 * Ai[6 + a];
+        H[a] += U0 * g; H[3 + a] += U1 * g; H[6 + a] += U2 * g;
+      }
+    }
+  } else {
+    for (int m = 0; m < s.nd; ++m) {
+      const int64_t dof = dofs[m];
+      const double t0 = tab[2 * m], t1 = tab[2 * m + 1];
+      const double U0 = s.u[2 * dof], U1 = s.u[2 * dof + 1];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double g = t0 * Ai[a] + t1 * Ai[3 + a];
+        H[a] += U0 * g; H[3 + a] += U1 * g;
+      }
+    }
+  }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+simplex_gradient_kernel(const MeshSource src, double* __restrict__ grad) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= src.ncells * src.nqp) return;
+  const int64_t cell = gid / src.nqp;
+  double H[9];
+  simplex_disp_grad(src, cell, (int)(gid - cell * src.nqp), H);
+  if constexpr (KIND == 0) {
+    const double r = 0.70710678118654752440;
+    double2_t* o2 = reinterpret_cast<double2_t*>(grad + gid * 6);
+    o2[0] = double2_t{H[0], H[4]};
+    o2[1] = double2_t{H[8], r * (H[1] + H[3])};
+    o2[2] = double2_t{r * (H[2] + H[6]), r * (H[5] + H[7])};
+  } else {
+    double* o = grad + gid * 9;
+    o[0] = 1.0 + H[0]; o[1] = 1.0 + H[4]; o[2] = 1.0 + H[8];
+    o[3] = H[1]; o[4] = H[3]; o[5] = H[2]; o[6] = H[6]; o[7] = H[5]; o[8] = H[7];
+  }
 }
 
 template <int KIND>

@@ -65,7 +65,8 @@ __device__ __forceinline__ double hardening_dR(const LawParams& prm, double p) {
 // (cell c of the tile, corner k) gathers one node into a wave-private LDS record, every lane then
 // evaluates the isoparametric gradient at its own point -- the strain array (48 B/point written by the
 // gradient kernel and read back here) never exists.  GRAD = 2: tet4 mesh, every lane gathers the 4
-// nodes of its own cell (the gradient is constant per cell).
+// nodes of its own cell (the gradient is constant per cell).  GRAD = 3: straight-sided simplices with a Lagrange
+// displacement of any order (tet10, tri6 in plane strain, ...: gradient.hpp::simplex_disp_grad), also gathered per lane.
 // Entries (i, j) and (i, j+1) of Ct = c1 1x1 + c2 I + c3 n x n from the nine staged numbers cf = (c1, c2, c3, n[6]).
 // k3 (ni nj), not (k3 ni) nj: the product ni nj commutes bit for bit, so the block is EXACTLY symmetric and can be
 // rebuilt from its coefficients with this very expression elsewhere (host path: dxmat.hip::expand_coef_tangent;
@@ -190,7 +191,9 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
         wave_lds_sync();  // the coefficient region is rewritten in step 5
       } else {
         if (valid) {
-          tet4_cell_disp_grad(src.coords, src.conn, src.u, (src.point0 + gi) / src.nqp, Hd);
+          const int64_t cell = (src.point0 + gi) / src.nqp;
+          if constexpr (GRAD == 2) tet4_cell_disp_grad(src.coords, src.conn, src.u, cell, Hd);
+          else simplex_disp_grad(src, cell, (int)(src.point0 + gi - cell * src.nqp), Hd);
         } else {
 #pragma unroll
           for (int k = 0; k < 9; ++k) Hd[k] = 0.0;

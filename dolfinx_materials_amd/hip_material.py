@@ -461,14 +461,15 @@ class HIPMaterial:
 
     def integrate_displacement(self, mesh, u, dt=0):
         """Same as :meth:`integrate`, with the gradient evaluated on the device from the nodal
-        displacement vector ``u`` (``mesh``: :class:`dolfinx_materials_amd.gradient.Hex8Mesh`):
+        displacement vector ``u`` (``mesh``: :class:`~dolfinx_materials_amd.gradient.Hex8Mesh`,
+        :class:`~dolfinx_materials_amd.gradient.Tet4Mesh` or :class:`~dolfinx_materials_amd.gradient.SimplexMesh`):
         only ``u`` crosses PCIe on the way in (the step before the path,
         ``quadrature_function.py:45-51``)."""
         h = self._require()
         nf, ng = self._info.n_flux, self._info.n_grad
         u = _as_c(u).reshape(-1)
-        if u.size != 3 * mesh.n_nodes:
-            raise ValueError(f"u must have {3 * mesh.n_nodes} entries, got {u.size}")
+        if u.size != mesh.displacement_size:
+            raise ValueError(f"u must have {mesh.displacement_size} entries, got {u.size}")
         flux = self._next_flux_buffer()
         st = Stats()
         eager = not self.lazy_isv
@@ -495,9 +496,9 @@ class HIPMaterial:
 
     def integrate_displacement_device(self, mesh, u_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
         """Device-resident form of :meth:`integrate_displacement`: ``u_ptr`` is the device address of
-        the ``(n_nodes, 3)`` displacement vector, ``flux_ptr`` / ``ct_ptr`` device arrays as for
+        the displacement vector (``mesh.displacement_size`` doubles), ``flux_ptr`` / ``ct_ptr`` device arrays as for
         :meth:`integrate_device`; asynchronous on ``stream``.  For hex8 meshes with 8 Gauss points per
-        cell the gradient is evaluated inside the update kernel."""
+        cell, tet4 meshes and Lagrange simplex meshes the gradient is evaluated inside the update kernel."""
         self._chk(self._lib.dxm_integrate_displacement_device(
             self._require(), mesh._handle, int(u_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None))
 

@@ -244,7 +244,7 @@ int dxm_host_free(void* p);
 int dxm_host_register(void* p, uint64_t bytes);
 int dxm_host_unregister(void* p);
 
-/* ---- gradient evaluation on device (the step before the path; first-order hexahedra and tetrahedra) --
+/* ---- gradient evaluation on device (the step before the path; hex8, tet4, Lagrange simplices of any order) --
  * Replaces, for the device-resident flow, QuadratureExpression.eval -> fem.Expression.eval
  * (quadrature_function.py:45-51; consumer quadrature_map.py:247-253): only the displacement
  * vector crosses PCIe, the (npoints, n_grad) gradient array is produced in HBM in the layout
@@ -258,21 +258,35 @@ dxm_mesh* dxm_mesh_create_hex8(const double* coords, int64_t n_nodes, const int3
  * cell's nqp Gauss points (point = cell * nqp + q). */
 dxm_mesh* dxm_mesh_create_tet4(const double* coords, int64_t n_nodes, const int32_t* conn,
                                int64_t n_cells, int nqp, int device);
+/* Lagrange displacement of any order on STRAIGHT-SIDED simplices (tdim 3: tetrahedra, tdim 2: triangles, embedded as
+ * plane strain: eps_zz = 0 / F_zz = 1) -- the P2 spaces of the reference's demos
+ * (demos/jax/finite_strain_elastoplasticity/finite_strain_elastoplasticity.py:115-117 tet10 with 4 points,
+ * demos/jax/elastoplasticity/plane_elastoplasticity.py:96-100 tri6 with 3 points).  The geometry map is affine and
+ * comes from the tdim+1 vertices of each cell: coords (n_vertices,3) [dolfinx geometry.x is 3-wide in 2-D too],
+ * geom_conn (n_cells, tdim+1).  The displacement has its own dofmap (n_cells, nd) into a vector of n_dofs blocks of tdim
+ * components [u.x.array of a (tdim,)-shaped space], and dphi (nqp, nd, tdim) holds the reference derivatives
+ * d N_m / d xi_d of its nd shape functions at the nqp quadrature points, in the dofmap's local ordering
+ * [basix: element.tabulate(1, points)[1:, :, :, 0] transposed to (point, dof, direction)]. */
+dxm_mesh* dxm_mesh_create_simplex(int tdim, const double* coords, int64_t n_vertices, const int32_t* geom_conn,
+                                  int64_t n_cells, const int32_t* dofmap, int nd, int64_t n_dofs,
+                                  const double* dphi, int nqp, int device);
 int dxm_mesh_destroy(dxm_mesh* mesh);
 int64_t dxm_mesh_npoints(const dxm_mesh* mesh);
+/* doubles in the displacement vector the mesh expects (3 per node; tdim per dof for dxm_mesh_create_simplex) */
+int64_t dxm_mesh_displacement_size(const dxm_mesh* mesh);
 /* kind 0: Mandel strain (6); kind 1: deformation gradient F = I + grad u (9).  u_dev: device
- * (n_nodes*3); grad_dev: device (npoints, 6|9).  Asynchronous on hip_stream. */
+ * (dxm_mesh_displacement_size doubles); grad_dev: device (npoints, 6|9).  Asynchronous on hip_stream. */
 int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, double* grad_dev,
                              void* hip_stream);
 /* dxm_integrate with the gradient computed on the device from the host displacement vector
- * u_host (n_nodes*3): uploads u, evaluates the law's gradient, runs the constitutive update,
+ * u_host (dxm_mesh_displacement_size doubles): uploads u, evaluates the law's gradient, runs the constitutive update,
  * downloads flux / isv / tangent (any may be NULL).  mesh npoints must equal the handle's. */
 int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
                                double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats);
 
-/* Device-resident form of dxm_integrate_displacement: u_dev (n_nodes*3), flux_dev, ct_dev are device
+/* Device-resident form of dxm_integrate_displacement: u_dev (dxm_mesh_displacement_size doubles), flux_dev, ct_dev are device
  * arrays, the call is asynchronous on hip_stream and capturable like dxm_integrate_device.  For
- * hexahedra with 8 Gauss points per cell and for tetrahedra the gradient is evaluated inside the
+ * hexahedra with 8 Gauss points per cell, for tetrahedra and for Lagrange simplices the gradient is evaluated inside the
  * update kernel (no strain / deformation-gradient array is written or read); otherwise the gradient kernel fills a scratch
  * array owned by the handle and the update kernel follows on the same stream. */
 int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const double* u_dev, double dt,

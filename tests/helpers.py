@@ -51,3 +51,51 @@ def fefp_path(n, nsteps=19, eps=2e-2, seed=4321, pert=0.2, n_exact=10):
         F += t * (eps * np.diag([1.0, -0.5, -0.5]) + pert * eps * G)
         out.append(onp.tensor_to_nsym(F))
     return out
+
+
+KUHN = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]   # hex8 -> 6 tets along 0-6
+
+
+def simplex_host_gradient(coords, geom_conn, dofmap, u, dphi):
+    """Plain numpy displacement gradient H (ncells, nqp, 3, 3) of a Lagrange field on straight-sided simplices (the
+    checker of dxm_mesh_create_simplex): H = sum_m u_m (x) A^-T dphi[q, m], zero-padded to 3x3 for triangles."""
+    tdim = geom_conn.shape[1] - 1
+    X = coords[geom_conn][:, :, :tdim]                       # (c, tdim+1, tdim)
+    A = (X[:, 1:] - X[:, :1]).transpose(0, 2, 1)             # dX_a / dxi_d
+    Ai = np.linalg.inv(A)                                    # dxi_d / dX_a
+    U = u.reshape(-1, tdim)[dofmap]                          # (c, nd, tdim)
+    g = np.einsum("qmd,cda->cqma", dphi, Ai)                 # dN_m / dX_a at point q
+    H = np.zeros((len(geom_conn), dphi.shape[0], 3, 3))
+    H[:, :, :tdim, :tdim] = np.einsum("cmi,cqma->cqia", U, g)
+    return H
+
+
+def mandel_strain(H):
+    """(…, 3, 3) displacement gradients -> (…, 6) Mandel strains [utils.py:146-165]."""
+    e = 0.5 * (H + np.swapaxes(H, -1, -2))
+    r = np.sqrt(2.0)
+    return np.stack([e[..., 0, 0], e[..., 1, 1], e[..., 2, 2], r * e[..., 0, 1], r * e[..., 0, 2], r * e[..., 1, 2]], axis=-1)
+
+
+def deformation_gradient9(H):
+    """(…, 3, 3) displacement gradients -> (…, 9) F = 1 + H in the order [11,22,33,12,21,13,31,23,32] (utils.py:168-190)."""
+    F = H + np.eye(3)
+    return np.stack([F[..., 0, 0], F[..., 1, 1], F[..., 2, 2], F[..., 0, 1], F[..., 1, 0], F[..., 0, 2], F[..., 2, 0],
+                     F[..., 1, 2], F[..., 2, 1]], axis=-1)
+
+
+def triangle_grid(n, distort=0.2, seed=0):
+    """Unit square cut into 2 n^2 triangles with interior vertices moved randomly: (coords (nv,2), cells (nc,3))."""
+    xs = np.linspace(0.0, 1.0, n + 1)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel()], axis=1)
+    rng = np.random.default_rng(seed)
+    inner = (coords > 1e-12).all(axis=1) & (coords < 1 - 1e-12).all(axis=1)
+    coords[inner] += distort / n * rng.uniform(-1, 1, (int(inner.sum()), 2))
+    idx = lambda i, j: i * (n + 1) + j   # noqa: E731
+    cells = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            cells += [(a, b, c), (a, c, d)]
+    return coords, np.array(cells, dtype=np.int32)

@@ -6,7 +6,8 @@ this module is skipped there; it is the test a maintainer runs after ``pip insta
 Checked: (i) ``QuadratureMap.update()`` drives ``HIPMaterial.integrate`` and the quadrature Functions receive
 the oracle's stress / tangent / state; (ii) ``NonlinearMaterialProblem.solve()`` reproduces the closed-form
 uniaxial answer in 3-D (the analogue of ``tests/mfront/test_elastoplasticity.py:14-36``); (iii)
-``Hex8Mesh.from_dolfinx`` evaluates the same strain at the same Gauss points as the compiled UFL expression."""
+``Hex8Mesh.from_dolfinx`` / ``SimplexMesh.from_dolfinx`` evaluate the same strain at the same Gauss points as the
+compiled UFL expression."""
 import numpy as np
 import pytest
 
@@ -108,4 +109,44 @@ def test_device_gradient_adapter_matches_the_ufl_expression():
     assert dmesh.npoints == eps_ufl.shape[0]
     sig_dev, _, _ = material.integrate_displacement(dmesh, u.x.array)
     sig_ufl = qmap.fluxes["stress"].x.array.reshape(-1, 6)
+    assert np.abs(np.asarray(sig_dev) - sig_ufl).max() < 1e-9 * np.abs(sig_ufl).max()
+
+
+@pytest.mark.parametrize("cell,order", [("tetrahedron", 2), ("tetrahedron", 1), ("triangle", 2)])
+def test_simplex_adapter_matches_the_ufl_expression(cell, order):
+    """`SimplexMesh.from_dolfinx` on the spaces of the reference's demos (P2 on gmsh tetrahedra with quadrature degree 2,
+    finite_strain_elastoplasticity.py:115-117; P2 triangles in plane strain, plane_elastoplasticity.py:96-100): the
+    strain the device evaluates from ``u.x.array`` is the one ``fem.Expression`` tabulates, point for point."""
+    import ufl
+    from dolfinx import fem, mesh
+    from dolfinx_materials.quadrature_map import QuadratureMap
+    from mpi4py import MPI
+
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.gradient import SimplexMesh
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+
+    if cell == "triangle":
+        domain = mesh.create_unit_square(MPI.COMM_WORLD, 4, 4, mesh.CellType.triangle)
+    else:
+        domain = mesh.create_unit_cube(MPI.COMM_WORLD, 3, 3, 3, mesh.CellType.tetrahedron)
+    tdim = domain.topology.dim
+    V = fem.functionspace(domain, ("P", order, (tdim,)))
+    u = fem.Function(V)
+    material = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)))
+    qmap = QuadratureMap(domain, 2, material)
+    e = ufl.sym(ufl.grad(u))
+    r2 = np.sqrt(2.0)
+    if tdim == 2:   # plane strain embedding (plane_elastoplasticity.py:109-114)
+        strain = ufl.as_vector([e[0, 0], e[1, 1], 0.0, r2 * e[0, 1], 0.0, 0.0])
+    else:
+        strain = ufl.as_vector([e[0, 0], e[1, 1], e[2, 2], r2 * e[0, 1], r2 * e[0, 2], r2 * e[1, 2]])
+    qmap.register_gradient("strain", strain)
+    rng = np.random.default_rng(2)
+    u.x.array[:] = 2e-3 * rng.standard_normal(u.x.array.size)
+    qmap.update()
+    sig_ufl = qmap.fluxes["stress"].x.array.reshape(-1, 6)
+    dmesh = SimplexMesh.from_dolfinx(V, 2)
+    assert dmesh.npoints == sig_ufl.shape[0] and dmesh.displacement_size == u.x.array.size
+    sig_dev, _, _ = material.integrate_displacement(dmesh, u.x.array)
     assert np.abs(np.asarray(sig_dev) - sig_ufl).max() < 1e-9 * np.abs(sig_ufl).max()

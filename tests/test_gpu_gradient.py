@@ -1,4 +1,4 @@
-"""GPU: device gradient evaluation (hex8) against a host isoparametric evaluation, and the
+"""GPU: device gradient evaluation (hex8, tet4, Lagrange simplices) against a host evaluation, and the
 displacement-driven integrate against the strain-driven one."""
 import os
 import sys
@@ -150,11 +150,78 @@ def test_tet4_gradient_matches_host_and_drives_the_update():
 KUHN = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]   # hex -> 6 tets along 0-6
 
 
+def _simplex_case(name):
+    """(SimplexMesh, dof coordinates (n_dofs, tdim), host arrays for the checker)."""
+    from dolfinx_materials_amd.gradient import SimplexMesh, lagrange_simplex_table, p2_dofmap, simplex_quadrature
+    from helpers import triangle_grid
+
+    if name.endswith("tri"):
+        coords, cells = triangle_grid(7, seed=3)                       # 98 triangles
+    else:
+        hm, coords = make_mesh(3, distort=0.2, seed=4)
+        cells = np.concatenate([hm.conn[:, list(k)] for k in KUHN], axis=0).astype(np.int32)   # 162 tetrahedra
+    degree = int(name[1])
+    mesh, xd = SimplexMesh.lagrange(coords, cells, degree=degree, quadrature_degree=2)
+    tdim = cells.shape[1] - 1
+    dofmap = cells if degree == 1 else p2_dofmap(cells)[0]
+    dphi = lagrange_simplex_table(tdim, degree, simplex_quadrature(tdim, 2))
+    return mesh, xd, (np.pad(coords, ((0, 0), (0, 3 - coords.shape[1]))), cells, dofmap, dphi)
+
+
+@pytest.mark.parametrize("name", ["p2tet", "p2tri", "p1tet", "p1tri"])
+def test_simplex_gradient_matches_host(name):
+    """dxm_mesh_create_simplex: tet10 x 4 points and tri6 x 3 points (plane strain) of the reference's demos, and the
+    first-order cases, against the numpy evaluation; both gradient kinds."""
+    torch = pytest.importorskip("torch")
+    from helpers import deformation_gradient9, mandel_strain, simplex_host_gradient
+
+    mesh, xd, host = _simplex_case(name)
+    tdim = xd.shape[1]
+    assert mesh.nqp == (3 if tdim == 2 else 4) and mesh.displacement_size == xd.size
+    rng = np.random.default_rng(11)
+    u = (xd * np.array([8e-3, -3e-3, -3e-3][:tdim]) + 1e-3 * rng.standard_normal(xd.shape) + 5e-3 * xd**2).ravel()
+    H = simplex_host_gradient(*host[:3], u, host[3]).reshape(-1, 3, 3)
+    dev = torch.device("cuda:0")
+    ud = torch.from_numpy(u).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for kind, ref in ((0, mandel_strain(H)), (1, deformation_gradient9(H))):
+        out = torch.full((mesh.npoints, ref.shape[1]), float("nan"), dtype=torch.float64, device=dev)
+        mesh.gradient_device(ud.data_ptr(), kind, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-13
+    if name == "p1tet":   # same numbers as the dedicated tet4 kernel
+        from dolfinx_materials_amd.gradient import Tet4Mesh
+
+        t4 = Tet4Mesh(host[0], host[1], nqp=4)
+        o2 = torch.empty((mesh.npoints, 6), dtype=torch.float64, device=dev)
+        t4.gradient_device(ud.data_ptr(), 0, o2.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.abs(o2.cpu().numpy() - mandel_strain(H)).max() < 1e-13
+
+
+def test_simplex_mesh_rejects_bad_input():
+    from dolfinx_materials_amd import _lib
+    from dolfinx_materials_amd.gradient import SimplexMesh, lagrange_simplex_table, simplex_quadrature
+
+    coords = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    cells = np.array([[0, 1, 2, 3]], dtype=np.int32)
+    tab = lagrange_simplex_table(3, 1, simplex_quadrature(3, 1))
+    SimplexMesh(coords, cells, cells, 4, tab).close()
+    flat = coords.copy()
+    flat[3] = [1.0, 1.0, 0.0]
+    with pytest.raises(_lib.DxmError, match="degenerate"):
+        SimplexMesh(flat, cells, cells, 4, tab)
+    with pytest.raises(_lib.DxmError, match="out of range"):
+        SimplexMesh(coords, cells, cells + 1, 4, tab)
+    with pytest.raises(ValueError):
+        SimplexMesh(coords, cells, cells, 4, tab[:, :3])
+
+
 @pytest.mark.parametrize("law", ["elastic", "j2_voce", "j2_linear_sym", "fefp"])
-@pytest.mark.parametrize("cells", ["hex3", "hex5", "tet3x1", "tet4x4", "hex3x27"])
+@pytest.mark.parametrize("cells", ["hex3", "hex5", "tet3x1", "tet4x4", "hex3x27", "p2tet", "p2tri"])
 def test_integrate_displacement_device_equals_gradient_then_update(law, cells):
-    """dxm_integrate_displacement_device (hex8 x 8 points and tet4 meshes: gradient evaluated inside the
-    update kernel, no strain / F array; hex8 with 27 points: two kernels through the handle's scratch)
+    """dxm_integrate_displacement_device (hex8 x 8 points, tet4 and Lagrange-simplex meshes: gradient evaluated inside
+    the update kernel, no strain / F array; hex8 with 27 points: two kernels through the handle's scratch)
     against the explicit sequence dxm_mesh_gradient_device -> dxm_integrate_device, over two increments
     with an advance between."""
     torch = pytest.importorskip("torch")
@@ -162,10 +229,14 @@ def test_integrate_displacement_device_equals_gradient_then_update(law, cells):
     from helpers import E, NU, SIG0_V, SIGU_V, B_V, SIG0_F, SIGU_F, B_F, SIG0_LIN, H_LIN
 
     dev = torch.device("cuda:0")
-    ncell = int(cells[3])
-    hm, coords = make_mesh(ncell)
-    conn = hm.conn
-    if cells.startswith("tet"):
+    if cells.startswith("p2"):
+        mesh, coords, _ = _simplex_case(cells)     # `coords`: the dof positions (n_dofs, tdim)
+    else:
+        hm, coords = make_mesh(int(cells[3]))
+        conn = hm.conn
+    if cells.startswith("p2"):
+        pass
+    elif cells.startswith("tet"):
         tconn = np.concatenate([conn[:, list(k)] for k in KUHN], axis=0).astype(np.int32)
         mesh = Tet4Mesh(coords, tconn, nqp=int(cells.split("x")[1]))   # 162 x 1 and 384 x 4 points
     elif cells.endswith("x27"):
@@ -195,7 +266,7 @@ def test_integrate_displacement_device_equals_gradient_then_update(law, cells):
     fa, fb = torch.empty((n, nf), dtype=torch.float64, device=dev), torch.empty((n, nf), dtype=torch.float64, device=dev)
     ca, cb = torch.empty((n, nt), dtype=torch.float64, device=dev), torch.empty((n, nt), dtype=torch.float64, device=dev)
     for t in (0.6, 1.0):
-        u = t * (coords * np.array([scale, -0.4 * scale, -0.4 * scale]) + rng.standard_normal(coords.shape) * 0.05 * scale)
+        u = t * (coords * np.array([scale, -0.4 * scale, -0.4 * scale][:coords.shape[1]]) + rng.standard_normal(coords.shape) * 0.05 * scale)
         ud = torch.from_numpy(u.ravel().copy()).to(dev)
         mesh.gradient_device(ud.data_ptr(), kind, grad.data_ptr(), st)
         a.integrate_device(grad.data_ptr(), fa.data_ptr(), ca.data_ptr(), st)
@@ -215,18 +286,25 @@ def test_integrate_displacement_device_equals_gradient_then_update(law, cells):
         b.data_manager.update()
 
 
-@pytest.mark.parametrize("law", ["j2", "fefp"])
+@pytest.mark.parametrize("law", ["j2", "fefp", "j2_p2tet", "fefp_p2tet"])
 def test_chunked_host_displacement_path_uses_the_right_cells(law):
     """Above 524288 points the host-buffer form is cut into chunks issued on two streams; with the gradient
     evaluated inside the update kernel every chunk must start at its own point (MeshSource.point0)."""
     torch = pytest.importorskip("torch")
-    m, coords = make_mesh(42)            # 74 088 cells, 592 704 points -> 2 chunks
+    p2 = law.endswith("_p2tet")
+    law = law.split("_")[0]
+    m, coords = make_mesh(28 if p2 else 42)            # hex8: 74 088 cells, 592 704 points -> 2 chunks
+    if p2:                                             # tet10: 131 712 cells x 4 points = 526 848 -> 2 chunks
+        from dolfinx_materials_amd.gradient import SimplexMesh
+
+        tets = np.concatenate([m.conn[:, list(k)] for k in KUHN], axis=0).astype(np.int32)
+        smesh, coords = SimplexMesh.lagrange(coords, tets, degree=2)
     rng = np.random.default_rng(5)
     u = (coords * np.array([8e-3, -3e-3, -3e-3]) + 2e-4 * rng.standard_normal(coords.shape)).ravel()
     el = jm.LinearElasticIsotropic(E=70e3, nu=0.3)
     beh = (jm.vonMisesIsotropicHardening(el, jm.LinearHardening(250.0, 5e3)) if law == "j2"
            else jm.FeFpJ2Plasticity(el, jm.VoceHardening(500.0, 750.0, 1000.0)))
-    mesh = Hex8Mesh(coords, m.conn)
+    mesh = smesh if p2 else Hex8Mesh(coords, m.conn)
     n = mesh.npoints
     assert n > 2 * 262144
     a, b = JAXMaterial(beh), JAXMaterial(beh)

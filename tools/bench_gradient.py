@@ -2,7 +2,7 @@
 """Device-side cost of the step before the hot path: displacement vector -> gradient at the Gauss
 points (gradient.hpp), alone and followed by the constitutive kernel, on a structured hex8 mesh.
 
-    python tools/bench_gradient.py [--cells 108] [--law j2_linear|fefp]
+    python tools/bench_gradient.py [--cells 108] [--law j2_linear|fefp] [--tet NQP | --p2tet]
 """
 import argparse
 import json
@@ -47,11 +47,14 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--tet", type=int, default=0, metavar="NQP",
                     help="split every hexahedron into 6 linear tetrahedra with NQP Gauss points each")
+    ap.add_argument("--p2tet", action="store_true",
+                    help="6 straight-sided tetrahedra per hexahedron with a P2 displacement and 4 Gauss points each (tet10: "
+                         "the space of the reference's finite-strain demo)")
     a = ap.parse_args()
     import torch
 
     import dolfinx_materials_amd.materials as jm
-    from dolfinx_materials_amd.gradient import Hex8Mesh, Tet4Mesh
+    from dolfinx_materials_amd.gradient import Hex8Mesh, SimplexMesh, Tet4Mesh
     from dolfinx_materials_amd.jaxmat import JAXMaterial
     from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_F, SIGU_F, B_F
 
@@ -59,8 +62,10 @@ def main():
     coords, conn = box_mesh(a.cells)
     rng = np.random.default_rng(0)
     coords[:, :] += rng.uniform(-0.2, 0.2, coords.shape) / a.cells  # distorted cells: nothing special-cased
-    if a.tet:
-        kuhn = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]
+    kuhn = [(0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6)]
+    if a.p2tet:
+        mesh, coords = SimplexMesh.lagrange(coords, np.concatenate([conn[:, list(k)] for k in kuhn], axis=0).astype(np.int32), degree=2)
+    elif a.tet:
         mesh = Tet4Mesh(coords, np.concatenate([conn[:, list(k)] for k in kuhn], axis=0).astype(np.int32), nqp=a.tet)
     else:
         mesh = Hex8Mesh(coords, conn)
@@ -94,7 +99,7 @@ def main():
     same = bool(torch.equal(flux, flux2)) and bool(torch.equal(ct, ct2))
     dmax = float((flux - flux2).abs().max())
     rc, stats = m.stats()
-    print(json.dumps({"mesh": f"tet4 x {a.tet}" if a.tet else "hex8 x 8", "cells": mesh.n_cells, "points": n, "nodes": len(coords), "law": a.law,
+    print(json.dumps({"mesh": "tet10 x 4" if a.p2tet else f"tet4 x {a.tet}" if a.tet else "hex8 x 8", "cells": mesh.n_cells, "points": n, "dofs": len(coords), "law": a.law,
                       "gradient_ms": round(t_grad, 4), "law_ms": round(t_law, 4), "both_ms": round(t_both, 4), "integrate_displacement_device_ms": round(t_one_call, 4),
                       "same_result_as_two_kernels": same, "max_abs_flux_diff": dmax,
                       "gradient_write_GBs": round(n * ng * 8 / t_grad / 1e6, 1),
