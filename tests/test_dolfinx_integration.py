@@ -137,7 +137,7 @@ def test_simplex_adapter_matches_the_ufl_expression(cell, order):
     qmap = QuadratureMap(domain, 2, material)
     e = ufl.sym(ufl.grad(u))
     r2 = np.sqrt(2.0)
-    if tdim == 2:   # plane strain embedding (plane_elastoplasticity.py:109-114)
+    if tdim == 2:   # plane strain embedding (plane_elastoplasticity.py:114-124)
         strain = ufl.as_vector([e[0, 0], e[1, 1], 0.0, r2 * e[0, 1], 0.0, 0.0])
     else:
         strain = ufl.as_vector([e[0, 0], e[1, 1], e[2, 2], r2 * e[0, 1], r2 * e[0, 2], r2 * e[1, 2]])
