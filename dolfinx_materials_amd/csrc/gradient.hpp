@@ -231,7 +231,7 @@ __device__ __forceinline__ void tet4_cell_disp_grad(const double* __restrict__ c
 }
 
 // Lagrange element of any order on a straight-sided simplex: the geometry map is affine (vertices only), so
-//   H[i][a] = sum_m u_m[i] * sum_d dphi[q][m][d] * Ai[d][a],   Ai = inverse of the edge matrix,
+//   H[i][a] = sum_d (sum_m u_m[i] dphi[q][m][d]) Ai[d][a],   Ai = inverse of the edge matrix,
 // with dphi the tabulated reference derivatives (what basix hands out as element.tabulate(1, points)[1:]).
 // tdim = 2: u has two components per dof, H is embedded in 3x3 with zeros (plane strain: eps_zz = 0, F_zz = 1).
 // Every lane gathers its own cell; the nqp lanes of a cell ask for the same addresses (merged by the
@@ -273,33 +273,34 @@ __device__ __forceinline__ void simplex_disp_grad(const MeshSource& s, const int
     Ai[0] = a11 * idet; Ai[1] = -a01 * idet;
     Ai[3] = -a10 * idet; Ai[4] = a00 * idet;
   }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) H[k] = 0.0;
+  // B[i][d] = sum_m u_m[i] dphi[q][m][d] (du_i / dxi_d: 9 fused multiply-adds per dof), then H = B Ai once
+  double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int32_t* dofs = s.dofmap + cell * s.nd;
   const double* tab = s.dphi + (int64_t)q * s.nd * s.tdim;
   if (s.tdim == 3) {
+#pragma unroll 2
     for (int m = 0; m < s.nd; ++m) {
       const int64_t dof = dofs[m];
       const double t0 = tab[3 * m], t1 = tab[3 * m + 1], t2 = tab[3 * m + 2];
       const double U0 = s.u[3 * dof], U1 = s.u[3 * dof + 1], U2 = s.u[3 * dof + 2];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double g = t0 * Ai[a] + t1 * Ai[3 + a] + t2 * Ai[6 + a];
-        H[a] += U0 * g; H[3 + a] += U1 * g; H[6 + a] += U2 * g;
-      }
+      B[0] += U0 * t0; B[1] += U0 * t1; B[2] += U0 * t2;
+      B[3] += U1 * t0; B[4] += U1 * t1; B[5] += U1 * t2;
+      B[6] += U2 * t0; B[7] += U2 * t1; B[8] += U2 * t2;
     }
   } else {
+#pragma unroll 2
     for (int m = 0; m < s.nd; ++m) {
       const int64_t dof = dofs[m];
       const double t0 = tab[2 * m], t1 = tab[2 * m + 1];
       const double U0 = s.u[2 * dof], U1 = s.u[2 * dof + 1];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const double g = t0 * Ai[a] + t1 * Ai[3 + a];
-        H[a] += U0 * g; H[3 + a] += U1 * g;
-      }
+      B[0] += U0 * t0; B[1] += U0 * t1;
+      B[3] += U1 * t0; B[4] += U1 * t1;
     }
   }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) H[i * 3 + a] = B[i * 3] * Ai[a] + B[i * 3 + 1] * Ai[3 + a] + B[i * 3 + 2] * Ai[6 + a];
 }
 
 template <int KIND>
