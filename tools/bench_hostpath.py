@@ -7,7 +7,10 @@ Modes:  r01      full 36-entry tangent and the ISVs downloaded in every call (ro
                  option packed_transfer = 0, lazy_isv = False), 440 B/point over PCIe;
         packed   the 9 tangent coefficients moved and the 6x6 block rebuilt on the host, ISVs on
                  demand (default), 168 B/point;
-        bound    packed + results delivered straight into caller-owned arrays (bind_outputs)."""
+        bound    packed + results delivered straight into caller-owned arrays (bind_outputs);
+        coef     the caller takes the 9 coefficients themselves (tangent_layout="coef"): the transfer pipeline alone;
+        pinned_in  bound + the strain array handed over in page-locked memory (what a caller that owns its gradient
+                 buffer can do; QuadratureMap's gather makes a fresh pageable array per call)."""
 import argparse
 import json
 import os
@@ -28,18 +31,24 @@ def run(n, mode, reps, threads=None):
 
     h = j2_history(n)
     m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)),
-                    lazy_isv=(mode != "r01"))
+                    lazy_isv=(mode != "r01"), tangent_layout="coef" if mode == "coef" else "full")
     m.set_data_manager(n)
     if mode == "r01":
         m.set_option("packed_transfer", 0)
         m.set_option("max_chunks", 8)
     if threads:
         m.set_option("host_threads", threads)
-    if mode == "bound":
+    if mode in ("bound", "pinned_in"):
         flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
         m.bind_outputs(flux=flux_fn, tangent=jac_fn)
     m.integrate(h[1])
     m.data_manager.update()
+    if mode == "pinned_in":
+        from dolfinx_materials_amd._lib import PinnedArray
+
+        pin = PinnedArray(h[2].shape)
+        pin.array[:] = h[2]
+        h[2] = pin.array
     m.integrate(h[2])
     ts = []
     for _ in range(reps):
