@@ -297,6 +297,16 @@ def live_traffic(args, kernel_prefix="small_strain_kernel<1"):
                               "hbm_read_bytes": read_b, "hbm_write_bytes": write_b, "launches_sampled": means["FETCH_SIZE"][1]}
 
 
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def launch_ranks(args, argv):
     """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves.
 
@@ -305,13 +315,9 @@ def launch_ranks(args, argv):
     ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` would hand them; rank 0 prints
     the JSON line on the inherited stdout.  A rank that fails takes the others down with it (they
     would otherwise wait in the rendezvous) and the exit code is that rank's."""
-    import socket
     import subprocess
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
@@ -351,6 +357,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and the gloo backend (exercises the N > 1 path on a 1-GPU box; "
                          "same as DXM_BENCH_SHARE_GPU=1; never for reported numbers)")
+    ap.add_argument("--single-rank-group", action="store_true",
+                    help="debug, --gpus 1 only: join an RCCL process group of one rank and run the gather legs through it "
+                         "(the device-tensor collectives of the N > 1 path on a 1-GPU box; never for reported numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true",
                     help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
@@ -393,8 +402,15 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # --single-rank-group (debug): an RCCL group of ONE rank on a 1-GPU box, so that the device-tensor collectives of the
+    # N > 1 path (all_gather_into_tensor, the p2p schedule, the coefficient gather + rebuild) run through RCCL itself
+    grouped = world > 1 or args.single_rank_group
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group("gloo")
         else:
@@ -463,7 +479,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -512,7 +528,7 @@ def main():
 
     gather = None
     group_info = None
-    if world > 1:
+    if grouped:
         cdev = torch.device("cpu") if share else dev  # gloo debug mode keeps collectives on the host
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -524,7 +540,7 @@ def main():
                       "ranks_counted_by_all_reduce": int(seen.item()),
                       "launcher": os.environ.get("DXM_BENCH_LAUNCHER", "torch.distributed.run"),
                       "share_gpu_debug_mode": bool(share)}
-    if world > 1 and not args.no_gather:
+    if grouped and not args.no_gather:
         # gather-inclusive variant: reassemble stress and tangent on every rank over xGMI.  Context
         # for cfg 3 only: a failure here (e.g. not enough HBM for the gathered buffers when the GPUs
         # are shared) must never lose the headline line, so it is reported instead of raised.
@@ -684,7 +700,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), seed)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -145,3 +145,24 @@ def test_coefficient_gather_payload_is_rebuilt_bit_for_bit_on_the_device(gpu_ava
         full.data_manager.update()
         coef.data_manager.update()
     assert full.stats()[1]["n_plastic"] == 0 and float(c9[:, 2].abs().max()) == 0.0   # last increment unloads
+
+
+def test_gather_legs_run_through_rccl_itself_in_a_group_of_one(gpu_available):
+    """RCCL refuses two ranks on one device, so the 2-rank tests above use gloo; here the SAME calls (all_gather_into_tensor
+    on device tensors, the p2p schedule, the coefficient gather + dxm_expand_tangent_device) go through the `nccl` backend
+    in a process group of one rank -- what a 1-GPU box can verify of the N > 1 data path before an 8-GPU node runs it."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "DXM_BENCH_SHARE_GPU")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-rank-group", "--points", "300000",
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-other-laws", "--no-host-path", "--no-live-traffic",
+                        "--gather-steps", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    pg, g = out["process_group"], out["gather_inclusive"]
+    assert pg["backend"] == "nccl" and pg["ranks_in_group"] == 1 and pg["ranks_counted_by_all_reduce"] == 1
+    assert "error" not in g and g["value"] > 0
+    assert "error" not in g["p2p_schedule"] and g["p2p_schedule"]["value"] > 0
+    assert "error" not in g["coefficient_gather"] and g["coefficient_gather"]["value"] > 0
+    assert out["n_gpus"] == 1 and out["value"] >= g["value"]
