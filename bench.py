@@ -544,11 +544,21 @@ def main():
         # gather-inclusive variant: reassemble stress and tangent on every rank over xGMI.  Context
         # for cfg 3 only: a failure here (e.g. not enough HBM for the gathered buffers when the GPUs
         # are shared) must never lose the headline line, so it is reported instead of raised.
+        # device tensors: the kernels write straight into this rank's rows of the gathered arrays and the gathers are
+        # in place (no local copy); the gloo debug mode gathers host copies
+        inplace = not share
+
         def timed_gather(fn, G):
             def gstep(i):
-                step(i)
-                fn(flux.to(cdev), plan, out=g_flux)
-                fn(ct.to(cdev), plan, out=g_ct)
+                if inplace:
+                    j = i % 3
+                    mats[j].integrate_device(eps[j + 1].data_ptr(), my_flux.data_ptr(), my_ct.data_ptr(), stream)
+                    fn(my_flux, plan, out=g_flux)
+                    fn(my_ct, plan, out=g_ct)
+                else:
+                    step(i)
+                    fn(flux.to(cdev), plan, out=g_flux)
+                    fn(ct.to(cdev), plan, out=g_ct)
 
             gstep(0)
             barrier()
@@ -565,9 +575,10 @@ def main():
             plan = ShardPlan(n * world, world)
             g_flux = torch.empty((n * world, 6), dtype=torch.float64, device=cdev)
             g_ct = torch.empty((n * world, 36), dtype=torch.float64, device=cdev)
+            my_flux, my_ct = plan.local_view(g_flux, rank), plan.local_view(g_ct, rank)
             G = max(1, args.gather_steps)
             gather = timed_gather(allgather_rows, G)
-            gather["collective"] = ("RCCL" if not share else "gloo (debug)") + " all_gather_into_tensor of stress (N,6) and tangent (N,36), fp64"
+            gather["collective"] = ("RCCL in-place" if not share else "gloo (debug)") + " all_gather_into_tensor of stress (N,6) and tangent (N,36), fp64"
             gather["bytes_received_per_rank"] = int((world - 1) * n * 42 * 8)
             gather["link_GBs_per_rank"] = round(gather["bytes_received_per_rank"] / (gather["ms_per_step"] * 1e-3) / 1e9, 1)
         except Exception as exc:
@@ -594,11 +605,18 @@ def main():
                     cmats.append(m)
                 coef_all = torch.empty((n * world, 9), dtype=torch.float64, device=cdev)
 
+                my_c9 = plan.local_view(coef_all, rank)
+
                 def cstep(i):
                     j = i % 3
-                    cmats[j].integrate_device(eps[j + 1].data_ptr(), flux.data_ptr(), ct9.data_ptr(), stream)
-                    allgather_rows(flux.to(cdev), plan, out=g_flux)
-                    allgather_tangent(ct9.to(cdev), plan, out=g_ct, coef_all=coef_all)
+                    if inplace:
+                        cmats[j].integrate_device(eps[j + 1].data_ptr(), my_flux.data_ptr(), my_c9.data_ptr(), stream)
+                        allgather_rows(my_flux, plan, out=g_flux)
+                        allgather_tangent(my_c9, plan, out=g_ct, coef_all=coef_all)
+                    else:
+                        cmats[j].integrate_device(eps[j + 1].data_ptr(), flux.data_ptr(), ct9.data_ptr(), stream)
+                        allgather_rows(flux.to(cdev), plan, out=g_flux)
+                        allgather_tangent(ct9.to(cdev), plan, out=g_ct, coef_all=coef_all)
 
                 cstep(0)
                 barrier()

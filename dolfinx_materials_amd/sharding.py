@@ -45,14 +45,25 @@ class ShardPlan:
     def max_count(self):
         return max(self.count(r) for r in range(self.world_size))
 
+    def local_view(self, full: torch.Tensor, rank: int) -> torch.Tensor:
+        """Rank ``rank``'s rows of a gathered ``(n_total, dim)`` array.  A kernel that writes its output THERE
+        (``integrate_device(..., flux_ptr=view.data_ptr())``) makes the gathers below in-place: no local copy."""
+        lo, hi = self.range(rank)
+        return full[lo:hi]
+
+
+def _is_own_block(local: torch.Tensor, out: torch.Tensor | None, lo: int, hi: int) -> bool:
+    return out is not None and hi > lo and local.is_contiguous() and local.data_ptr() == out[lo:hi].data_ptr()
+
 
 def allgather_rows(local: torch.Tensor, plan: ShardPlan, out: torch.Tensor | None = None,
                    scratch: torch.Tensor | None = None, group=None) -> torch.Tensor:
     """All-gather row blocks of unequal length into ``out`` of shape ``(n_total, dim)``.
 
     Equal shards use one ``all_gather_into_tensor`` straight into ``out`` (a single large
-    collective: xGMI is point-to-point, so few big messages beat many small ones).  Ragged
-    shards are padded to ``max_count`` rows in ``scratch`` and compacted afterwards.
+    collective: xGMI is point-to-point, so few big messages beat many small ones); when ``local`` already IS this
+    rank's rows of ``out`` (:meth:`ShardPlan.local_view`) that is the in-place form of the collective and nothing is
+    copied locally.  Ragged shards are padded to ``max_count`` rows in ``scratch`` and compacted afterwards.
     """
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
@@ -91,7 +102,8 @@ def allgather_rows_p2p(local: torch.Tensor, plan: ShardPlan, out: torch.Tensor |
     assert local.shape[0] == hi - lo
     if out is None:
         out = torch.empty((plan.n_total, dim), dtype=local.dtype, device=local.device)
-    out[lo:hi] = local
+    if not _is_own_block(local, out, lo, hi):
+        out[lo:hi] = local
     src = local.contiguous()
     ops = []
     b = plan.bounds

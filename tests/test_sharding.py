@@ -49,6 +49,13 @@ def _worker(rank, world, port, n, q):
         sig2 = allgather_rows_p2p(torch.from_numpy(r["sig"]), plan)
         ct2 = allgather_rows_p2p(torch.from_numpy(r["Ct"].reshape(-1, 36)), plan)
         assert torch.equal(sig, sig2) and torch.equal(ct, ct2)
+        # in-place form: the producer writes into its own rows of the gathered array (ShardPlan.local_view)
+        for gather in (allgather_rows, allgather_rows_p2p):
+            full = torch.full((n, 36), float("nan"), dtype=torch.float64)
+            mine = plan.local_view(full, rank)
+            mine.copy_(torch.from_numpy(r["Ct"].reshape(-1, 36)))
+            got = gather(mine, plan, out=full)
+            assert got.data_ptr() == full.data_ptr() and torch.equal(full, ct)
         # coefficient form: 9 instead of 36 doubles per point on the wire, rebuilt locally
         one = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
         nrm = np.zeros((hi - lo, 6))                            # (c1, c2, c3, n) from the oracle's pieces
