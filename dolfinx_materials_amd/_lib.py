@@ -106,6 +106,10 @@ SYMBOLS = {
     "dxm_mesh_npoints": (C.c_int64, [_h]),
     "dxm_mesh_displacement_size": (C.c_int64, [_h]),
     "dxm_mesh_gradient_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dxm_mesh_set_weights": (C.c_int, [_h, C.c_void_p]),
+    "dxm_mesh_internal_force_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dxm_mesh_tangent_apply_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dxm_mesh_tangent_diagonal_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dxm_integrate_displacement": (
         C.c_int,
         [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],

@@ -1095,6 +1095,11 @@ struct dxm_mesh {
   int64_t n_dofs = 0;
   int32_t* d_dofmap = nullptr;
   double* d_dphi = nullptr;
+  // assembly-side consumers (hex8 x 8 points): quadrature weights, element scratch, node -> (cell, corner) table
+  double w[27];
+  double* d_fe = nullptr;
+  int64_t* d_node_ptr = nullptr;
+  int32_t* d_node_adj = nullptr;
 };
 
 static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, const int32_t* conn,
@@ -1117,6 +1122,7 @@ static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, con
   mesh->n_cells = n_cells;
   mesh->u_len = 3 * n_nodes;
   mesh->qp.nqp = nqp;
+  for (int q = 0; q < 27; ++q) mesh->w[q] = 1.0;   // 2x2x2 Gauss-Legendre on [-1,1]^3; dxm_mesh_set_weights otherwise
   if (qpoints)
     for (int q = 0; q < nqp; ++q)
       for (int d = 0; d < 3; ++d) mesh->qp.xi[q][d] = qpoints[3 * q + d];
@@ -1212,6 +1218,9 @@ int dxm_mesh_destroy(dxm_mesh* mesh) {
   if (mesh->d_u) (void)hipFree(mesh->d_u);
   if (mesh->d_dofmap) (void)hipFree(mesh->d_dofmap);
   if (mesh->d_dphi) (void)hipFree(mesh->d_dphi);
+  if (mesh->d_fe) (void)hipFree(mesh->d_fe);
+  if (mesh->d_node_ptr) (void)hipFree(mesh->d_node_ptr);
+  if (mesh->d_node_adj) (void)hipFree(mesh->d_node_adj);
   if (mesh->grad_done) (void)hipEventDestroy(mesh->grad_done);
   delete mesh;
   return 0;
@@ -1257,6 +1266,79 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
   }
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+// ---- assembly-side consumers on the device (gradient.hpp: hex8_element_kernel + node_gather_kernel) ------------
+int dxm_mesh_set_weights(dxm_mesh* mesh, const double* weights) {
+  if (!mesh || !weights) return fail(-1, "null argument");
+  if (mesh->nodes_per_cell != 8) return fail(-1, "quadrature weights are used by the hex8 operators only");
+  for (int q = 0; q < mesh->qp.nqp; ++q) mesh->w[q] = weights[q];
+  return 0;
+}
+
+// scratch for the element values and the node -> (cell, corner) table (counting sort of the connectivity), on first use
+static int ensure_operator_buffers(dxm_mesh* mesh) {
+  if (mesh->nodes_per_cell != 8 || mesh->qp.nqp != 8)
+    return fail(-1, "the device operators need a hex8 mesh with 8 Gauss points per cell");
+  if (mesh->d_fe) return 0;
+  const int64_t ne = mesh->n_cells * 8;
+  if (ne > INT32_MAX) return fail(-1, "too many cells for the 32-bit (cell, corner) table");
+  std::vector<int32_t> conn((size_t)ne);
+  HIP_TRY(hipMemcpy(conn.data(), mesh->d_conn, sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
+  std::vector<int64_t> ptr((size_t)mesh->n_nodes + 1, 0);
+  for (int64_t k = 0; k < ne; ++k) ++ptr[(size_t)conn[k] + 1];
+  for (int64_t v = 0; v < mesh->n_nodes; ++v) ptr[v + 1] += ptr[v];
+  std::vector<int32_t> adj((size_t)ne);
+  {
+    std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t k = 0; k < ne; ++k) adj[(size_t)fill[conn[k]]++] = (int32_t)k;   // ascending k per node: fixed summation order
+  }
+  HIP_TRY(hipMalloc(&mesh->d_node_ptr, sizeof(int64_t) * (mesh->n_nodes + 1)));
+  HIP_TRY(hipMalloc(&mesh->d_node_adj, sizeof(int32_t) * ne));
+  HIP_TRY(hipMemcpy(mesh->d_node_ptr, ptr.data(), sizeof(int64_t) * (mesh->n_nodes + 1), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(mesh->d_node_adj, adj.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&mesh->d_fe, sizeof(double) * ne * 3));
+  return 0;
+}
+
+static int run_operator(int op, dxm_mesh* mesh, const double* field, int layout, const double* x, double* y, hipStream_t st) {
+  if (int rc = ensure_operator_buffers(mesh)) return rc;
+  HexOperatorArgs a{};
+  a.coords = mesh->d_coords; a.conn = mesh->d_conn; a.x = x; a.field = field; a.ncells = mesh->n_cells; a.layout = layout;
+  for (int q = 0; q < 8; ++q) {
+    for (int d = 0; d < 3; ++d) a.xi[q][d] = mesh->qp.xi[q][d];
+    a.w[q] = mesh->w[q];
+  }
+  const int blocks = (int)((mesh->n_cells + HEX_OP_CELLS - 1) / HEX_OP_CELLS);
+  if (op == OP_FORCE) hipLaunchKernelGGL(hex8_element_kernel<OP_FORCE>, dim3(blocks), dim3(256), 0, st, a, mesh->d_fe);
+  else if (op == OP_APPLY) hipLaunchKernelGGL(hex8_element_kernel<OP_APPLY>, dim3(blocks), dim3(256), 0, st, a, mesh->d_fe);
+  else hipLaunchKernelGGL(hex8_element_kernel<OP_DIAGONAL>, dim3(blocks), dim3(256), 0, st, a, mesh->d_fe);
+  hipLaunchKernelGGL(node_gather_kernel, dim3((int)((mesh->n_nodes + 255) / 256)), dim3(256), 0, st, mesh->n_nodes,
+                     mesh->d_node_ptr, mesh->d_node_adj, mesh->d_fe, y);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dxm_mesh_internal_force_device(dxm_mesh* mesh, const double* flux_dev, double* f_dev, void* hip_stream) {
+  if (!mesh || !flux_dev || !f_dev) return fail(-1, "null argument");
+  DEVICE_GUARD(mesh);
+  return run_operator(OP_FORCE, mesh, flux_dev, 0, nullptr, f_dev, (hipStream_t)hip_stream);
+}
+
+int dxm_mesh_tangent_apply_device(dxm_mesh* mesh, const double* ct_dev, int layout, const double* x_dev, double* y_dev,
+                                  void* hip_stream) {
+  if (!mesh || !ct_dev || !x_dev || !y_dev) return fail(-1, "null argument");
+  if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_COEF)
+    return fail(-1, "tangent layout must be DXM_TANGENT_FULL or DXM_TANGENT_COEF");
+  if (x_dev == y_dev) return fail(-1, "x and y must not alias");
+  DEVICE_GUARD(mesh);
+  return run_operator(OP_APPLY, mesh, ct_dev, layout, x_dev, y_dev, (hipStream_t)hip_stream);
+}
+
+int dxm_mesh_tangent_diagonal_device(dxm_mesh* mesh, const double* coef_dev, double* d_dev, void* hip_stream) {
+  if (!mesh || !coef_dev || !d_dev) return fail(-1, "null argument");
+  DEVICE_GUARD(mesh);
+  return run_operator(OP_DIAGONAL, mesh, coef_dev, DXM_TANGENT_COEF, nullptr, d_dev, (hipStream_t)hip_stream);
 }
 
 // kind of in-kernel gradient evaluation this mesh allows: 1 hex8 x 8 points, 2 tet4, 3 Lagrange simplex, 0 none

@@ -185,6 +185,185 @@ hex8_gradient_staged_kernel(const double* __restrict__ coords, const int32_t* __
   hex8_point<KIND>(qp.xi[q][0], qp.xi[q][1], qp.xi[q][2], node, grad + gid * (KIND == 0 ? 6 : 9));
 }
 
+// ---- assembly-side consumers on the device (hex8 with 8 Gauss points per cell, small strain) -----------------
+// What dolfinx assembly does with the quadrature Functions after QuadratureMap.update (the residual form
+// `dot(sig, strain(v)) * dx` and its derivative, tests/uniaxial_tension.py:62-67, quadrature_map.py:132-158),
+// restated matrix-free for a caller that keeps everything on the GPU:
+//   OP_FORCE     f  = sum_q w detJ  B_q^T sigma_q                        (internal force from the stress array)
+//   OP_APPLY     y  = sum_q w detJ  B_q^T Ct_q B_q x                     (tangent operator times a vector)
+//   OP_DIAGONAL  d  = diag( sum_q w detJ  B_q^T Ct_q B_q )               (Jacobi preconditioner)
+// with Ct either the nine coefficients of Ct = c1 1x1 + c2 I + c3 n x n (TL_COEF, 72 B/point) or the full block.
+// Two deterministic passes, no atomics: hex8_element_kernel writes the 24 element values of every cell
+// (lane (cell, q) evaluates its Gauss point and leaves inverse Jacobian + weighted stress in LDS, lane (cell, corner)
+// then sums B^T over the cell's 8 points), node_gather_kernel adds up the <= 8 element contributions of every node
+// through a node -> (cell, corner) table.
+enum { OP_FORCE = 0, OP_APPLY = 1, OP_DIAGONAL = 2 };
+struct HexOperatorArgs {
+  const double* coords;
+  const int32_t* conn;
+  const double* x;       // OP_APPLY: nodal vector (n_nodes * 3)
+  const double* field;   // OP_FORCE: stress (npoints, 6) Mandel; otherwise the tangent in `layout`
+  int64_t ncells;
+  int32_t layout;        // 0 full (npoints, 36), 2 coefficients (npoints, 9)
+  double xi[8][3];
+  double w[8];
+};
+constexpr int HEX_OP_CELLS = 32;    // cells per 256-thread block
+constexpr int HEX_OP_PT = 21;       // doubles per Gauss-point record (Ji 9, stress 6 | coefficients 9, w detJ): odd stride
+
+template <int OP>
+__global__ void __launch_bounds__(256)
+hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells, 8, 3) */) {
+  __shared__ __attribute__((aligned(16))) double lds[256 * HEX_OP_PT];
+  const int lane8 = threadIdx.x & 7, cl = threadIdx.x >> 3;
+  const int64_t cell = (int64_t)blockIdx.x * HEX_OP_CELLS + cl;
+  const bool live = cell < a.ncells;
+  // ---- stage the nodes of the block's cells: one (cell, corner) per thread
+  {
+    double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
+    if (live) {
+      const int64_t nd = a.conn[cell * 8 + lane8];
+      r0 = double2_t{a.coords[3 * nd], a.coords[3 * nd + 1]};
+      r1.x = a.coords[3 * nd + 2];
+      if constexpr (OP == OP_APPLY) { r1.y = a.x[3 * nd]; r2 = double2_t{a.x[3 * nd + 1], a.x[3 * nd + 2]}; }
+    }
+    double2_t* d = reinterpret_cast<double2_t*>(lds + cl * HEX_STAGE_REC + lane8 * 6);
+    d[0] = r0; d[1] = r1; d[2] = r2;
+  }
+  __syncthreads();
+  // ---- phase A: lane (cell, q) -- inverse Jacobian, w detJ and the (weighted) stress-like tensor of its point
+  double rec[HEX_OP_PT];
+  {
+    const double2_t* nrec = reinterpret_cast<const double2_t*>(lds + cl * HEX_STAGE_REC);
+    const double x = a.xi[lane8][0], y = a.xi[lane8][1], z = a.xi[lane8][2];
+    double Jm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int m = 0; m < 8; ++m) {
+      double dN[3];
+      hex8_dN(m, x, y, z, dN);
+      const double2_t p0 = nrec[m * 3], p1 = nrec[m * 3 + 1];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { Jm[d] += p0.x * dN[d]; Jm[3 + d] += p0.y * dN[d]; Jm[6 + d] += p1.x * dN[d]; }
+    }
+    const double c00 = Jm[4] * Jm[8] - Jm[5] * Jm[7], c01 = Jm[5] * Jm[6] - Jm[3] * Jm[8], c02 = Jm[3] * Jm[7] - Jm[4] * Jm[6];
+    const double det = Jm[0] * c00 + Jm[1] * c01 + Jm[2] * c02;
+    const double idet = live ? 1.0 / det : 0.0;
+    double* Ji = rec;
+    Ji[0] = c00 * idet; Ji[3] = c01 * idet; Ji[6] = c02 * idet;
+    Ji[1] = (Jm[2] * Jm[7] - Jm[1] * Jm[8]) * idet;
+    Ji[4] = (Jm[0] * Jm[8] - Jm[2] * Jm[6]) * idet;
+    Ji[7] = (Jm[1] * Jm[6] - Jm[0] * Jm[7]) * idet;
+    Ji[2] = (Jm[1] * Jm[5] - Jm[2] * Jm[4]) * idet;
+    Ji[5] = (Jm[2] * Jm[3] - Jm[0] * Jm[5]) * idet;
+    Ji[8] = (Jm[0] * Jm[4] - Jm[1] * Jm[3]) * idet;
+    const double wdet = live ? a.w[lane8] * det : 0.0;
+    const int64_t pt = cell * 8 + lane8;
+    const double r = 0.70710678118654752440;
+    if constexpr (OP == OP_DIAGONAL) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) rec[9 + k] = live ? a.field[pt * 9 + k] : 0.0;
+      rec[18] = wdet;
+    } else {
+      double s[6] = {0, 0, 0, 0, 0, 0};
+      if constexpr (OP == OP_FORCE) {
+        if (live) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s[k] = a.field[pt * 6 + k];
+        }
+      } else {
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+        for (int m = 0; m < 8; ++m) {
+          double dN[3], g[3];
+          hex8_dN(m, x, y, z, dN);
+          const double2_t p1 = nrec[m * 3 + 1], p2 = nrec[m * 3 + 2];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) g[c] = dN[0] * Ji[c] + dN[1] * Ji[3 + c] + dN[2] * Ji[6 + c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { H[c] += p1.y * g[c]; H[3 + c] += p2.x * g[c]; H[6 + c] += p2.y * g[c]; }
+        }
+        const double e[6] = {H[0], H[4], H[8], r * (H[1] + H[3]), r * (H[2] + H[6]), r * (H[5] + H[7])};
+        if (live) {
+          if (a.layout == 2) {
+            const double* cf = a.field + pt * 9;
+            const double k1 = cf[0], k2 = cf[1], k3 = cf[2];
+            const double tr = e[0] + e[1] + e[2];
+            double nd = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nd += cf[3 + k] * e[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s[k] = k2 * e[k] + (k3 * nd) * cf[3 + k] + (k < 3 ? k1 * tr : 0.0);
+          } else {
+            const double* ct = a.field + pt * 36;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              double acc = 0.0;
+#pragma unroll
+              for (int j = 0; j < 6; ++j) acc += ct[i * 6 + j] * e[j];
+              s[i] = acc;
+            }
+          }
+        }
+      }
+      // symmetric tensor, weighted: [xx, yy, zz, xy, xz, yz]
+      rec[9] = wdet * s[0]; rec[10] = wdet * s[1]; rec[11] = wdet * s[2];
+      rec[12] = wdet * r * s[3]; rec[13] = wdet * r * s[4]; rec[14] = wdet * r * s[5];
+    }
+  }
+  __syncthreads();   // everybody is done with the node records: the region becomes the point records
+  {
+    double* dst = lds + threadIdx.x * HEX_OP_PT;
+    constexpr int NW = OP == OP_DIAGONAL ? 19 : 15;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) dst[k] = rec[k];
+  }
+  __syncthreads();
+  // ---- phase B: lane (cell, corner m) sums over the cell's 8 points
+  double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 2
+  for (int q = 0; q < 8; ++q) {
+    const double* pr = lds + (cl * 8 + q) * HEX_OP_PT;   // the 8 lanes of a cell read the same record: broadcast
+    double dN[3], g[3];
+    hex8_dN(lane8, a.xi[q][0], a.xi[q][1], a.xi[q][2], dN);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = dN[0] * pr[c] + dN[1] * pr[3 + c] + dN[2] * pr[6 + c];
+    if constexpr (OP == OP_DIAGONAL) {
+      const double k1 = pr[9], k2 = pr[10], k3 = pr[11], wd = pr[18];
+      const double r = 0.70710678118654752440;
+      const double gg = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+      // unit displacement of this node in direction i: eps = sym(e_i (x) g); |eps|^2 = (g_i^2 + |g|^2) / 2, tr = g_i
+      const double n0 = pr[12], n1 = pr[13], n2 = pr[14], n3 = pr[15], n4 = pr[16], n5 = pr[17];
+      const double ne[3] = {n0 * g[0] + r * (n3 * g[1] + n4 * g[2]), n1 * g[1] + r * (n3 * g[0] + n5 * g[2]),
+                            n2 * g[2] + r * (n4 * g[0] + n5 * g[1])};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        acc[i] += wd * (k1 * g[i] * g[i] + k2 * 0.5 * (g[i] * g[i] + gg) + k3 * ne[i] * ne[i]);
+    } else {
+      acc[0] += pr[9] * g[0] + pr[12] * g[1] + pr[13] * g[2];
+      acc[1] += pr[12] * g[0] + pr[10] * g[1] + pr[14] * g[2];
+      acc[2] += pr[13] * g[0] + pr[14] * g[1] + pr[11] * g[2];
+    }
+  }
+  if (live) {
+    double* o = fe + (cell * 8 + lane8) * 3;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+  }
+}
+
+// y[node] = sum of the element values of the (cell, corner) pairs that are this node (adj sorted by node)
+__global__ void __launch_bounds__(256)
+node_gather_kernel(const int64_t nnodes, const int64_t* __restrict__ ptr, const int32_t* __restrict__ adj,
+                   const double* __restrict__ fe, double* __restrict__ y) {
+  const int64_t nd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (nd >= nnodes) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int64_t k = ptr[nd]; k < ptr[nd + 1]; ++k) {
+    const double* f = fe + 3 * (int64_t)adj[k];
+    a0 += f[0]; a1 += f[1]; a2 += f[2];
+  }
+  y[3 * nd] = a0; y[3 * nd + 1] = a1; y[3 * nd + 2] = a2;
+}
+
 // First-order tetrahedra (affine): the displacement gradient is constant per cell,
 //   H = sum_m u_m (x) grad N_m,  grad N from the inverse of the edge matrix [X1-X0, X2-X0, X3-X0].
 // One thread per Gauss point (the nqp points of a cell repeat the cell value, as a dolfinx

@@ -292,6 +292,22 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
 int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const double* u_dev, double dt,
                                       double* flux_dev, double* ct_dev, void* hip_stream);
 
+/* ---- assembly-side consumers on the device (hex8 meshes with 8 Gauss points per cell, small strain) ----------
+ * What dolfinx assembly does with the quadrature Functions that QuadratureMap.update filled -- the residual form
+ * `dot(sig, strain(v)) * dx` and its derivative with the tangent blocks (tests/uniaxial_tension.py:62-67,
+ * quadrature_map.py:132-158) -- restated matrix-free for a caller that keeps stress, tangent and displacement on the
+ * GPU (no (N,6,6) array ever reaches the host):
+ *   internal force   f = sum_q w detJ B_q^T sigma_q                       flux_dev (npoints,6) Mandel -> f_dev (n_nodes*3)
+ *   tangent apply    y = sum_q w detJ B_q^T Ct_q B_q x                    ct_dev in `layout` (DXM_TANGENT_FULL or _COEF)
+ *   tangent diagonal d = diag(sum_q w detJ B_q^T Ct_q B_q)                coefficient layout only
+ * Deterministic (two passes: element values, then a node gather; no atomics), asynchronous on hip_stream, outputs
+ * overwritten.  Quadrature weights default to 1 (2x2x2 Gauss-Legendre on [-1,1]^3). */
+int dxm_mesh_set_weights(dxm_mesh* mesh, const double* weights /* nqp */);
+int dxm_mesh_internal_force_device(dxm_mesh* mesh, const double* flux_dev, double* f_dev, void* hip_stream);
+int dxm_mesh_tangent_apply_device(dxm_mesh* mesh, const double* ct_dev, int layout, const double* x_dev, double* y_dev,
+                                  void* hip_stream);
+int dxm_mesh_tangent_diagonal_device(dxm_mesh* mesh, const double* coef_dev, double* d_dev, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,152 @@
+"""GPU: the assembly-side consumers on the device (dxm_mesh_internal_force_device / _tangent_apply_device /
+_tangent_diagonal_device; what dolfinx assembly does with the quadrature Functions, tests/uniaxial_tension.py:62-67,
+quadrature_map.py:132-158) against a numpy evaluation on distorted hex8 meshes and against the block-CSR matrix of the
+stand-in host FE loop."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from dolfinx_materials_amd.conventions import tangent_from_coefficients
+from dolfinx_materials_amd.gradient import Hex8Mesh, gauss_points_hex
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+S = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
+R2 = np.sqrt(2.0)
+
+
+def shape_gradients(coords, conn, qp):
+    """Physical shape-function gradients g (cells, nqp, 8, 3) and w detJ (cells, nqp), weights 1."""
+    X = coords[conn]
+    g = np.empty((len(conn), len(qp), 8, 3))
+    wdet = np.empty((len(conn), len(qp)))
+    for q, xi in enumerate(qp):
+        dN = np.empty((8, 3))
+        for m in range(8):
+            for d in range(3):
+                f = 0.125 * S[m, d]
+                for o in range(3):
+                    if o != d:
+                        f *= 1 + S[m, o] * xi[o]
+                dN[m, d] = f
+        J = np.einsum("cma,md->cad", X, dN)
+        wdet[:, q] = np.linalg.det(J)
+        g[:, q] = np.einsum("md,cda->cma", dN, np.linalg.inv(J))
+    return g, wdet
+
+
+def mandel_to_tensor(s):
+    T = np.empty(s.shape[:-1] + (3, 3))
+    T[..., 0, 0], T[..., 1, 1], T[..., 2, 2] = s[..., 0], s[..., 1], s[..., 2]
+    T[..., 0, 1] = T[..., 1, 0] = s[..., 3] / R2
+    T[..., 0, 2] = T[..., 2, 0] = s[..., 4] / R2
+    T[..., 1, 2] = T[..., 2, 1] = s[..., 5] / R2
+    return T
+
+
+def host_force(g, wdet, conn, nnodes, sig):
+    T = mandel_to_tensor(sig.reshape(len(conn), -1, 6)) * wdet[..., None, None]
+    fe = np.einsum("cqia,cqma->cmi", T, g)
+    f = np.zeros((nnodes, 3))
+    np.add.at(f, conn, fe)
+    return f.ravel()
+
+
+def host_apply(g, wdet, conn, nnodes, ct, x):
+    H = np.einsum("cmi,cqma->cqia", x.reshape(-1, 3)[conn], g)
+    e = 0.5 * (H + H.transpose(0, 1, 3, 2))
+    em = np.stack([e[..., 0, 0], e[..., 1, 1], e[..., 2, 2], R2 * e[..., 0, 1], R2 * e[..., 0, 2], R2 * e[..., 1, 2]], axis=-1)
+    s = np.einsum("cqij,cqj->cqi", ct.reshape(len(conn), -1, 6, 6), em)
+    return host_force(g, wdet, conn, nnodes, s.reshape(-1, 6))
+
+
+def _case(n, seed):
+    from hex_fem import HexMesh
+
+    m = HexMesh(n)
+    rng = np.random.default_rng(seed)
+    coords = m.coords + 0.2 * m.h * rng.uniform(-1, 1, m.coords.shape)
+    conn = m.conn.astype(np.int32)
+    npts = len(conn) * 8
+    coef = rng.standard_normal((npts, 9))
+    coef[:, :3] = np.abs(coef[:, :3]) * [50e3, 40e3, -30e3]
+    coef[:, 3:] /= np.linalg.norm(coef[:, 3:], axis=1)[:, None]
+    return m, coords, conn, coef, rng
+
+
+@pytest.mark.parametrize("n", [3, 5])
+def test_force_apply_and_diagonal_match_numpy_on_a_distorted_mesh(n):
+    torch = pytest.importorskip("torch")
+    m, coords, conn, coef, rng = _case(n, seed=n)
+    g, wdet = shape_gradients(coords, conn, gauss_points_hex(2))
+    nn = len(coords)
+    mesh = Hex8Mesh(coords, conn)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    sig = rng.standard_normal((len(conn) * 8, 6))
+    x = rng.standard_normal(3 * nn)
+    ct = tangent_from_coefficients(coef).reshape(-1, 36)
+    d_sig, d_x, d_coef, d_ct = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sig, x, coef, ct))
+    y = torch.full((3 * nn,), float("nan"), dtype=torch.float64, device=dev)
+    mesh.internal_force_device(d_sig.data_ptr(), y.data_ptr(), st)
+    torch.cuda.synchronize()
+    ref = host_force(g, wdet, conn, nn, sig)
+    assert np.abs(y.cpu().numpy() - ref).max() < 1e-13 * np.abs(ref).max()
+    ref = host_apply(g, wdet, conn, nn, ct, x)
+    for layout, field in (("coef", d_coef), ("full", d_ct)):
+        y.fill_(float("nan"))
+        mesh.tangent_apply_device(field.data_ptr(), d_x.data_ptr(), y.data_ptr(), layout=layout, stream=st)
+        torch.cuda.synchronize()
+        assert np.abs(y.cpu().numpy() - ref).max() < 1e-12 * np.abs(ref).max(), layout
+    # deterministic: a second application gives the same bits
+    y2 = torch.empty_like(y)
+    mesh.tangent_apply_device(d_ct.data_ptr(), d_x.data_ptr(), y2.data_ptr(), layout="full", stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    # diagonal = the operator applied to unit vectors, entry by entry (small mesh only)
+    if n == 3:
+        diag = np.array([host_apply(g, wdet, conn, nn, ct, np.eye(3 * nn)[j])[j] for j in range(3 * nn)])
+        mesh.tangent_diagonal_device(d_coef.data_ptr(), y.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.abs(y.cpu().numpy() - diag).max() < 1e-12 * diag.max() and diag.min() > 0
+
+
+def test_apply_equals_the_assembled_block_csr_matrix_of_the_host_loop():
+    """Uniform mesh: y = K x with K assembled by examples/hex_fem.py from the same coefficients; f = its residual."""
+    torch = pytest.importorskip("torch")
+    from hex_fem import HexMesh
+
+    m = HexMesh(6)
+    rng = np.random.default_rng(1)
+    coef = rng.standard_normal((m.num_cells * 8, 9))
+    coef[:, :3] = np.abs(coef[:, :3]) * [50e3, 40e3, -30e3]
+    sig = rng.standard_normal((m.num_cells * 8, 6))
+    r, K = m.assemble(sig, coef, m.B_eps, "coef")
+    x = rng.standard_normal(m.ndof)
+    mesh = Hex8Mesh(m.coords, m.conn.astype(np.int32))
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    d_sig, d_x, d_coef = (torch.from_numpy(a).to(dev) for a in (sig, x, coef))
+    y = torch.empty(m.ndof, dtype=torch.float64, device=dev)
+    mesh.tangent_apply_device(d_coef.data_ptr(), d_x.data_ptr(), y.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    ref = K @ x
+    assert np.abs(y.cpu().numpy() - ref).max() < 1e-12 * np.abs(ref).max()
+    mesh.internal_force_device(d_sig.data_ptr(), y.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - r).max() < 1e-12 * np.abs(r).max()
+    mesh.tangent_diagonal_device(d_coef.data_ptr(), y.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - K.diagonal()).max() < 1e-12 * K.diagonal().max()
+
+
+def test_operators_need_eight_points_per_cell():
+    from dolfinx_materials_amd import _lib
+    from hex_fem import HexMesh
+
+    m = HexMesh(2)
+    mesh = Hex8Mesh(m.coords, m.conn.astype(np.int32), qpoints=gauss_points_hex(4))
+    with pytest.raises(_lib.DxmError, match="8 Gauss points"):
+        mesh.internal_force_device(8, 8)

@@ -60,3 +60,20 @@ def test_assembly_from_the_packed_tangent_layouts_gives_the_same_newton_history(
     h = b["history"][-1]
     expect = (b["sig0"] + b["H"] * h["exx"]) / (1 + b["H"] / b["E"])
     assert abs(h["sxx"] - expect) < 1e-8 * expect
+
+
+@pytest.mark.parametrize("preconditioner,n", [("jacobi", 6), ("mg", 16)])
+def test_device_resident_loop_reaches_the_closed_form(preconditioner, n):
+    """The consumer that keeps displacement, stress and tangent coefficients on the GPU (examples/device_fem.py:
+    matrix-free residual and tangent operator through dxm_mesh_internal_force_device / _tangent_apply_device, CG
+    preconditioned by the operator's diagonal or by the matrix-free multigrid V-cycle): same closed-form answer and
+    the same Newton behaviour as the host loop."""
+    from uniaxial_tension_3d_device import run
+
+    out = run(n=n, steps=4, preconditioner=preconditioner, verbose=False)
+    assert out["rel_err"] < 1e-9 and out["sxx_spread"] < 1e-6 and out["other_components_max"] < 1e-6
+    assert abs(out["p_mean"] - out["p_closed_form"]) < 1e-10
+    for step in out["history"]:
+        assert step["iters"] <= 4 and step["norms"][-1] < 1e-7      # linear predictor: at most a few corrections
+    if preconditioner == "mg":
+        assert out["levels"] == 2 and out["cg_iterations"] / max(out["newton_iterations"] - 4, 1) < 40
