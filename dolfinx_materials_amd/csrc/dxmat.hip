@@ -1290,8 +1290,11 @@ static int ensure_operator_buffers(dxm_mesh* mesh) {
   for (int64_t v = 0; v < mesh->n_nodes; ++v) ptr[v + 1] += ptr[v];
   std::vector<int32_t> adj((size_t)ne);
   {
+    // element values are stored corner-major (gradient.hpp): entry = corner * n_cells + cell, ascending per node
     std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
-    for (int64_t k = 0; k < ne; ++k) adj[(size_t)fill[conn[k]]++] = (int32_t)k;   // ascending k per node: fixed summation order
+    for (int c = 0; c < 8; ++c)
+      for (int64_t cell = 0; cell < mesh->n_cells; ++cell)
+        adj[(size_t)fill[conn[cell * 8 + c]]++] = (int32_t)((int64_t)c * mesh->n_cells + cell);
   }
   HIP_TRY(hipMalloc(&mesh->d_node_ptr, sizeof(int64_t) * (mesh->n_nodes + 1)));
   HIP_TRY(hipMalloc(&mesh->d_node_adj, sizeof(int32_t) * ne));

@@ -209,15 +209,23 @@ struct HexOperatorArgs {
   double w[8];
 };
 constexpr int HEX_OP_CELLS = 32;    // cells per 256-thread block
-constexpr int HEX_OP_PT = 21;       // doubles per Gauss-point record (Ji 9, stress 6 | coefficients 9, w detJ): odd stride
+constexpr int HEX_OP_PT_DIAG = 21, HEX_OP_PT = 9;   // doubles per Gauss-point record (see phase A), odd strides
 
 template <int OP>
 __global__ void __launch_bounds__(256)
-hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells, 8, 3) */) {
-  __shared__ __attribute__((aligned(16))) double lds[256 * HEX_OP_PT];
+hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (8, ncells, 3): corner-major */) {
+  constexpr int PT = OP == OP_DIAGONAL ? HEX_OP_PT_DIAG : HEX_OP_PT;
+  static_assert(256 * PT >= HEX_OP_CELLS * HEX_STAGE_REC, "the point records reuse the node staging region");
+  __shared__ __attribute__((aligned(16))) double lds[256 * PT];
+  __shared__ double dnt[8 * 8 * 3];   // reference shape-function gradients dN_m / dxi_d at the 8 points: [q][m][d]
   const int lane8 = threadIdx.x & 7, cl = threadIdx.x >> 3;
   const int64_t cell = (int64_t)blockIdx.x * HEX_OP_CELLS + cl;
   const bool live = cell < a.ncells;
+  if (threadIdx.x < 64) {
+    double dN[3];
+    hex8_dN(lane8, a.xi[cl][0], a.xi[cl][1], a.xi[cl][2], dN);   // here cl = q, lane8 = m
+    dnt[threadIdx.x * 3] = dN[0]; dnt[threadIdx.x * 3 + 1] = dN[1]; dnt[threadIdx.x * 3 + 2] = dN[2];
+  }
   // ---- stage the nodes of the block's cells: one (cell, corner) per thread
   {
     double2_t r0 = {0.0, 0.0}, r1 = {0.0, 0.0}, r2 = {0.0, 0.0};
@@ -231,24 +239,27 @@ hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells,
     d[0] = r0; d[1] = r1; d[2] = r2;
   }
   __syncthreads();
-  // ---- phase A: lane (cell, q) -- inverse Jacobian, w detJ and the (weighted) stress-like tensor of its point
-  double rec[HEX_OP_PT];
+  // ---- phase A: lane (cell, q).  Record left for phase B:
+  //   OP_FORCE / OP_APPLY   T[i][d] = w detJ sum_a S[i][a] Ji[d][a]  (9): the stress-like tensor pulled back to the
+  //                         reference cell, so that phase B needs the REFERENCE gradients only: f_m[i] = T[i][:] . dN_m
+  //   OP_DIAGONAL           Ji (9), coefficients (9), w detJ
+  double rec[PT];
   {
     const double2_t* nrec = reinterpret_cast<const double2_t*>(lds + cl * HEX_STAGE_REC);
-    const double x = a.xi[lane8][0], y = a.xi[lane8][1], z = a.xi[lane8][2];
+    const double* dq = dnt + lane8 * 24;
     double Jm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 2
     for (int m = 0; m < 8; ++m) {
-      double dN[3];
-      hex8_dN(m, x, y, z, dN);
+      const double d0 = dq[3 * m], d1 = dq[3 * m + 1], d2 = dq[3 * m + 2];
       const double2_t p0 = nrec[m * 3], p1 = nrec[m * 3 + 1];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { Jm[d] += p0.x * dN[d]; Jm[3 + d] += p0.y * dN[d]; Jm[6 + d] += p1.x * dN[d]; }
+      Jm[0] += p0.x * d0; Jm[1] += p0.x * d1; Jm[2] += p0.x * d2;
+      Jm[3] += p0.y * d0; Jm[4] += p0.y * d1; Jm[5] += p0.y * d2;
+      Jm[6] += p1.x * d0; Jm[7] += p1.x * d1; Jm[8] += p1.x * d2;
     }
     const double c00 = Jm[4] * Jm[8] - Jm[5] * Jm[7], c01 = Jm[5] * Jm[6] - Jm[3] * Jm[8], c02 = Jm[3] * Jm[7] - Jm[4] * Jm[6];
     const double det = Jm[0] * c00 + Jm[1] * c01 + Jm[2] * c02;
     const double idet = live ? 1.0 / det : 0.0;
-    double* Ji = rec;
+    double Ji[9];
     Ji[0] = c00 * idet; Ji[3] = c01 * idet; Ji[6] = c02 * idet;
     Ji[1] = (Jm[2] * Jm[7] - Jm[1] * Jm[8]) * idet;
     Ji[4] = (Jm[0] * Jm[8] - Jm[2] * Jm[6]) * idet;
@@ -261,6 +272,8 @@ hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells,
     const double r = 0.70710678118654752440;
     if constexpr (OP == OP_DIAGONAL) {
 #pragma unroll
+      for (int k = 0; k < 9; ++k) rec[k] = Ji[k];
+#pragma unroll
       for (int k = 0; k < 9; ++k) rec[9 + k] = live ? a.field[pt * 9 + k] : 0.0;
       rec[18] = wdet;
     } else {
@@ -271,17 +284,21 @@ hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells,
           for (int k = 0; k < 6; ++k) s[k] = a.field[pt * 6 + k];
         }
       } else {
-        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // du_i / dxi_d first (reference gradients), then H = B Ji
+        double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 2
         for (int m = 0; m < 8; ++m) {
-          double dN[3], g[3];
-          hex8_dN(m, x, y, z, dN);
+          const double d0 = dq[3 * m], d1 = dq[3 * m + 1], d2 = dq[3 * m + 2];
           const double2_t p1 = nrec[m * 3 + 1], p2 = nrec[m * 3 + 2];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) g[c] = dN[0] * Ji[c] + dN[1] * Ji[3 + c] + dN[2] * Ji[6 + c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { H[c] += p1.y * g[c]; H[3 + c] += p2.x * g[c]; H[6 + c] += p2.y * g[c]; }
+          B[0] += p1.y * d0; B[1] += p1.y * d1; B[2] += p1.y * d2;
+          B[3] += p2.x * d0; B[4] += p2.x * d1; B[5] += p2.x * d2;
+          B[6] += p2.y * d0; B[7] += p2.y * d1; B[8] += p2.y * d2;
         }
+        double H[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) H[i * 3 + c] = B[i * 3] * Ji[c] + B[i * 3 + 1] * Ji[3 + c] + B[i * 3 + 2] * Ji[6 + c];
         const double e[6] = {H[0], H[4], H[8], r * (H[1] + H[3]), r * (H[2] + H[6]), r * (H[5] + H[7])};
         if (live) {
           if (a.layout == 2) {
@@ -305,15 +322,20 @@ hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells,
           }
         }
       }
-      // symmetric tensor, weighted: [xx, yy, zz, xy, xz, yz]
-      rec[9] = wdet * s[0]; rec[10] = wdet * s[1]; rec[11] = wdet * s[2];
-      rec[12] = wdet * r * s[3]; rec[13] = wdet * r * s[4]; rec[14] = wdet * r * s[5];
+      // weighted symmetric tensor S, then T[i][d] = sum_a S[i][a] Ji[d][a]
+      const double S[9] = {wdet * s[0], wdet * r * s[3], wdet * r * s[4],
+                           wdet * r * s[3], wdet * s[1], wdet * r * s[5],
+                           wdet * r * s[4], wdet * r * s[5], wdet * s[2]};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) rec[i * 3 + d] = S[i * 3] * Ji[d * 3] + S[i * 3 + 1] * Ji[d * 3 + 1] + S[i * 3 + 2] * Ji[d * 3 + 2];
     }
   }
   __syncthreads();   // everybody is done with the node records: the region becomes the point records
   {
-    double* dst = lds + threadIdx.x * HEX_OP_PT;
-    constexpr int NW = OP == OP_DIAGONAL ? 19 : 15;
+    double* dst = lds + threadIdx.x * PT;
+    constexpr int NW = OP == OP_DIAGONAL ? 19 : 9;
 #pragma unroll
     for (int k = 0; k < NW; ++k) dst[k] = rec[k];
   }
@@ -322,12 +344,13 @@ hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells,
   double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll 2
   for (int q = 0; q < 8; ++q) {
-    const double* pr = lds + (cl * 8 + q) * HEX_OP_PT;   // the 8 lanes of a cell read the same record: broadcast
-    double dN[3], g[3];
-    hex8_dN(lane8, a.xi[q][0], a.xi[q][1], a.xi[q][2], dN);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) g[c] = dN[0] * pr[c] + dN[1] * pr[3 + c] + dN[2] * pr[6 + c];
+    const double* pr = lds + (cl * 8 + q) * PT;   // the 8 lanes of a cell read the same record: broadcast
+    const double* dm = dnt + (q * 8 + lane8) * 3;
+    const double d0 = dm[0], d1 = dm[1], d2 = dm[2];
     if constexpr (OP == OP_DIAGONAL) {
+      double g[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] = d0 * pr[c] + d1 * pr[3 + c] + d2 * pr[6 + c];
       const double k1 = pr[9], k2 = pr[10], k3 = pr[11], wd = pr[18];
       const double r = 0.70710678118654752440;
       const double gg = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
@@ -339,18 +362,20 @@ hex8_element_kernel(const HexOperatorArgs a, double* __restrict__ fe /* (ncells,
       for (int i = 0; i < 3; ++i)
         acc[i] += wd * (k1 * g[i] * g[i] + k2 * 0.5 * (g[i] * g[i] + gg) + k3 * ne[i] * ne[i]);
     } else {
-      acc[0] += pr[9] * g[0] + pr[12] * g[1] + pr[13] * g[2];
-      acc[1] += pr[12] * g[0] + pr[10] * g[1] + pr[14] * g[2];
-      acc[2] += pr[13] * g[0] + pr[14] * g[1] + pr[11] * g[2];
+      acc[0] += pr[0] * d0 + pr[1] * d1 + pr[2] * d2;
+      acc[1] += pr[3] * d0 + pr[4] * d1 + pr[5] * d2;
+      acc[2] += pr[6] * d0 + pr[7] * d1 + pr[8] * d2;
     }
   }
+  // corner-major: neighbouring nodes of a structured mesh find the values of the same corner slot side by side
   if (live) {
-    double* o = fe + (cell * 8 + lane8) * 3;
+    double* o = fe + ((int64_t)lane8 * a.ncells + cell) * 3;
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
   }
 }
 
-// y[node] = sum of the element values of the (cell, corner) pairs that are this node (adj sorted by node)
+// y[node] = sum of the element values of the (cell, corner) pairs that are this node; adj[k] = corner * ncells + cell,
+// per node in ascending order (a fixed summation order: the result is reproducible bit for bit)
 __global__ void __launch_bounds__(256)
 node_gather_kernel(const int64_t nnodes, const int64_t* __restrict__ ptr, const int32_t* __restrict__ adj,
                    const double* __restrict__ fe, double* __restrict__ y) {
