@@ -129,3 +129,27 @@ def test_multigrid_preconditioned_cg_solves_the_fe_loop():
     expect = (SIG0_LIN + H_LIN * exx) / (1 + H_LIN / E)
     assert np.allclose(qmap.fluxes["stress"].values[:, 0], expect, rtol=1e-8)
     assert timers["cg_iterations"] / (timers["newton_iterations"] - 3) < 40
+
+
+def test_device_loop_grid_transfers_are_trilinear_and_transposes_of_each_other():
+    """examples/device_fem.py (the device-resident loop) moves between multigrid levels by slicing on the node grid; the
+    pieces that need no GPU are checked here: prolongation reproduces a trilinear function exactly, restriction is its
+    transpose, and cell averaging of tangents keeps a constant."""
+    import torch
+    from device_fem import Multigrid, _cell_mean_full, structured_hex_mesh
+
+    nc = 3
+    mg = Multigrid.__new__(Multigrid)
+    coords_c, _ = structured_hex_mesh(nc)
+    coords_f, conn_f = structured_hex_mesh(2 * nc)
+    f = lambda x: 1.0 + x @ np.array([0.3, -0.2, 0.5]) + 0.7 * x[:, 0] * x[:, 1] * x[:, 2]   # noqa: E731  trilinear
+    xc = torch.from_numpy(np.stack([f(coords_c), 2 * f(coords_c), -f(coords_c)], axis=1).reshape(-1))
+    xf = mg.prolong(xc, nc)
+    assert np.abs(xf.numpy().reshape(-1, 3)[:, 0] - f(coords_f)).max() < 1e-14
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.standard_normal(xc.shape[0]))
+    b = torch.from_numpy(rng.standard_normal(xf.shape[0]))
+    assert abs(float(torch.dot(mg.prolong(a, nc), b) - torch.dot(a, mg.restrict(b, 2 * nc)))) < 1e-12
+    assert conn_f.shape == (216, 8) and conn_f.dtype == np.int32 and conn_f.max() == len(coords_f) - 1
+    t = torch.ones((216 * 8, 36), dtype=torch.float64) * 3.0
+    assert torch.equal(_cell_mean_full(t, 6), torch.full((27, 36), 3.0, dtype=torch.float64))
