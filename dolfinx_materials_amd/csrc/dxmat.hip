@@ -1296,11 +1296,23 @@ static int ensure_operator_buffers(dxm_mesh* mesh) {
       for (int64_t cell = 0; cell < mesh->n_cells; ++cell)
         adj[(size_t)fill[conn[cell * 8 + c]]++] = (int32_t)((int64_t)c * mesh->n_cells + cell);
   }
-  HIP_TRY(hipMalloc(&mesh->d_node_ptr, sizeof(int64_t) * (mesh->n_nodes + 1)));
-  HIP_TRY(hipMalloc(&mesh->d_node_adj, sizeof(int32_t) * ne));
-  HIP_TRY(hipMemcpy(mesh->d_node_ptr, ptr.data(), sizeof(int64_t) * (mesh->n_nodes + 1), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(mesh->d_node_adj, adj.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&mesh->d_fe, sizeof(double) * ne * 3));
+  // all three or none: d_fe != nullptr is the "ready" mark
+  int64_t* d_ptr = nullptr;
+  int32_t* d_adj = nullptr;
+  double* d_fe = nullptr;
+  bool ok = hipMalloc(&d_ptr, sizeof(int64_t) * (mesh->n_nodes + 1)) == hipSuccess;
+  ok = ok && hipMalloc(&d_adj, sizeof(int32_t) * ne) == hipSuccess;
+  ok = ok && hipMalloc(&d_fe, sizeof(double) * ne * 3) == hipSuccess;
+  ok = ok && hipMemcpy(d_ptr, ptr.data(), sizeof(int64_t) * (mesh->n_nodes + 1), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (d_ptr) (void)hipFree(d_ptr);
+    if (d_adj) (void)hipFree(d_adj);
+    if (d_fe) (void)hipFree(d_fe);
+    return fail(-3, "device allocation for the mesh operators failed");
+  }
+  mesh->d_node_ptr = d_ptr; mesh->d_node_adj = d_adj; mesh->d_fe = d_fe;
   return 0;
 }
 
