@@ -367,3 +367,54 @@ def test_fused_displacement_path_is_graph_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(f, f2) and torch.equal(c, c2)
+
+
+def test_dolfinx_adapters_run_against_a_stand_in_function_space(monkeypatch):
+    """No dolfinx on either box: `SimplexMesh.from_dolfinx` / `Tet4Mesh.from_dolfinx` are exercised with a stand-in that
+    exposes the attributes they read (mesh.geometry.x / .dofmap, dofmap.list / index_map, element.basix_element.tabulate,
+    basix.make_quadrature) in the shapes dolfinx 0.8+ documents; the real thing is tests/test_dolfinx_integration.py."""
+    import sys
+    import types
+
+    torch = pytest.importorskip("torch")
+    from dolfinx_materials_amd.gradient import (SimplexMesh, Tet4Mesh, lagrange_simplex_table, p2_dofmap, simplex_quadrature)
+    from helpers import mandel_strain, simplex_host_gradient
+
+    hm, coords = make_mesh(2, distort=0.2, seed=9)
+    cells = np.concatenate([hm.conn[:, list(k)] for k in KUHN], axis=0).astype(np.int32)
+    dofmap, n_dofs, edges = p2_dofmap(cells)
+    xd = np.concatenate([coords, 0.5 * (coords[edges[:, 0]] + coords[edges[:, 1]])], axis=0)
+    pts = simplex_quadrature(3, 2)
+
+    basix = types.ModuleType("basix")
+    basix.CellType = types.SimpleNamespace(triangle="triangle", tetrahedron="tetrahedron", hexahedron="hexahedron")
+    basix.make_quadrature = lambda cell, degree: (pts, np.full(len(pts), 1.0 / 24))
+    monkeypatch.setitem(sys.modules, "basix", basix)
+
+    def space(degree):
+        tab = lagrange_simplex_table(3, degree, pts)                         # (nqp, nd, 3)
+        full = np.zeros((4, len(pts), tab.shape[1], 1))
+        full[1:, :, :, 0] = tab.transpose(2, 0, 1)                            # basix: (derivative, point, dof, value)
+        dm = dofmap if degree == 2 else cells
+        nd = n_dofs if degree == 2 else len(coords)
+        return types.SimpleNamespace(
+            mesh=types.SimpleNamespace(topology=types.SimpleNamespace(dim=3), geometry=types.SimpleNamespace(x=coords, dofmap=cells)),
+            dofmap=types.SimpleNamespace(index_map_bs=3, list=dm, index_map=types.SimpleNamespace(size_local=nd, num_ghosts=0),
+                                         cell_dofs=lambda c: dm[c]),
+            element=types.SimpleNamespace(basix_element=types.SimpleNamespace(tabulate=lambda n, p: full)),
+            ufl_element=lambda: types.SimpleNamespace(degree=degree),
+            tabulate_dof_coordinates=lambda: xd if degree == 2 else coords)
+
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(3)
+    mesh = SimplexMesh.from_dolfinx(space(2), 2)
+    assert (mesh.nqp, mesh.nd, mesh.n_dofs, mesh.tdim) == (4, 10, n_dofs, 3)
+    u = (xd * np.array([8e-3, -3e-3, -3e-3]) + 1e-3 * rng.standard_normal(xd.shape)).ravel()
+    out = torch.empty((mesh.npoints, 6), dtype=torch.float64, device=dev)
+    mesh.gradient_device(torch.from_numpy(u).to(dev).data_ptr(), 0, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    H = simplex_host_gradient(coords, cells, dofmap, u, lagrange_simplex_table(3, 2, pts)).reshape(-1, 3, 3)
+    assert np.abs(out.cpu().numpy() - mandel_strain(H)).max() < 1e-13
+    t4 = Tet4Mesh.from_dolfinx(space(1), 2)
+    assert t4.nqp == 4 and t4.n_cells == len(cells)
