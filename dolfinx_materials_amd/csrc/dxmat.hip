@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
@@ -243,6 +244,7 @@ struct dxm_material {
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
   bool opt_tune_verbose = false;
   int opt_host_threads = 16;
+  int64_t opt_packed_min_points = 32768;   // below: waking the workers costs what the bytes save (r02_hostpath_v2.jsonl)
   size_t opt_tune_max_skip = (size_t)2 << 30;   // dxm_tune_placement: bytes of skip blocks it may hold
   int opt_max_chunks = DXM_MAX_CHUNKS;
   HostPool* pool = nullptr;
@@ -952,11 +954,11 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 template <class Upload>
 static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
                             double* ct_aos, dxm_stats* stats, const MeshSource* fused = nullptr) {
+  const auto t_enter = std::chrono::steady_clock::now();
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  // (below ~2.6e5 points waking the worker threads costs more than the bytes saved on the wire)
-  const bool packed = m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && d.n_grad == 6 && ct_aos != nullptr && n >= 262144;
+  const bool packed = m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && d.n_grad == 6 && ct_aos != nullptr && n >= m->opt_packed_min_points;
   const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
   const int tl = packed && !constant ? TL_COEF : m->tangent_layout;   // layout of this call's launches
   const int nt = tl == TL_COEF ? 9 : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad);   // doubles per point in d_ct
@@ -971,7 +973,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     m->elastic_lm[1] = m->prm.mu;
   }
   // the last chunk's host expansion is not hidden behind any transfer: many small chunks keep that tail short
-  int nchunks = (int)(n / (packed ? 65536 : 131072));
+  int nchunks = (int)(n / (packed ? (n >= 2097152 ? 65536 : 32768) : 131072));
   if (nchunks < 1) nchunks = 1;
   if (!packed && nchunks > 8) nchunks = 8;
   if (nchunks > m->opt_max_chunks) nchunks = m->opt_max_chunks;
@@ -979,7 +981,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));
   const int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
-  int stats_off = 0, issued = 0;
+  int stats_off = 0, issued = 0, submitted = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
   // no worker may still be writing into the caller's array when this function returns, error paths included
   struct PoolDrain {
@@ -1019,22 +1021,37 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     }
     HIP_TRY(hipEventRecord(m->chunk_done[c], st));
     issued = c + 1;
+    // a pageable upload blocks this thread for its whole duration, so earlier chunks land while the later ones are
+    // still being issued: hand them to the workers now, not after the loop
+    if (packed && !constant)
+      while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
+        const int64_t o = (int64_t)submitted * csize;
+        m->pool->submit(m->h_coef + o * 9, ct_aos + o * 36, (n - o) < csize ? (n - o) : csize, 9);
+        ++submitted;
+      }
   }
+  (void)hipGetLastError();   // hipEventQuery reports "not ready" through the error state
   m->last_grid = stats_off;
   m->launched = true;
   m->s1_alias = false;  // every slot of s1 has been rewritten
   // the chunks complete in issue order on their two streams; rebuild each block as soon as it has landed
+  const auto t_issued = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   for (int c = 0; c < issued; ++c) {
     HIP_TRY(hipEventSynchronize(m->chunk_done[c]));
-    if (packed && !constant) {
+    if (m->opt_tune_verbose && (c % 8 == 7 || c == 0)) fprintf(stderr, "[dxm host path] chunk %d landed at +%.2f ms after issue (issue loop took %.2f ms)\n", c, ms_since(t_issued), std::chrono::duration<double, std::milli>(t_issued - t_enter).count());
+    if (packed && !constant && c >= submitted) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
       m->pool->submit(m->h_coef + off * 9, ct_aos + off * 36, cnt, 9);
+      submitted = c + 1;
     }
   }
   HIP_TRY(hipEventRecord(m->last_event, m->own_stream));   // everything of this call is complete already
   m->last_event_recorded = true;
+  const auto t_landed = std::chrono::steady_clock::now();
   if (packed) m->pool->wait();
+  if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] all landed at +%.2f ms, workers done %.2f ms later\n", std::chrono::duration<double, std::milli>(t_landed - t_issued).count(), ms_since(t_landed));
   return dxm_get_stats(m, stats);
 }
 
@@ -1543,6 +1560,10 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   else if (k == "packed_transfer") m->opt_packed_transfer = on;
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
   else if (k == "tune_verbose") m->opt_tune_verbose = on;
+  else if (k == "packed_min_points") {
+    if (!(value >= 0 && value <= 1e12)) return fail(-1, "packed_min_points must be >= 0");
+    m->opt_packed_min_points = (int64_t)value;
+  }
   else if (k == "host_threads") {
     if (!(value >= 1 && value <= 256)) return fail(-1, "host_threads must be in [1, 256]");
     m->opt_host_threads = (int)value;

@@ -215,16 +215,19 @@ int dxm_notify_replay(dxm_material* m);
 /* Per-handle options (no environment variables are read by the library):
  *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on two streams (default 1)
  *   "max_chunks"     1..64   upper bound on the chunks of that pipeline (default 64)
- *   "packed_transfer" 1 | 0  host-buffer form, small-strain laws, full tangent layout, >= 262144 points: move the
+ *   "packed_transfer" 1 | 0  host-buffer form, small-strain laws, full tangent layout, >= packed_min_points: move the
  *                            9 coefficients of Ct = c1 1x1 + c2 I + c3 n x n (72 instead of 288 B/point; nothing
  *                            for the elastic law) and rebuild the (N,6,6) block on the host with the kernel's
  *                            own expression, bit-identical (default 1)
+ *   "packed_min_points" >= 0 batch size from which packed_transfer applies (default 32768: below, waking the
+ *                            worker threads costs what the bytes save)
  *   "host_threads"   1..256  worker threads of that rebuild (default 16)
  *   "fused_gradient" 1 | 0   displacement forms: evaluate the gradient inside the update kernel where the mesh
  *                            allows (default 1)
  *   "blocks_per_cu"  1..256  grid size of the update kernel in workgroups per CU (default 32 small strain,
  *                            the resident 2 for FeFp)
- *   "tune_verbose"   1 | 0   dxm_tune_placement logs every candidate to stderr (default 0)
+ *   "tune_verbose"   1 | 0   dxm_tune_placement logs every candidate, the host-buffer form its chunk timeline, to
+ *                            stderr (default 0)
  *   "tune_max_skip_bytes"    upper bound on the skip blocks dxm_tune_placement may hold (default 2 GiB) */
 int dxm_set_option(dxm_material* m, const char* name, double value);
 /* get_initial_state_dict / get_final_state_dict without a device array of the caller: packs the

@@ -22,10 +22,10 @@ def _j2(kind="linear", **kw):
     return JAXMaterial(jm.vonMisesIsotropicHardening(el, hard), **kw)
 
 
-@pytest.mark.parametrize("n", [1, 255, 300_001, 2_200_000])
+@pytest.mark.parametrize("n", [1, 255, 40_001, 300_001, 2_200_000])
 def test_packed_tangent_transfer_is_bit_identical_to_the_full_download(n):
-    """2.2e6 points = 33 chunks on two streams with 16 expansion threads behind them; 300001 = ragged chunks;
-    the two small sizes take the unpacked route (below 262144 points)."""
+    """2.2e6 points = 33 chunks on two streams with 16 expansion threads behind them; 300001 and 40001 = ragged chunks
+    of 32768 points; the two small sizes take the unpacked route (below option packed_min_points = 32768)."""
     a, b = _j2(), _j2()
     a.set_data_manager(n)
     b.set_data_manager(n)
@@ -220,7 +220,7 @@ def test_returned_arrays_outlive_the_material():
 
 
 def test_elastic_host_path_fills_the_constant_block_without_moving_it():
-    """Elastic law, full layout, >= 262144 points: no tangent bytes cross PCIe, worker threads fill the constant block;
+    """Elastic law, full layout, >= 32768 points: no tangent bytes cross PCIe, worker threads fill the constant block;
     equal to the device-computed block and to python_materials/elasticity.py:15-19."""
     n = 300_001
     el = jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU))

@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+MIN_POINTS = None
+
+
 def run(n, mode, reps, threads=None):
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
@@ -38,6 +41,8 @@ def run(n, mode, reps, threads=None):
         m.set_option("max_chunks", 8)
     if threads:
         m.set_option("host_threads", threads)
+    if MIN_POINTS is not None:
+        m.set_option("packed_min_points", MIN_POINTS)
     if mode in ("bound", "pinned_in"):
         flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
         m.bind_outputs(flux=flux_fn, tangent=jac_fn)
@@ -70,7 +75,10 @@ def main():
     ap.add_argument("--modes", nargs="+", default=["r01", "packed", "bound"])
     ap.add_argument("--threads", type=int, nargs="+", default=[0])
     ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--packed-min-points", type=int, default=None, help="option packed_min_points (library default 262144)")
     a = ap.parse_args()
+    global MIN_POINTS
+    MIN_POINTS = a.packed_min_points
     for n in a.points:
         for mode in a.modes:
             for t in a.threads:
