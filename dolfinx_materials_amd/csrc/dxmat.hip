@@ -141,6 +141,30 @@ static void expand_coef_tangent(const double* __restrict__ s, double* __restrict
   }
 }
 
+// FeFp: the 9x9 block from its 54 building blocks (fefp.hpp step 6):
+//   A[row=(i,J)][col=(k,L)] = Vc[col] Fi[J][i] + Wc[col] Sr[row] + U[i][L] Fi[J][k] + (i==k) g[L][J]
+// evaluated as the kernel evaluates it (one product, three fused multiply-adds, the Kronecker delta as a 0/1 factor).
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("fma")))
+#endif
+static void expand_fefp_tangent(const double* __restrict__ s, double* __restrict__ d, int64_t n) {
+  static const int TI[9] = {0, 1, 2, 0, 1, 0, 2, 1, 2}, TJ[9] = {0, 1, 2, 1, 0, 2, 0, 2, 1};
+  for (int64_t p = 0; p < n; ++p, s += 54, d += 81) {
+    const double* fi = s;
+    for (int r = 0; r < 9; ++r) {
+      const int i = TI[r], J = TJ[r];
+      for (int c = 0; c < 9; ++c) {
+        const int k = TI[c], L = TJ[c];
+        double t = s[9 + c] * fi[J * 3 + i];
+        t = __builtin_fma(s[27 + c], s[36 + r], t);
+        t = __builtin_fma(s[18 + i * 3 + L], fi[J * 3 + k], t);
+        t = __builtin_fma(i == k ? 1.0 : 0.0, s[45 + L * 3 + J], t);
+        d[r * 9 + c] = t;
+      }
+    }
+  }
+}
+
 // elastic law: the same constant block for every point
 static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, double* __restrict__ d, int64_t n) {
   double o[36];
@@ -152,7 +176,7 @@ static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, do
 
 // A few persistent worker threads per handle (created on the first host-path call that needs them).
 struct HostPool {
-  struct Job { const double* src; double* dst; int64_t n; int stride; };   // stride 9: coefficients, 0: constant
+  struct Job { const double* src; double* dst; int64_t n; int stride; };   // stride 9: J2 coefficients, 54: FeFp, 0: constant
   std::vector<std::thread> threads;
   std::mutex mu;
   std::condition_variable cv, cv_done;
@@ -177,7 +201,8 @@ struct HostPool {
         j = queue.front();
         queue.pop_front();
       }
-      if (j.stride) expand_coef_tangent(j.src, j.dst, j.n);
+      if (j.stride == 9) expand_coef_tangent(j.src, j.dst, j.n);
+      else if (j.stride == 54) expand_fefp_tangent(j.src, j.dst, j.n);
       else fill_const_tangent(j.src, j.dst, j.n);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -191,7 +216,7 @@ struct HostPool {
     const int64_t per = (n + pieces - 1) / pieces;
     std::lock_guard<std::mutex> lk(mu);
     for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * stride, dst + o * 36, std::min(per, n - o), stride});
+      queue.push_back(Job{src + o * stride, dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride});
       ++pending;
     }
     cv.notify_all();
@@ -712,15 +737,16 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
       BlockStats* bs = m->d_stats + stats_off;
       const MeshSource none{};
       const bool voce = m->law == DXM_LAW_FEFP_J2_VOCE;
-#define DXM_LAUNCH_FEFP(HARD, G) \
-  hipLaunchKernelGGL((fefp_kernel<HARD, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, *fused)
-      if (fused && fused->kind == 1) { if (voce) DXM_LAUNCH_FEFP(1, 1); else DXM_LAUNCH_FEFP(0, 1); }
-      else if (fused && fused->kind == 2) { if (voce) DXM_LAUNCH_FEFP(1, 2); else DXM_LAUNCH_FEFP(0, 2); }
-      else if (fused)                { if (voce) DXM_LAUNCH_FEFP(1, 3); else DXM_LAUNCH_FEFP(0, 3); }
-      else if (voce)
-        hipLaunchKernelGGL((fefp_kernel<1, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, none);
-      else
-        hipLaunchKernelGGL((fefp_kernel<0, 0>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, none);
+      const MeshSource& fsrc = fused ? *fused : none;
+      const int g = fused ? fused->kind : 0;
+#define DXM_LAUNCH_FEFP(HARD, G, T) \
+  hipLaunchKernelGGL((fefp_kernel<HARD, G, T>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, m->ld, flux, ct, bs, fsrc)
+#define DXM_LAUNCH_FEFP_G(HARD, T) do { if (g == 0) DXM_LAUNCH_FEFP(HARD, 0, T); else if (g == 1) DXM_LAUNCH_FEFP(HARD, 1, T); \
+                                       else if (g == 2) DXM_LAUNCH_FEFP(HARD, 2, T); else DXM_LAUNCH_FEFP(HARD, 3, T); } while (0)
+      // tl == TL_COEF: the 54 building blocks of the tangent per point instead of its 81 entries (host-buffer form)
+      if (tl == TL_COEF) { if (voce) DXM_LAUNCH_FEFP_G(1, 1); else DXM_LAUNCH_FEFP_G(0, 1); }
+      else               { if (voce) DXM_LAUNCH_FEFP_G(1, 0); else DXM_LAUNCH_FEFP_G(0, 0); }
+#undef DXM_LAUNCH_FEFP_G
 #undef DXM_LAUNCH_FEFP
       break;
     }
@@ -958,13 +984,16 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  const bool packed = m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && d.n_grad == 6 && ct_aos != nullptr && n >= m->opt_packed_min_points;
+  const bool packed = m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && ct_aos != nullptr && n >= m->opt_packed_min_points;
   const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
+  const bool fefp = d.n_grad == 9;
   const int tl = packed && !constant ? TL_COEF : m->tangent_layout;   // layout of this call's launches
-  const int nt = tl == TL_COEF ? 9 : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : d.n_flux * d.n_grad);   // doubles per point in d_ct
+  const int np = fefp ? FEFP_REC : 9;                                   // doubles per point of the packed form
+  const int nfull = d.n_flux * d.n_grad;
+  const int nt = tl == TL_COEF ? np : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : nfull);   // doubles per point in d_ct
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (packed) {
-    if (!constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * 9, hipHostMallocDefault));
+    if (!constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * np, hipHostMallocDefault));
     if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
       delete m->pool;
       m->pool = new HostPool(m->opt_host_threads);
@@ -1016,7 +1045,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                              hipMemcpyDeviceToHost, st));
     }
     if (ct_aos && !constant) {
-      double* dst = packed ? m->h_coef + off * 9 : ct_aos + off * nt;
+      double* dst = packed ? m->h_coef + off * np : ct_aos + off * nt;
       HIP_TRY(hipMemcpyAsync(dst, m->d_ct + off * nt, sizeof(double) * cnt * nt, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(m->chunk_done[c], st));
@@ -1026,7 +1055,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && !constant)
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
-        m->pool->submit(m->h_coef + o * 9, ct_aos + o * 36, (n - o) < csize ? (n - o) : csize, 9);
+        m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, np);
         ++submitted;
       }
   }
@@ -1043,7 +1072,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && !constant && c >= submitted) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-      m->pool->submit(m->h_coef + off * 9, ct_aos + off * 36, cnt, 9);
+      m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, np);
       submitted = c + 1;
     }
   }

@@ -121,7 +121,11 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
 //     spare LDS region, counted s_waitcnt at the top of the next tile; needs 7-point rounds to make room): +6 %, of
 //     which +5 % is the 7-point rounds alone -- load latency and the in-order completion of a wave's memory
 //     operations are not what the kernel waits for; unrolling the two steps of a round: no gain.
-template <int HARD, int GRAD = 0>
+// TLF: 0 = the 9x9 tangent (81 doubles per point); 1 = its 54 building blocks per point (the record of step 6 below,
+//      432 instead of 648 B: what the host-buffer form moves over PCIe before rebuilding the block on the host with the
+//      same four-term expression, dxmat.hip::expand_fefp_tangent)
+constexpr int FEFP_REC = 54;
+template <int HARD, int GRAD = 0, int TLF = 0>
 __global__ void __launch_bounds__(BLOCK, 2)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
             const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
@@ -470,6 +474,21 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         Sd[k * 3 + L] = d[DXM_SYM(k, 0)] * Fi[L * 3] + d[DXM_SYM(k, 1)] * Fi[L * 3 + 1] + d[DXM_SYM(k, 2)] * Fi[L * 3 + 2];
       }
 
+    if constexpr (TLF == 1) {
+      // building blocks only: every lane leaves its own record (rare path: the transfer behind it is 50x the kernel)
+      if (valid) {
+        double* rec = ct + gi * FEFP_REC;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          rec[t] = Fi[t];
+          rec[9 + t] = V[TI[t] * 3 + TJ[t]];
+          rec[18 + t] = U[t];
+          rec[27 + t] = W[TI[t] * 3 + TJ[t]];
+          rec[36 + t] = Sd[TI[t] * 3 + TJ[t]];
+          rec[45 + t] = gs * G[DXM_SYM(t / 3, t % 3)];
+        }
+      }
+    } else
 #pragma unroll 1
     for (int rd = 0; rd < (WAVE + F2_PPR - 1) / F2_PPR; ++rd) {
       const int p0 = rd * F2_PPR;                               // first point of the round

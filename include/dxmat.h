@@ -215,10 +215,11 @@ int dxm_notify_replay(dxm_material* m);
 /* Per-handle options (no environment variables are read by the library):
  *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on two streams (default 1)
  *   "max_chunks"     1..64   upper bound on the chunks of that pipeline (default 64)
- *   "packed_transfer" 1 | 0  host-buffer form, small-strain laws, full tangent layout, >= packed_min_points: move the
- *                            9 coefficients of Ct = c1 1x1 + c2 I + c3 n x n (72 instead of 288 B/point; nothing
- *                            for the elastic law) and rebuild the (N,6,6) block on the host with the kernel's
- *                            own expression, bit-identical (default 1)
+ *   "packed_transfer" 1 | 0  host-buffer form, full tangent layout, >= packed_min_points: move the 9 coefficients
+ *                            of Ct = c1 1x1 + c2 I + c3 n x n (72 instead of 288 B/point; nothing for the elastic
+ *                            law) / for the FeFp laws the 54 building blocks of the 9x9 tangent (432 instead of
+ *                            648 B/point), and rebuild the block on the host with the kernel's own expression,
+ *                            bit-identical (default 1)
  *   "packed_min_points" >= 0 batch size from which packed_transfer applies (default 32768: below, waking the
  *                            worker threads costs what the bytes save)
  *   "host_threads"   1..256  worker threads of that rebuild (default 16)

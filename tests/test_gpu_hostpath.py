@@ -48,6 +48,31 @@ def test_packed_tangent_transfer_is_bit_identical_to_the_full_download(n):
     assert np.abs(ct[safe] - ref["Ct"][safe]).max() <= 1e-12 * np.abs(ref["Ct"]).max()
 
 
+@pytest.mark.parametrize("n,hard", [(33_001, "voce"), (300_001, "voce"), (70_000, "linear")])
+def test_fefp_building_block_transfer_is_bit_identical_to_the_full_download(n, hard):
+    """FeFp, host-buffer form: the 54 building blocks of the 9x9 tangent cross PCIe (432 instead of 648 B/point) and worker
+    threads rebuild the block with the kernel's four-term expression; load path of tests/test_FeFp_jax.py:28-30 with
+    perturbations, elastic and plastic steps, advance in between."""
+    from helpers import SIG0_F, SIGU_F, B_F, fefp_path
+
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    h = jm.VoceHardening(SIG0_F, SIGU_F, B_F) if hard == "voce" else jm.LinearHardening(SIG0_F, 2e3)
+    a, b = JAXMaterial(jm.FeFpJ2Plasticity(el, h)), JAXMaterial(jm.FeFpJ2Plasticity(el, h))
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    b.set_option("packed_transfer", 0)
+    nplastic = 0
+    for F in fefp_path(n, nsteps=6, eps=3e-2)[::2]:
+        fa, ia, ca = a.integrate(F)
+        fb, ib, cb = b.integrate(F)
+        assert ca.shape == (n, 9, 9) and np.array_equal(fa, fb) and np.array_equal(ca, cb)
+        assert np.array_equal(np.asarray(ia), np.asarray(ib)) and a.last_stats == b.last_stats
+        nplastic += a.last_stats["n_plastic"]
+        a.data_manager.update()
+        b.data_manager.update()
+    assert nplastic > 0
+
+
 def test_isv_is_fetched_on_demand_and_equals_the_eager_download():
     n = 40_000
     lazy, eager = _j2("voce"), _j2("voce", lazy_isv=False)

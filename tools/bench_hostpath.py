@@ -27,14 +27,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 MIN_POINTS = None
 
 
+LAW = "j2_linear"
+
+
 def run(n, mode, reps, threads=None):
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
-    from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
+    from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_F, SIGU_F, B_F, fefp_path, j2_history
 
-    h = j2_history(n)
-    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)),
-                    lazy_isv=(mode != "r01"), tangent_layout="coef" if mode == "coef" else "full")
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if LAW == "fefp":   # 9x9 tangent: 72 B up, 72 + 648 (r01) or 72 + 432 (packed: its 54 building blocks) down
+        h = [None] + fefp_path(n, nsteps=4, eps=3e-2)[1:3]
+        m = JAXMaterial(jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F)), lazy_isv=(mode != "r01"))
+    else:
+        h = j2_history(n)
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN)),
+                        lazy_isv=(mode != "r01"), tangent_layout="coef" if mode == "coef" else "full")
     m.set_data_manager(n)
     if mode == "r01":
         m.set_option("packed_transfer", 0)
@@ -43,8 +51,9 @@ def run(n, mode, reps, threads=None):
         m.set_option("host_threads", threads)
     if MIN_POINTS is not None:
         m.set_option("packed_min_points", MIN_POINTS)
+    nf = 9 if LAW == "fefp" else 6
     if mode in ("bound", "pinned_in"):
-        flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
+        flux_fn, jac_fn = np.zeros(n * nf), np.zeros(n * nf * nf)
         m.bind_outputs(flux=flux_fn, tangent=jac_fn)
     m.integrate(h[1])
     m.data_manager.update()
@@ -62,7 +71,9 @@ def run(n, mode, reps, threads=None):
         ts.append(time.perf_counter() - t0)
     dt = float(np.median(ts))
     bpp = 48 + 48 + (56 + 288 if mode == "r01" else 72)
-    out = {"law": "j2_linear", "mode": mode, "points": n, "host_threads": threads or 8, "host_path_ms": round(dt * 1e3, 3),
+    if LAW == "fefp":
+        bpp = 72 + 72 + (56 + 648 if mode == "r01" else 432)
+    out = {"law": LAW, "mode": mode, "points": n, "host_threads": threads or 8, "host_path_ms": round(dt * 1e3, 3),
            "min_ms": round(min(ts) * 1e3, 3), "Mpoints_per_s": round(n / dt / 1e6, 2), "pcie_bytes_per_point": bpp,
            "GBs_over_pcie": round(n * bpp / dt / 1e9, 2)}
     m.close()
@@ -76,9 +87,10 @@ def main():
     ap.add_argument("--threads", type=int, nargs="+", default=[0])
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--packed-min-points", type=int, default=None, help="option packed_min_points (library default 262144)")
+    ap.add_argument("--law", default="j2_linear", choices=["j2_linear", "fefp"])
     a = ap.parse_args()
-    global MIN_POINTS
-    MIN_POINTS = a.packed_min_points
+    global MIN_POINTS, LAW
+    MIN_POINTS, LAW = a.packed_min_points, a.law
     for n in a.points:
         for mode in a.modes:
             for t in a.threads:
