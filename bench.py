@@ -121,23 +121,32 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
     QuadratureMap.update calls it, quadrature_map.py:321).  Context only, never `value`: the transfer, not the
     kernel, is the whole cost when the consumer lives on the host."""
     h = history(n, seed)
-    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
-    m.set_data_manager(n)
-    m.integrate(h[0])
-    m.data_manager.update()
-    m.integrate(h[1])
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        flux, isv, ct = m.integrate(h[1])
-        ts.append(time.perf_counter() - t0)
-    dt = float(np.median(ts))
+
+    def timed(bind):
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
+        m.set_data_manager(n)
+        if bind:   # the arrays of the caller's quadrature Functions, page-locked in place (field_map.py; SURVEY 8(f) row 1)
+            flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
+            m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+        m.integrate(h[0])
+        m.data_manager.update()
+        m.integrate(h[1])
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            m.integrate(h[1])
+            ts.append(time.perf_counter() - t0)
+        m.close()
+        return float(np.median(ts))
+
+    dt_own, dt = timed(False), timed(True)
     out = {"value": round(n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_call": round(dt * 1e3, 3), "points": n,
+           "into_the_materials_own_arrays": {"value": round(n / dt_own / 1e6, 2), "ms_per_call": round(dt_own * 1e3, 3)},
            "pcie_bytes_per_point": {"h2d_strain": 48, "d2h_stress": 48, "d2h_tangent_coefficients": 72, "isv": "on demand (56)"},
            "GBs_over_pcie": round(n * 168 / dt / 1e9, 1),
            "note": "host buffers in and out through dxm_integrate: chunk-pipelined on two streams, the 9 coefficients of the tangent moved "
-                   "and the (N,6,6) block rebuilt by 16 host threads with the kernel's own expression, bit-identical to the full download"}
-    m.close()
+                   "and the (N,6,6) block rebuilt by 16 host threads with the kernel's own expression, bit-identical to the full download; "
+                   "`value`: results delivered into caller-owned arrays (bind_outputs: the x.array of the quadrature Functions)"}
     return out
 
 
