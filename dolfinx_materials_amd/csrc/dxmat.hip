@@ -1109,31 +1109,19 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats);
 }
 
-// Page-locked host arrays for the results: ordinary (page-aligned) host memory registered with the runtime rather than
-// hipHostMalloc -- the worker threads' streaming stores into it run at the host's normal rate (the rebuilt tangent is
-// 288 B/point of them) and the pages sit where the threads that first touch them run.
 void* dxm_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
   if (bytes == 0) bytes = 8;
-  const uint64_t rounded = (bytes + 4095) / 4096 * 4096;
-  void* p = aligned_alloc(4096, rounded);
-  if (!p) {
-    fail(-3, "aligned_alloc(%llu) failed", (unsigned long long)rounded);
-    return nullptr;
-  }
-  hipError_t e = hipHostRegister(p, rounded, hipHostRegisterDefault);
+  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
   if (e != hipSuccess) {
-    free(p);
-    fail(-3, "hipHostRegister(%llu) failed: %s", (unsigned long long)rounded, hipGetErrorString(e));
+    fail(-3, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
     return nullptr;
   }
   return p;
 }
 
 int dxm_host_free(void* p) {
-  if (!p) return 0;
-  hipError_t e = hipHostUnregister(p);
-  free(p);
-  if (e != hipSuccess) return fail(-2, "hipHostUnregister failed: %s", hipGetErrorString(e));
+  if (p) HIP_TRY(hipHostFree(p));
   return 0;
 }
 
