@@ -19,7 +19,9 @@ earlier increments, and every handle runs ``tune_placement`` once with the real 
 recommended budget: 4 candidate allocations, at most 2 GiB of skip blocks) -- the kernel has a fast and a
 slow mode in where the resident state sits relative to them (DESIGN.md section 3);
 ``config.placement_tuning`` reports what that did, ``roofline.untuned`` carries the figure of the same
-launches before it, ``--no-tune`` skips it, ``--tune-candidates 24 --tune-skip-gib 16`` is round 1's deep search.
+launches before it, ``--no-tune`` skips it, ``--tune-candidates 24 --tune-skip-gib 16`` is round 1's deep search; a handle
+that is still in the slow mode after the small search (below ``--tune-extend-below`` = 0.72 of the HBM peak: on some boxes
+every nearby allocation is slow) gets that deep search once, and the record says so.
 
 The JSON line also carries
   roofline      achieved algorithmic HBM GB/s of the constitutive kernel (496 B/point x points
@@ -374,6 +376,9 @@ def main():
                     help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
     ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle")
     ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
+    ap.add_argument("--tune-extend-below", type=float, default=0.72,
+                    help="a handle whose kernel is still below this fraction of the HBM peak after the small search gets one "
+                         "deep search (24 candidates, skip blocks up to 16 GiB); 0 disables")
     ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -477,8 +482,17 @@ def main():
             try:
                 m.set_option("tune_max_skip_bytes", args.tune_skip_gib * 2**30)
                 info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
-                tuning.append({"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4),
-                               "candidates_tried": info["candidates_tried"]})
+                rec = {"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4),
+                       "candidates_tried": info["candidates_tried"]}
+                # still in the slow mode after the small search (some boxes put every nearby allocation there, DESIGN.md
+                # section 3): one deep search for this handle -- more candidates, skip blocks of up to 16 GiB
+                frac = ALG_BYTES * n / (info["ms_after"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if frac < args.tune_extend_below and args.tune_candidates < 24:
+                    m.set_option("tune_max_skip_bytes", 16 * 2**30)
+                    deep = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=24)
+                    rec["deep_search"] = {"because_frac": round(frac, 4), "ms_after": round(deep["ms_after"], 4),
+                                          "candidates_tried": deep["candidates_tried"]}
+                tuning.append(rec)
             except Exception as exc:  # an optimisation of the setup: never lose the run over it
                 tuning.append({"error": repr(exc)})
 
