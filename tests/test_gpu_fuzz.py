@@ -1,0 +1,116 @@
+"""GPU: randomised parity sweep of the HIP path against the C oracle over the PARAMETER space, not only the BASELINE
+values -- elastic constants, yield stress, hardening from perfect plasticity to steep Voce laws, strain amplitudes up to
+tens of yield strains, non-proportional three-increment histories with reversals (small strain) and finite stretches
+and shears up to 30 % (FeFp).  Same acceptance as tests/test_gpu_parity.py: points within 1e-9 sig0 of the yield surface
+are excluded (either branch is right there), everything else must agree with the oracle to 1e-10 of the batch's scale."""
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from dolfinx_materials_amd.jaxmat import JAXMaterial
+from oracle import constitutive_np as onp
+from oracle import oracle_c
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def rel(a, b, scale=None):
+    scale = np.abs(b).max() if scale is None else scale
+    return np.abs(a - b).max() / max(scale, 1e-300)
+
+
+def draw_elastic(rng):
+    return float(10 ** rng.uniform(3, 5.5)), float(rng.uniform(0.0, 0.49))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_j2_random_parameters_and_nonproportional_histories(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = 20_000
+    E, nu = draw_elastic(rng)
+    mu = E / 2 / (1 + nu)
+    sig0 = float(10 ** rng.uniform(1, 3.3))
+    voce = seed % 2 == 1
+    if voce:
+        sigu, b = sig0 * float(rng.uniform(1.0, 3.0)), float(10 ** rng.uniform(0, 4.5))
+        hard, kind, h1, h2 = jm.VoceHardening(sig0, sigu, b), 1, sigu, b
+    else:
+        H = 0.0 if seed == 0 else float(rng.uniform(0.0, 0.5)) * E      # seed 0: perfect plasticity
+        hard, kind, h1, h2 = jm.LinearHardening(sig0, H), 0, H, 0.0
+    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=nu), hard))
+    m.set_data_manager(n)
+    ey = sig0 / (2 * mu) * np.sqrt(2.0 / 3.0)
+    amp = float(10 ** rng.uniform(0, 1.6))
+    epsp, p = np.zeros((n, 6)), np.zeros(n)
+    eps = np.zeros((n, 6))
+    nplastic = 0
+    for inc in range(3):
+        d = rng.standard_normal((n, 6))
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        eps = eps * (0.3 if inc == 2 else 1.0) + d * (rng.uniform(0, amp, n) * ey)[:, None]   # increment 2: partial reversal
+        sig, isv, ct = m.integrate(eps)
+        ref = oracle_c.j2(eps, epsp, p, E, nu, kind, sig0, h1, h2)
+        assert ref["n_not_converged"] == 0 and m.last_stats["n_not_converged"] == 0 and m.last_stats["n_nan"] == 0
+        e_el = eps - epsp
+        f_tr = np.sqrt(1.5) * np.linalg.norm(2 * mu * (e_el - np.outer(e_el[:, :3].sum(1) / 3, [1, 1, 1, 0, 0, 0])), axis=1) \
+            - (sig0 + h1 * p if kind == 0 else sig0 + (h1 - sig0) * (1 - np.exp(-h2 * p)))
+        safe = np.abs(f_tr) > 1e-9 * sig0
+        assert safe.mean() > 0.99
+        assert rel(np.asarray(sig)[safe], ref["sig"][safe]) < TOL, ("sig", E, nu, sig0, h1, h2)
+        assert rel(np.asarray(ct)[safe], ref["Ct"][safe]) < TOL, ("Ct", E, nu, sig0, h1, h2)
+        isv = np.asarray(isv)
+        assert np.abs(isv[safe, 0] - ref["p"][safe]).max() < TOL * max(ref["p"].max(), 1e-300) + 1e-18
+        assert rel(isv[safe, 1:], ref["epsp"][safe], scale=max(np.abs(ref["epsp"]).max(), 1e-300)) < TOL
+        nplastic += m.last_stats["n_plastic"]
+        m.data_manager.update()
+        epsp, p = ref["epsp"], ref["p"]
+    assert nplastic > 0
+    m.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fefp_random_parameters_and_finite_deformations(seed):
+    rng = np.random.default_rng(2000 + seed)
+    n = 6_000
+    E, nu = draw_elastic(rng)
+    nu = min(nu, 0.45)
+    sig0 = float(10 ** rng.uniform(1.5, 3.3))
+    voce = seed % 2 == 0
+    if voce:
+        sigu, b = sig0 * float(rng.uniform(1.0, 2.5)), float(10 ** rng.uniform(0, 3.5))
+        hard, kind, h1, h2 = jm.VoceHardening(sig0, sigu, b), 1, sigu, b
+        ohard = onp.VoceHardening(sig0, sigu, b)
+    else:
+        H = float(rng.uniform(0.0, 0.2)) * E
+        hard, kind, h1, h2 = jm.LinearHardening(sig0, H), 0, H, 0.0
+        ohard = onp.LinearHardening(sig0, H)
+    m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=nu), hard))
+    m.set_data_manager(n)
+    st = onp.fefp_initial_state(n)
+    cp, p = st["cpinv"], st["p"]
+    amp = float(rng.uniform(0.02, 0.3))
+    A = rng.standard_normal((n, 3, 3)) * (rng.uniform(0, amp, n) / 3.0)[:, None, None]
+    nplastic = 0
+    for t in (0.4, 1.0, 0.7):          # load, load, partial unload along the same path
+        F = np.eye(3)[None] + t * A
+        F9 = onp.tensor_to_nsym(F)
+        P, isv, Ct = m.integrate(F9)
+        ref = oracle_c.fefp(F9, cp, p, E, nu, sig0, h1, h2, kind=kind)
+        chk = onp.fefp_update(F9[:50], cp[:50], p[:50], E, nu, ohard)    # the numpy restatement agrees with the C one
+        assert rel(chk["P"], ref["P"][:50]) < 1e-11
+        ok = np.isfinite(ref["P"]).all(axis=1)
+        assert ref["n_not_converged"] == 0 and m.last_stats["n_not_converged"] == 0 and m.last_stats["n_nan"] == 0 and ok.all()
+        ftr = onp.fefp_update(F9, cp, p, E, nu, ohard, tangent=False)["f_trial"]
+        safe = np.abs(ftr) > 1e-9 * sig0
+        assert safe.mean() > 0.99
+        assert rel(np.asarray(P)[safe], ref["P"][safe]) < TOL, ("P", E, nu, sig0, h1, h2, amp)
+        assert rel(np.asarray(Ct)[safe], ref["Ct"][safe]) < 10 * TOL, ("Ct", E, nu, sig0, h1, h2, amp)
+        isv = np.asarray(isv)
+        assert np.abs(isv[safe, 0] - ref["p"][safe]).max() < TOL * max(ref["p"].max(), 1e-300) + 1e-18
+        assert rel(isv[safe, 1:], ref["be_bar"][safe]) < TOL
+        nplastic += m.last_stats["n_plastic"]
+        m.data_manager.update()
+        cp, p = ref["cpinv"], ref["p"]
+    assert nplastic > 0
+    m.close()
