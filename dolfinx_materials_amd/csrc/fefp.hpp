@@ -272,6 +272,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       double cf[9];
       cof3(F, cf);
       J = F[0] * cf[0] + F[1] * cf[1] + F[2] * cf[2];
+      // an inverted or flat point (det F <= 0) has no answer: J^(-2/3) is NaN in the reference's arithmetic and
+      // QuadratureMap.update asserts on it (quadrature_map.py:322-324); cbrt(J^2) below would quietly accept it
+      J = J > 0.0 ? J : __builtin_nan("");
       const double iJ = fast_rcp(J);
 #pragma unroll
       for (int r = 0; r < 3; ++r)

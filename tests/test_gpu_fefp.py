@@ -136,3 +136,28 @@ def test_fefp_with_linear_hardening_matches_oracle():
         m.data_manager.update()
         cp, p = ref["cpinv"], ref["p"]
     assert ref["plastic"].all()
+
+
+def test_inverted_points_are_reported_not_computed():
+    """det F <= 0: the reference's arithmetic gives NaN (J^(-2/3)) and QuadratureMap.update asserts on it
+    (quadrature_map.py:322-324); the kernel must poison exactly those points, count them, and leave the others alone."""
+    n = 1000
+    rng = np.random.default_rng(11)
+    F = np.eye(3)[None] + 0.05 * rng.standard_normal((n, 3, 3))
+    bad = np.arange(0, n, 37)
+    F[bad, 0, :] *= -1.0                      # reflected: det F < 0
+    F[5] = 0.0
+    F[5, 0, 0] = F[5, 1, 1] = 1.0             # flat: det F = 0
+    bad = np.union1d(bad, [5])
+    F9 = onp.tensor_to_nsym(F)
+    m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_F, SIGU_F, B_F)))
+    m.set_data_manager(n)
+    P, _, Ct = m.integrate(F9)                # (QuadratureMap's own `assert not np.isnan` then fires, as upstream)
+    assert m.last_stats["n_nan"] == len(bad)
+    P, Ct = np.asarray(P), np.asarray(Ct)
+    assert np.isnan(Ct[bad]).all() and np.isfinite(Ct[good_ := np.setdiff1d(np.arange(n), bad)]).all()
+    good = np.setdiff1d(np.arange(n), bad)
+    assert np.isnan(P[bad]).all() and np.isfinite(P[good]).all()
+    st = onp.fefp_initial_state(n)
+    ref = onp.fefp_update(F9[good], st["cpinv"][good], st["p"][good], E, NU, onp.VoceHardening(SIG0_F, SIGU_F, B_F))
+    assert relerr(P[good], ref["P"]) < TIGHT
