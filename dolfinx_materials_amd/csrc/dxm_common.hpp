@@ -17,7 +17,8 @@ struct LawParams {
   double sig0;     // initial yield stress
   double h1;       // linear: H           | Voce: sigu
   double h2;       // linear: unused      | Voce: b
-  double tol;      // absolute residual tolerance of the local Newton (= rtol * sig0)
+  double tol;      // absolute residual tolerance of the local Newton (= rtol * max(|sig0|, 2e-8 mu))
+  double rtol;     // the relative one it was built from
   int32_t maxit;   // local Newton iteration cap
   int32_t pad;
   double c[6];     // parameters of a user-supplied hardening law (JIT builds only, see below)

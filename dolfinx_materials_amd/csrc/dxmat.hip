@@ -336,7 +336,9 @@ static int build_params(dxm_material* m, const double* p, int np) {
       break;
   }
   q.maxit = m->maxit;
-  q.tol = m->rtol * fabs(q.sig0);
+  // relative to the initial yield stress, floored so that a law with R(0) = 0 keeps a reachable tolerance
+  q.rtol = m->rtol;
+  q.tol = m->rtol * fmax(fabs(q.sig0), 2e-8 * q.mu);
   m->prm = q;
   m->raw_params.assign(p, p + np);
   return 0;

@@ -324,7 +324,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       cs[4] = sh[3] * sh[5] - sh[4] * sh[1];
       cs[5] = sh[3] * sh[4] - sh[0] * sh[5];
       const double delta = sh[0] * cs[0] + sh[3] * cs[3] + sh[4] * cs[4];
-      const double tol1 = (prm.tol / fabs(prm.sig0)) * fmax(fabs(prm.sig0), SQ32 * mu * atr);
+      const double tol1 = fmax(prm.tol, prm.rtol * (SQ32 * mu * atr));
       unsigned iters = 0;
       // the hardening law (an exp for Voce, anything for a traced law) is evaluated once per iterate: the first
       // iterate (dp = 0) reuses the values of the yield test, the converged ones are reused after the loop

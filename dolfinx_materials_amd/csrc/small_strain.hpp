@@ -243,10 +243,12 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           dp = f / (prm.h1 + 3.0 * mu);                       // mfront:62-63
         } else {
           // r(dp) = seq - 3 mu dp - R(p_n + dp) = 0, monotone Newton from dp = 0
+          // tolerance relative to the larger of the yield stress and the trial stress the residual is made of
           dp = 0.0;
+          const double tolp = fmax(prm.tol, prm.rtol * seq);
           for (int it = 0;; ++it) {
             const double r = seq - 3.0 * mu * dp - hardening_R<LAW>(prm, p_n + dp);
-            if (fabs(r) <= prm.tol) break;
+            if (fabs(r) <= tolp) break;
             if (it >= prm.maxit) { if (valid) ++c_notconv; break; }
             const double dr = -3.0 * mu - hardening_dR<LAW>(prm, p_n + dp);
             dp -= r / dr;

@@ -125,7 +125,13 @@ class VoceHardening:
 
 #: Newton controls shared by the oracle, the C restatement and the HIP kernels
 NEWTON_MAXIT = 25
-NEWTON_RTOL = 1e-14  # |r| <= rtol * sig0
+NEWTON_RTOL = 1e-14  # |r| <= rtol * max(stress_scale(sig0, mu), trial stress)
+
+
+def stress_scale(sig0, mu):
+    """Stress the local Newton tolerance is relative to: the initial yield stress, floored at 2e-8 mu so that a law with
+    R(0) = 0 (hardening from zero) still has a reachable tolerance (dxmat.hip::build_params)."""
+    return max(abs(float(sig0)), 2e-8 * float(mu))
 
 
 def _solve_dp(seq, p_n, mu, hard, maxit=NEWTON_MAXIT, rtol=NEWTON_RTOL):
@@ -141,7 +147,7 @@ def _solve_dp(seq, p_n, mu, hard, maxit=NEWTON_MAXIT, rtol=NEWTON_RTOL):
     active = np.ones(seq.shape, dtype=bool)
     for _ in range(maxit):
         r = seq - 3 * mu * dp - hard.R(p_n + dp)
-        active = np.abs(r) > rtol * hard.sig0
+        active = np.abs(r) > np.maximum(rtol * stress_scale(hard.sig0, mu), rtol * seq)
         if not active.any():
             break
         dr = -3 * mu - hard.dR(p_n + dp)
@@ -290,7 +296,7 @@ def _cof3(A):
 
 
 def fefp_scale_tol(hard, mu, a_tr, rtol=NEWTON_RTOL):
-    return rtol * np.maximum(hard.sig0, SQ32 * mu * a_tr)
+    return np.maximum(rtol * stress_scale(hard.sig0, mu), rtol * (SQ32 * mu * a_tr))
 
 
 def fefp_update(F9, cpinv_n, p_n, E, nu, hard, maxit=NEWTON_MAXIT, rtol=NEWTON_RTOL, tangent=True):

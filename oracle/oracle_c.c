@@ -83,7 +83,7 @@ int64_t orc_j2(int64_t n, const double* eps, const double* epsp_n, const double*
       } else {
         for (int it = 0;; ++it) {
           const double r = seq - 3 * mu * dp - hard_R(kind, s0, h1, h2, pn + dp);
-          if (fabs(r) <= rtol * s0) break;
+          if (fabs(r) <= fmax(rtol * fmax(fabs(s0), 2e-8 * mu), rtol * seq)) break;
           if (it >= ORC_MAXIT) { ++notconv; break; }
           dp -= r / (-3 * mu - hard_dR(kind, s0, h1, h2, pn + dp));
         }
@@ -198,7 +198,7 @@ int64_t orc_fefp(int64_t n, const double* F9, const double* cpinv_n, const doubl
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) sh[i][j] = d[i][j] / atr;
       delta = det3(sh);
-      const double tol1 = rtol * fmax(s0, SQ32 * mu * atr);
+      const double tol1 = fmax(rtol * fmax(fabs(s0), 2e-8 * mu), rtol * (SQ32 * mu * atr));
       for (int it = 0;; ++it) {
         const double aa = SQ23 * hard_R(kind, s0, su, b, pn + dp) / mu;
         const double r1 = atr - aa - SQ6 * dp * Ie;

@@ -114,3 +114,32 @@ def test_fefp_random_parameters_and_finite_deformations(seed):
         cp, p = ref["cpinv"], ref["p"]
     assert nplastic > 0
     m.close()
+
+
+@pytest.mark.parametrize("law", ["j2", "fefp"])
+def test_hardening_from_zero_initial_yield_stress_converges(law):
+    """R(0) = 0 (Voce law rising from zero): the local Newton tolerance is relative to max(|sig0|, 2e-8 mu), not to a
+    zero yield stress -- every point converges and matches the oracle (before: tolerance 0, every plastic point
+    reported as not converged)."""
+    rng = np.random.default_rng(77)
+    n = 5000
+    E, nu, sigu, b = 70e3, 0.3, 400.0, 300.0
+    hard = jm.VoceHardening(0.0, sigu, b)
+    el = jm.LinearElasticIsotropic(E=E, nu=nu)
+    if law == "j2":
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(el, hard))
+        m.set_data_manager(n)
+        eps = 3e-3 * rng.standard_normal((n, 6))
+        sig, isv, ct = m.integrate(eps)
+        ref = oracle_c.j2(eps, np.zeros((n, 6)), np.zeros(n), E, nu, 1, 0.0, sigu, b)
+        assert rel(np.asarray(sig), ref["sig"]) < TOL and rel(np.asarray(ct), ref["Ct"]) < TOL
+    else:
+        m = JAXMaterial(jm.FeFpJ2Plasticity(el, hard))
+        m.set_data_manager(n)
+        F9 = onp.tensor_to_nsym(np.eye(3)[None] + 0.02 * rng.standard_normal((n, 3, 3)))
+        st = onp.fefp_initial_state(n)
+        P, isv, Ct = m.integrate(F9)
+        ref = oracle_c.fefp(F9, st["cpinv"], st["p"], E, nu, 0.0, sigu, b, kind=1)
+        assert rel(np.asarray(P), ref["P"]) < TOL and rel(np.asarray(Ct), ref["Ct"]) < 10 * TOL
+    assert m.last_stats["n_plastic"] == n and m.last_stats["n_not_converged"] == 0 and ref["n_not_converged"] == 0
+    m.close()
