@@ -626,7 +626,10 @@ int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos)
   const int dim = d.isv_dim[field];
   const int64_t n = m->n;
   if (n == 0) return 0;
-  if (which == DXM_S1) if (int rc = materialize_s1(m)) return rc;
+  // s1 served from s0 (after advance / revert) gets its own storage before EITHER is written: writing s1 must not
+  // touch s0, and writing s0 must not change what s1 shows (the reference rebinds `data_manager.s0` and leaves s1
+  // alone, generic.py:200-201 / jaxmat.py:205-206; found by tests/test_gpu_fuzz_protocol.py: advance, set, advance)
+  if (int rc = materialize_s1(m)) return rc;
   // upload the AoS block and transpose on the device (a host-side transposition of 6 x 1e7
   // doubles costs more than the PCIe transfer)
   if (!m->d_field) HIP_TRY(hipMalloc(&m->d_field, sizeof(double) * n * 6));

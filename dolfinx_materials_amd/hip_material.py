@@ -399,6 +399,7 @@ class HIPMaterial:
         self._chk(self._lib.dxm_revert(self._require()))
         self._grad[1] = self._grad[0]
         self._flux[1] = self._flux[0]
+        self._serial += 1   # s1 changed: lazy ISV views refetch
 
     # ---- protocol: the hot path -----------------------------------------------------------------
     def integrate(self, gradients, dt=0):
