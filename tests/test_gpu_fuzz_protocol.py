@@ -20,11 +20,12 @@ class Model:
 
     def __init__(self, n):
         self.n = n
+        self.sig0 = SIG0_V
         self.s0 = dict(p=np.zeros(n), epsp=np.zeros((n, 6)), stress=np.zeros((n, 6)))
         self.s1 = {k: v.copy() for k, v in self.s0.items()}
 
     def integrate(self, eps):
-        r = oracle_c.j2(eps, self.s0["epsp"], self.s0["p"], E, NU, 1, SIG0_V, SIGU_V, B_V)
+        r = oracle_c.j2(eps, self.s0["epsp"], self.s0["p"], E, NU, 1, self.sig0, SIGU_V, B_V)
         self.s1 = dict(p=r["p"].copy(), epsp=r["epsp"].copy(), stress=r["sig"].copy())
         return r
 
@@ -54,8 +55,14 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     ey = SIG0_V / (2 * mu) * np.sqrt(2.0 / 3.0)
     eps = np.zeros((n, 6))
     held = None           # (isv object of an earlier integrate, what it must show when looked at)
-    ops = rng.choice(["integrate", "integrate", "integrate", "update", "revert", "get", "set", "look"], size=40)
-    did_integrate = False
+    ops = rng.choice(["integrate", "integrate", "integrate", "update", "revert", "get", "set", "look", "device", "tune", "prop"], size=48)
+    known = {"initial": False, "final": False}   # whether the host-side stress mirror of s0 / s1 is meaningful
+    import torch
+
+    dev = torch.device("cuda:0")
+    d_flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    d_ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+    sig0_now = SIG0_V
     for op in ops:
         if op == "integrate":
             d = rng.standard_normal((n, 6))
@@ -68,19 +75,44 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
                 assert close(flux_fn, ref["sig"].ravel(), scale) and close(jac_fn, ref["Ct"].ravel(), np.abs(ref["Ct"]).max())
             assert m.last_stats["n_plastic"] == ref["n_plastic"] and m.last_stats["n_nan"] == 0
             held = isv
-            did_integrate = True
+            known["final"] = True
+        elif op in ("device", "tune"):
+            # device-pointer forms: asynchronous launch on torch's stream / the placement search (which acts like one
+            # integrate_device and may move the resident state to another allocation)
+            d = rng.standard_normal((n, 6))
+            eps = 0.6 * eps + d * (rng.uniform(0, 3.0, n) * ey / np.linalg.norm(d, axis=1))[:, None]
+            d_eps = torch.from_numpy(eps).to(dev)
+            st = torch.cuda.current_stream().cuda_stream
+            if op == "device":
+                m.integrate_device(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr(), st)
+            else:
+                m.tune_placement(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr(), max_candidates=3)
+            torch.cuda.synchronize()
+            ref = model.integrate(eps)
+            scale = max(np.abs(ref["sig"]).max(), SIG0_V)
+            assert close(d_flux.cpu().numpy(), ref["sig"], scale) and close(d_ct.cpu().numpy(), ref["Ct"].reshape(n, 36), np.abs(ref["Ct"]).max())
+            assert m.stats()[1]["n_plastic"] == ref["n_plastic"]
+            known["final"] = False      # the host-side stress mirror does not follow the device-pointer forms
+            held = None
+        elif op == "prop":
+            # QuadratureMap.update_material_properties hands 0-d arrays (quadrature_map.py:160-172)
+            sig0_now = float(rng.uniform(0.8, 1.2)) * SIG0_V
+            m.update_material_property("yield_stress.sig0", np.asarray(sig0_now))
+            model.sig0 = sig0_now
         elif op == "update":
             m.data_manager.update()
             model.update()
+            known["initial"] = known["final"]
         elif op == "revert":
             m.data_manager.revert()
             model.revert()
+            known["final"] = known["initial"]
         elif op == "get":
             for which, st in (("initial", model.s0), ("final", model.s1)):
                 got = m.get_initial_state_dict() if which == "initial" else m.get_final_state_dict()
                 assert close(got["p"], st["p"][:, None], max(st["p"].max(), 1e-300) + 1e-30), which
                 assert close(got["epsp"], st["epsp"], max(np.abs(st["epsp"]).max(), 1e-300) + 1e-30), which
-                if did_integrate:
+                if known[which]:
                     assert close(got["stress"], st["stress"], max(np.abs(st["stress"]).max(), SIG0_V)), which
         elif op == "set":
             # a consistent plastic state: p >= 0 and a deviatoric plastic strain
