@@ -128,3 +128,59 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
             assert close(a[:, 0], model.s1["p"], max(model.s1["p"].max(), 1e-300) + 1e-30)
             assert close(a[:, 1:], model.s1["epsp"], max(np.abs(model.s1["epsp"]).max(), 1e-300) + 1e-30)
     m.close()
+
+
+@pytest.mark.parametrize("seed,n", [(10, 500), (11, 64), (12, 3001)])
+def test_random_operation_sequences_fefp(seed, n):
+    """The same for the finite-strain law, whose user-visible state (p, be_bar) is not what the kernel keeps: the hidden
+    isochoric Cp^-1 follows from (F_n, be_bar_n), so `set_initial_state_dict` with `be_bar` and / or `F` goes through
+    `conventions.cp_bar_inv_from_be_bar` with the s0 gradient mirror (hip_material.py)."""
+    from helpers import SIG0_F, SIGU_F, B_F
+    from oracle import constitutive_np as onp
+
+    rng = np.random.default_rng(seed)
+    m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_F, SIGU_F, B_F)))
+    m.set_data_manager(n)
+    ident6 = np.zeros((n, 6))
+    ident6[:, :3] = 1.0
+    ident9 = np.zeros((n, 9))
+    ident9[:, :3] = 1.0
+    s0 = dict(p=np.zeros(n), be_bar=ident6.copy(), cpinv=ident6.copy(), F=ident9.copy())
+    s1 = {k: v.copy() for k, v in s0.items()}
+    A = rng.standard_normal((n, 3, 3)) * 0.03
+    t = 0.0
+    for op in rng.choice(["integrate", "integrate", "update", "revert", "get", "set_be", "set_F_be"], size=30):
+        if op == "integrate":
+            t = float(np.clip(t + rng.uniform(-0.3, 0.6), -1.0, 2.0))
+            F9 = onp.tensor_to_nsym(np.eye(3)[None] + t * A)
+            P, isv, Ct = m.integrate(F9)
+            ref = oracle_c.fefp(F9, s0["cpinv"], s0["p"], E, NU, SIG0_F, SIGU_F, B_F, kind=1)
+            assert ref["n_not_converged"] == 0 and m.last_stats["n_nan"] == 0
+            assert close(P, ref["P"], max(np.abs(ref["P"]).max(), SIG0_F)) and close(Ct, ref["Ct"], np.abs(ref["Ct"]).max() * 10)
+            s1 = dict(p=ref["p"].copy(), be_bar=ref["be_bar"].copy(), cpinv=ref["cpinv"].copy(), F=F9.copy())
+        elif op == "update":
+            m.data_manager.update()
+            s0 = {k: v.copy() for k, v in s1.items()}
+        elif op == "revert":
+            m.data_manager.revert()
+            s1 = {k: v.copy() for k, v in s0.items()}
+        elif op == "get":
+            for got, st in ((m.get_initial_state_dict(), s0), (m.get_final_state_dict(), s1)):
+                assert close(got["p"], st["p"][:, None], max(st["p"].max(), 1e-300) + 1e-30)
+                assert close(got["be_bar"], st["be_bar"], 1.0) and close(got["F"], st["F"], 1.0)
+        else:
+            # a consistent visible state: be_bar symmetric positive definite with unit determinant, p >= 0
+            B = np.eye(3)[None] + 0.02 * rng.standard_normal((n, 3, 3))
+            be = B @ B.transpose(0, 2, 1)
+            be /= np.cbrt(np.linalg.det(be))[:, None, None]
+            be6 = onp.tensor_to_mandel(be)
+            p = rng.uniform(0, 5e-3, n)
+            state = {"p": p, "be_bar": be6}
+            if op == "set_F_be":
+                Fn = onp.tensor_to_nsym(np.eye(3)[None] + 0.02 * rng.standard_normal((n, 3, 3)))
+                state["F"] = Fn
+                s0["F"] = Fn.copy()
+            m.set_initial_state_dict(state)
+            s0["p"], s0["be_bar"] = p.copy(), be6.copy()
+            s0["cpinv"] = onp.cpinv_from_be_bar(s0["F"], be6)
+    m.close()
