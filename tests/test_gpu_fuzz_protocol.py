@@ -184,3 +184,67 @@ def test_random_operation_sequences_fefp(seed, n):
             s0["p"], s0["be_bar"] = p.copy(), be6.copy()
             s0["cpinv"] = onp.cpinv_from_be_bar(s0["F"], be6)
     m.close()
+
+
+@pytest.mark.parametrize("seed,subset", [(20, False), (21, True), (22, True), (23, False)])
+def test_field_map_driven_by_the_engine_equals_field_map_driven_by_the_oracle(seed, subset):
+    """Differential test one level up: the SAME random sequence of QuadratureFieldMap operations (update, advance,
+    update_initial_state with numbers / rows / current content, refresh of the ISV fields, several updates per
+    increment) once with HIPMaterial behind the map and once with the oracle-backed material of tests/oracle_material.py;
+    every field must agree after every operation (maps over all cells bind the engine's output arrays, maps over a
+    subset scatter rows: field_map.py)."""
+    from dolfinx_materials_amd.field_map import QuadratureFieldMap
+    from oracle import constitutive_np as onp
+    from oracle_material import OracleJ2Material
+
+    rng = np.random.default_rng(seed)
+    ncell, nqp = int(rng.integers(3, 40)), int(rng.choice([1, 4, 8]))
+    cells = np.sort(rng.choice(ncell, size=max(1, ncell // 2), replace=False)).astype(np.int32) if subset else None
+    beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
+    maps = [QuadratureFieldMap(ncell, nqp, JAXMaterial(beh), cells=cells),
+            QuadratureFieldMap(ncell, nqp, OracleJ2Material(E, NU, onp.VoceHardening(SIG0_V, SIGU_V, B_V)), cells=cells)]
+    mu = E / 2 / (1 + NU)
+    ey = SIG0_V / (2 * mu) * np.sqrt(2.0 / 3.0)
+    strain = {"all": np.zeros((ncell * nqp, 6))}
+    for qm in maps:
+        qm.register_gradient("strain", lambda c: strain["all"].reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+
+    def same(what):
+        a, b = maps
+        for name in ("stress",):
+            assert close(a.fluxes[name].values, b.fluxes[name].values, SIG0_V), (what, name)
+        assert close(a.jacobian_flatten.values, b.jacobian_flatten.values.reshape(a.jacobian_flatten.values.shape), E), (what, "jacobian")
+        for name in ("p", "epsp"):
+            fa, fb = a.internal_state_variables[name].values, b.internal_state_variables[name].values
+            assert close(fa, fb, max(np.abs(fb).max(), 1e-6)), (what, name)
+
+    for op in rng.choice(["update", "update", "advance", "init_number", "init_rows", "init_current", "refresh"], size=30):
+        if op == "update":
+            d = rng.standard_normal((ncell * nqp, 6))
+            strain["all"] = 0.7 * strain["all"] + d * (rng.uniform(0, 2.5, ncell * nqp) * ey / np.linalg.norm(d, axis=1))[:, None]
+            for qm in maps:
+                qm.update()
+        elif op == "advance":
+            if not all(getattr(qm, "_initialized") and hasattr(qm, "_last_isv") for qm in maps):
+                continue
+            for qm in maps:
+                qm.advance()
+        elif op == "refresh":
+            if not all(hasattr(qm, "_last_isv") for qm in maps):
+                continue
+            for qm in maps:
+                qm.refresh_internal_state_variables()
+        elif op == "init_number":
+            v = float(rng.uniform(0, 3e-3))
+            for qm in maps:
+                qm.update_initial_state("p", v)
+        elif op == "init_rows":
+            row = rng.standard_normal(6) * 1e-3
+            row[:3] -= row[:3].mean()
+            for qm in maps:
+                qm.update_initial_state("epsp", row)
+        else:
+            for qm in maps:
+                qm.update_initial_state("p")
+        same(op)
+    maps[0].material.close()
