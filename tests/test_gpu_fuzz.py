@@ -75,7 +75,7 @@ def test_fefp_random_parameters_and_finite_deformations(seed):
     n = 6_000
     E, nu = draw_elastic(rng)
     nu = min(nu, 0.45)
-    sig0 = float(10 ** rng.uniform(1.5, 3.3))
+    sig0 = min(float(10 ** rng.uniform(1.5, 3.3)), 0.01 * E)            # yield strains of at most a few per cent
     voce = seed % 2 == 0
     if voce:
         sigu, b = sig0 * float(rng.uniform(1.0, 2.5)), float(10 ** rng.uniform(0, 3.5))
@@ -89,7 +89,8 @@ def test_fefp_random_parameters_and_finite_deformations(seed):
     m.set_data_manager(n)
     st = onp.fefp_initial_state(n)
     cp, p = st["cpinv"], st["p"]
-    amp = float(rng.uniform(0.02, 0.3))
+    mu_ = E / 2 / (1 + nu)
+    amp = max(float(rng.uniform(0.02, 0.3)), 6.0 * sig0 / (2 * mu_))     # reaches a few yield strains whatever E / sig0
     A = rng.standard_normal((n, 3, 3)) * (rng.uniform(0, amp, n) / 3.0)[:, None, None]
     nplastic = 0
     for t in (0.4, 1.0, 0.7):          # load, load, partial unload along the same path
