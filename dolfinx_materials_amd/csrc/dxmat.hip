@@ -249,6 +249,7 @@ struct dxm_material {
   size_t s1_skew = 0;
   bool s1_alias = false;  // after advance()/revert() s1 == s0 until the next integrate: no copy is made
   BlockStats* d_stats = nullptr;
+  BlockStats* h_stats = nullptr;   // page-locked landing of the block records (no DMA into pageable memory)
   int stats_capacity = 0;
   int last_grid = 0;                      // stats records written by the last integrate
   hipStream_t pipe_stream = nullptr;      // second stream of the chunk-pipelined host path
@@ -285,6 +286,8 @@ struct dxm_material {
   double* d_isv = nullptr;
   double* d_ct = nullptr;
   double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
+  double* h_bounce = nullptr; // page-locked staging of download_to_host (2 x BOUNCE_BYTES)
+  hipEvent_t bounce_done[2] = {nullptr, nullptr};
 };
 
 static int sync_last(dxm_material* m);
@@ -537,11 +540,14 @@ int dxm_destroy(dxm_material* m) {
   if (m->last_event) (void)hipEventDestroy(m->last_event);
   free_state(m);
   if (m->d_stats) (void)hipFree(m->d_stats);
+  if (m->h_stats) (void)hipHostFree(m->h_stats);
   if (m->d_grad) (void)hipFree(m->d_grad);
   if (m->d_flux) (void)hipFree(m->d_flux);
   if (m->d_isv) (void)hipFree(m->d_isv);
   if (m->d_ct) (void)hipFree(m->d_ct);
   if (m->d_field) (void)hipFree(m->d_field);
+  if (m->h_bounce) (void)hipHostFree(m->h_bounce);
+  for (hipEvent_t e : m->bounce_done) if (e) (void)hipEventDestroy(e);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->pipe_stream) (void)hipStreamDestroy(m->pipe_stream);
   delete m;
@@ -646,6 +652,47 @@ int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos)
   return 0;
 }
 
+// Device -> host into memory the caller owns.  Never a DMA into pageable memory: the runtime page-locks such a range
+// on the fly and keeps the mapping in a cache keyed by address; a range it has once mapped READ-ONLY (the source of an
+// earlier pageable upload -- e.g. a strain array numpy has freed since) comes back from that cache when a later
+// allocation at the same address is the DESTINATION, and the copy dies with "Memory access fault ... Write access to a
+// read-only page" (seen once in ~25 runs of the GPU test suite, at get_final_state_dict into a fresh np.empty).
+// Page-locked or registered destinations are written directly; anything else goes through the handle's own page-locked
+// staging, two halves in flight, copied out by the CPU.
+constexpr size_t BOUNCE_BYTES = 16u << 20;
+static bool page_locked(const void* host) {
+  hipPointerAttribute_t attr{};
+  const bool locked = host && hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();   // "not a registered pointer" is the expected answer for ordinary memory
+  return locked;
+}
+static int download_to_host(dxm_material* m, void* host, const void* dev, size_t bytes, hipStream_t st) {
+  if (page_locked(host)) {
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  }
+  if (!m->h_bounce) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_bounce), 2 * BOUNCE_BYTES, hipHostMallocDefault));
+    for (hipEvent_t& e : m->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  char* stage = reinterpret_cast<char*>(m->h_bounce);
+  const size_t nchunks = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
+  auto size_of = [&](size_t c) { return c + 1 < nchunks ? BOUNCE_BYTES : bytes - c * BOUNCE_BYTES; };
+  for (size_t c = 0; c <= nchunks; ++c) {
+    if (c < nchunks) {
+      HIP_TRY(hipMemcpyAsync(stage + (c & 1) * BOUNCE_BYTES, static_cast<const char*>(dev) + c * BOUNCE_BYTES, size_of(c),
+                             hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(m->bounce_done[c & 1], st));
+    }
+    if (c > 0) {   // the previous chunk lands while this one is in flight
+      HIP_TRY(hipEventSynchronize(m->bounce_done[(c - 1) & 1]));
+      memcpy(static_cast<char*>(host) + (c - 1) * BOUNCE_BYTES, stage + ((c - 1) & 1) * BOUNCE_BYTES, size_of(c - 1));
+    }
+  }
+  return 0;
+}
+
 int dxm_get_state(dxm_material* m, int which, int field, double* host_aos) {
   if (int rc = check_field(m, which, field)) return rc;
   if (!host_aos) return fail(-1, "null host pointer");
@@ -664,9 +711,7 @@ int dxm_get_state(dxm_material* m, int which, int field, double* host_aos) {
   hipLaunchKernelGGL(pack_isv_kernel, dim3(blocks), dim3(256), 0, st, state_of(m, which), m->ld, n,
                      m->d_field, map);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(host_aos, m->d_field, sizeof(double) * n * dim, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  return 0;
+  return download_to_host(m, host_aos, m->d_field, sizeof(double) * n * dim, st);
 }
 
 int dxm_advance(dxm_material* m) {
@@ -911,10 +956,11 @@ int dxm_get_stats(dxm_material* m, dxm_stats* stats) {
   s.n_points = m->n;
   if (m->launched && m->last_grid > 0) {
     DEVICE_GUARD(m);
-    std::vector<BlockStats> h(m->last_grid);
     if (int rc = sync_last(m)) return rc;
-    HIP_TRY(hipMemcpy(h.data(), m->d_stats, sizeof(BlockStats) * m->last_grid, hipMemcpyDeviceToHost));
-    for (const BlockStats& b : h) {
+    if (!m->h_stats) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_stats), sizeof(BlockStats) * m->stats_capacity, hipHostMallocDefault));
+    HIP_TRY(hipMemcpy(m->h_stats, m->d_stats, sizeof(BlockStats) * m->last_grid, hipMemcpyDeviceToHost));
+    for (int k = 0; k < m->last_grid; ++k) {
+      const BlockStats& b = m->h_stats[k];
       s.n_plastic += (int64_t)b.n_plastic;
       s.n_not_converged += (int64_t)b.n_not_converged;
       s.n_nan += (int64_t)b.n_nan;
@@ -1015,6 +1061,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));
   const int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
+  const bool flux_locked = page_locked(flux_aos), isv_locked = page_locked(isv_aos), ct_locked = page_locked(ct_aos);
   int stats_off = 0, issued = 0, submitted = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
   // no worker may still be writing into the caller's array when this function returns, error paths included
@@ -1036,7 +1083,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                               m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr, tl))
       return rc;
     stats_off += grid;
-    if (flux_aos)
+    if (flux_aos && flux_locked)
       HIP_TRY(hipMemcpyAsync(flux_aos + off * d.n_flux, m->d_flux + off * d.n_flux,
                              sizeof(double) * cnt * d.n_flux, hipMemcpyDeviceToHost, st));
     if (isv_aos && total > 0) {
@@ -1046,10 +1093,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       int rc = pack_isv_range(m, DXM_S1, off, cnt, m->d_isv + off * total, st);
       m->s1_alias = alias;
       if (rc) return rc;
-      HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
-                             hipMemcpyDeviceToHost, st));
+      if (isv_locked)
+        HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
+                               hipMemcpyDeviceToHost, st));
     }
-    if (ct_aos && !constant) {
+    if (ct_aos && !constant && (packed || ct_locked)) {
       double* dst = packed ? m->h_coef + off * np : ct_aos + off * nt;
       HIP_TRY(hipMemcpyAsync(dst, m->d_ct + off * nt, sizeof(double) * cnt * nt, hipMemcpyDeviceToHost, st));
     }
@@ -1081,6 +1129,14 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       submitted = c + 1;
     }
   }
+  // destinations in ordinary (pageable) memory were left out above: they are filled through the page-locked staging now
+  // (download_to_host; slower, and only a C caller that did not use dxm_host_alloc / dxm_host_register gets here)
+  if (flux_aos && !flux_locked)
+    if (int rc = download_to_host(m, flux_aos, m->d_flux, sizeof(double) * n * d.n_flux, m->own_stream)) return rc;
+  if (isv_aos && total > 0 && !isv_locked)
+    if (int rc = download_to_host(m, isv_aos, m->d_isv, sizeof(double) * n * total, m->own_stream)) return rc;
+  if (ct_aos && !constant && !packed && !ct_locked)
+    if (int rc = download_to_host(m, ct_aos, m->d_ct, sizeof(double) * n * nt, m->own_stream)) return rc;
   HIP_TRY(hipEventRecord(m->last_event, m->own_stream));   // everything of this call is complete already
   m->last_event_recorded = true;
   const auto t_landed = std::chrono::steady_clock::now();
@@ -1334,8 +1390,11 @@ static int ensure_operator_buffers(dxm_mesh* mesh) {
   if (mesh->d_fe) return 0;
   const int64_t ne = mesh->n_cells * 8;
   if (ne > INT32_MAX) return fail(-1, "too many cells for the 32-bit (cell, corner) table");
-  std::vector<int32_t> conn((size_t)ne);
-  HIP_TRY(hipMemcpy(conn.data(), mesh->d_conn, sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
+  // (through page-locked memory: see download_to_host)
+  int32_t* conn = nullptr;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&conn), sizeof(int32_t) * ne, hipHostMallocDefault));
+  struct Unpin { void* p; ~Unpin() { (void)hipHostFree(p); } } unpin{conn};
+  HIP_TRY(hipMemcpy(conn, mesh->d_conn, sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
   std::vector<int64_t> ptr((size_t)mesh->n_nodes + 1, 0);
   for (int64_t k = 0; k < ne; ++k) ++ptr[(size_t)conn[k] + 1];
   for (int64_t v = 0; v < mesh->n_nodes; ++v) ptr[v + 1] += ptr[v];
@@ -1628,9 +1687,7 @@ int dxm_isv_host(dxm_material* m, int which, double* isv_aos) {
   if (int rc = sync_last(m)) return rc;
   if (!m->d_isv) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * m->n * total));
   if (int rc = pack_isv_range(m, which, 0, m->n, m->d_isv, m->own_stream)) return rc;
-  HIP_TRY(hipMemcpyAsync(isv_aos, m->d_isv, sizeof(double) * m->n * total, hipMemcpyDeviceToHost, m->own_stream));
-  HIP_TRY(hipStreamSynchronize(m->own_stream));
-  return 0;
+  return download_to_host(m, isv_aos, m->d_isv, sizeof(double) * m->n * total, m->own_stream);
 }
 
 int dxm_host_register(void* p, uint64_t bytes) {
