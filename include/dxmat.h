@@ -239,7 +239,10 @@ int dxm_isv_host(dxm_material* m, int which, double* isv_aos);
 /* ---- pinned host memory for the host-buffer form --------------------------------------------
  * integrate() returns arrays owned by the material (the reference returns views of its state
  * manager: generic.py:185-189); allocating them page-locked lets the D2H copies run at full PCIe
- * rate without the runtime's staging copy.  Returns NULL on failure. */
+ * rate without the runtime's staging copy.  Returns NULL on failure.
+ * Output arrays in ordinary (pageable) memory are accepted everywhere, but the library never lets the GPU write into
+ * them directly: they are filled through its own page-locked staging and a CPU copy, after the transfers of the call
+ * (slower; and not subject to the runtime's cache of on-the-fly page-locked ranges -- DESIGN.md section 1). */
 void* dxm_host_alloc(uint64_t bytes);
 int dxm_host_free(void* p);
 /* Page-lock an existing host range in place (e.g. the `x.array` of the dolfinx quadrature Functions that
