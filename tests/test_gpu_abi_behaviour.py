@@ -250,3 +250,33 @@ def test_plain_c_host_runs():
     r = subprocess.run([os.path.join(root, "examples", "c_host", "j2_batch"), "300001"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "plastic points = 300001" in r.stdout
+
+
+@pytest.mark.parametrize("law,n", [("j2", 100), ("j2", 50_001), ("j2", 2_300_000), ("fefp", 40_001)])
+def test_pageable_output_arrays_are_filled_through_the_staging_path(law, n):
+    """A C caller may hand ordinary (pageable) arrays to dxm_integrate / dxm_isv_host / dxm_get_state: the GPU never
+    writes into them directly (page-locked staging + CPU copy, dxmat.hip::download_to_host); same numbers as the
+    page-locked route of the Python layer, for the unpacked, the packed and the chunked (two staging rounds) cases."""
+    from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_F, SIGU_F, B_F, fefp_path, j2_history
+
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if law == "j2":
+        mk = lambda: JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN)), lazy_isv=False)   # noqa: E731
+        g, nf, ng, nisv = j2_history(n, seed=2)[2], 6, 6, 7
+    else:
+        mk = lambda: JAXMaterial(jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F)), lazy_isv=False)   # noqa: E731
+        g, nf, ng, nisv = fefp_path(n, nsteps=3, eps=3e-2)[2], 9, 9, 7
+    a, b = mk(), mk()
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    fa, ia, ca = a.integrate(g)
+    lib = _lib.load()
+    flux, isv, ct = np.full((n, nf), np.nan), np.full((n, nisv), np.nan), np.full((n, nf * ng), np.nan)   # plain numpy memory
+    st = _lib.Stats()
+    rc = lib.dxm_integrate(b._handle, np.ascontiguousarray(g).ctypes.data, 0.0, flux.ctypes.data, isv.ctypes.data, ct.ctypes.data, C.byref(st))
+    assert rc == 0 and st.as_dict() == a.last_stats
+    assert np.array_equal(flux, fa) and np.array_equal(ct.reshape(np.asarray(ca).shape), ca) and np.array_equal(isv, np.asarray(ia))
+    isv2 = np.full((n, nisv), np.nan)
+    assert lib.dxm_isv_host(b._handle, 1, isv2.ctypes.data) == 0 and np.array_equal(isv2, isv)
+    p = np.full((n, 1), np.nan)
+    assert lib.dxm_get_state(b._handle, 1, 0, p.ctypes.data) == 0 and np.array_equal(p[:, 0], isv[:, 0])
