@@ -124,9 +124,11 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
     kernel, is the whole cost when the consumer lives on the host."""
     h = history(n, seed)
 
-    def timed(bind):
+    def timed(bind, pageable_dma=False):
         m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
         m.set_data_manager(n)
+        if pageable_dma:
+            m.set_option("pageable_dma", 1)
         if bind:   # the arrays of the caller's quadrature Functions, page-locked in place (field_map.py; SURVEY 8(f) row 1)
             flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
             m.bind_outputs(flux=flux_fn, tangent=jac_fn)
@@ -141,14 +143,18 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
         m.close()
         return float(np.median(ts))
 
-    dt_own, dt = timed(False), timed(True)
+    dt_own, dt, dt_fast = timed(False), timed(True), timed(True, pageable_dma=True)
     out = {"value": round(n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_call": round(dt * 1e3, 3), "points": n,
            "into_the_materials_own_arrays": {"value": round(n / dt_own / 1e6, 2), "ms_per_call": round(dt_own * 1e3, 3)},
+           "with_option_pageable_dma": {"value": round(n / dt_fast / 1e6, 2), "ms_per_call": round(dt_fast * 1e3, 3),
+                                        "note": "the pageable strain array handed to the runtime's own transfer path instead of the library's page-locked "
+                                                "staging ring: faster, but exposed to the runtime's cache of on-the-fly page-locked ranges (DESIGN.md section 1)"},
            "pcie_bytes_per_point": {"h2d_strain": 48, "d2h_stress": 48, "d2h_tangent_coefficients": 72, "isv": "on demand (56)"},
            "GBs_over_pcie": round(n * 168 / dt / 1e9, 1),
            "note": "host buffers in and out through dxm_integrate: chunk-pipelined on two streams, the 9 coefficients of the tangent moved "
                    "and the (N,6,6) block rebuilt by 16 host threads with the kernel's own expression, bit-identical to the full download; "
-                   "`value`: results delivered into caller-owned arrays (bind_outputs: the x.array of the quadrature Functions)"}
+                   "`value`: results delivered into caller-owned arrays (bind_outputs: the x.array of the quadrature Functions), the pageable strain array "
+                   "staged through a page-locked ring by the worker threads (no DMA from or into pageable memory)"}
     return out
 
 

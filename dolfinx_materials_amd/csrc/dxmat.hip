@@ -176,12 +176,14 @@ static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, do
 
 // A few persistent worker threads per handle (created on the first host-path call that needs them).
 struct HostPool {
-  struct Job { const double* src; double* dst; int64_t n; int stride; };   // stride 9: J2 coefficients, 54: FeFp, 0: constant
+  // stride 9: J2 coefficients -> 6x6, 54: FeFp building blocks -> 9x9, 0: constant block, -1: plain copy of n BYTES
+  struct Job { const double* src; double* dst; int64_t n; int stride; int tag; };
   std::vector<std::thread> threads;
   std::mutex mu;
-  std::condition_variable cv, cv_done;
+  std::condition_variable cv, cv_done, cv_copy;
   std::deque<Job> queue;
   int pending = 0;
+  int pending_copy[64] = {};   // plain copies still running, per tag (the chunk they belong to)
   bool stop = false;
   explicit HostPool(int nthreads) {
     for (int t = 0; t < nthreads; ++t) threads.emplace_back([this] { run(); });
@@ -203,10 +205,12 @@ struct HostPool {
       }
       if (j.stride == 9) expand_coef_tangent(j.src, j.dst, j.n);
       else if (j.stride == 54) expand_fefp_tangent(j.src, j.dst, j.n);
+      else if (j.stride == -1) memcpy(j.dst, j.src, (size_t)j.n);
       else fill_const_tangent(j.src, j.dst, j.n);
       {
         std::lock_guard<std::mutex> lk(mu);
-        if (--pending == 0) cv_done.notify_all();
+        if (j.stride == -1) { if (--pending_copy[j.tag] == 0) cv_copy.notify_all(); }
+        else if (--pending == 0) cv_done.notify_all();
       }
     }
   }
@@ -216,7 +220,7 @@ struct HostPool {
     const int64_t per = (n + pieces - 1) / pieces;
     std::lock_guard<std::mutex> lk(mu);
     for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * stride, dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride});
+      queue.push_back(Job{src + o * stride, dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0});
       ++pending;
     }
     cv.notify_all();
@@ -224,6 +228,29 @@ struct HostPool {
   void wait() {
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [this] { return pending == 0; });
+  }
+  // `bytes` from src to dst, cut over the threads and queued AHEAD of any rebuild work; wait_copy(tag) returns when
+  // every piece submitted under that tag (0..63) has been copied
+  void copy_async(const void* src, void* dst, size_t bytes, int tag) {
+    if (bytes <= (256u << 10)) {   // waking the threads costs more than copying this much
+      memcpy(dst, src, bytes);
+      return;
+    }
+    const size_t pieces = std::min<size_t>(threads.size(), 8);
+    const size_t per = ((bytes + pieces - 1) / pieces + 63) / 64 * 64;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t o = 0; o < bytes; o += per) {
+        queue.push_front(Job{reinterpret_cast<const double*>(static_cast<const char*>(src) + o),
+                             reinterpret_cast<double*>(static_cast<char*>(dst) + o), (int64_t)std::min(per, bytes - o), -1, tag});
+        ++pending_copy[tag];
+      }
+    }
+    cv.notify_all();
+  }
+  void wait_copy(int tag) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_copy.wait(lk, [this, tag] { return pending_copy[tag] == 0; });
   }
 };
 
@@ -270,6 +297,7 @@ struct dxm_material {
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
   bool opt_tune_verbose = false;
   int opt_host_threads = 16;
+  int opt_pageable_dma = 0;   // 1: hand pageable host arrays to the runtime (faster uploads; see upload_from_host)
   int64_t opt_packed_min_points = 32768;   // below: waking the workers costs what the bytes save (r02_hostpath_v2.jsonl)
   size_t opt_tune_max_skip = (size_t)2 << 30;   // dxm_tune_placement: bytes of skip blocks it may hold
   int opt_max_chunks = DXM_MAX_CHUNKS;
@@ -286,8 +314,10 @@ struct dxm_material {
   double* d_isv = nullptr;
   double* d_ct = nullptr;
   double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
-  double* h_bounce = nullptr; // page-locked staging of download_to_host (2 x BOUNCE_BYTES)
-  hipEvent_t bounce_done[2] = {nullptr, nullptr};
+  // host-buffer form, strain in ordinary memory: page-locked ring the kernels read the chunks from (zero-copy)
+  double* h_grad_ring = nullptr;
+  int64_t ring_slot_doubles = 0;
+  hipEvent_t ring_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static int sync_last(dxm_material* m);
@@ -365,6 +395,13 @@ __global__ void fill_slot_kernel(double* dst, int64_t count, double value) {
 struct PackMap { int n; int slot[16]; };
 
 // SoA state -> AoS (n, total) internal-state-variable array (jaxmat.py:46-58 `_hcat_mixed`).
+// Strain chunks from the page-locked ring to HBM: a copy kernel on a few workgroups (the PCIe link, not the CUs, bounds
+// it), so that the rest of the chip stays free for the update kernel and the downloads of the other stream.
+__global__ void __launch_bounds__(256) ring_upload_kernel(const double2_t* __restrict__ src, double2_t* __restrict__ dst, int64_t n16) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (int64_t)gridDim.x * blockDim.x)
+    dst[k] = __builtin_nontemporal_load(src + k);
+}
+
 __global__ void pack_isv_kernel(const double* __restrict__ soa, int64_t ld, int64_t n,
                                 double* __restrict__ aos, PackMap map) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,8 +583,8 @@ int dxm_destroy(dxm_material* m) {
   if (m->d_isv) (void)hipFree(m->d_isv);
   if (m->d_ct) (void)hipFree(m->d_ct);
   if (m->d_field) (void)hipFree(m->d_field);
-  if (m->h_bounce) (void)hipHostFree(m->h_bounce);
-  for (hipEvent_t e : m->bounce_done) if (e) (void)hipEventDestroy(e);
+  if (m->h_grad_ring) (void)hipHostFree(m->h_grad_ring);
+  for (hipEvent_t e : m->ring_done) if (e) (void)hipEventDestroy(e);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->pipe_stream) (void)hipStreamDestroy(m->pipe_stream);
   delete m;
@@ -623,6 +660,89 @@ static int materialize_s1(dxm_material* m) {
 }
 
 
+// No DMA to or from pageable memory.  The runtime page-locks such a range on the fly and keeps the mapping in a cache
+// keyed by address; when the owner has freed that memory since and a later allocation lands on the same address, the
+// cached mapping is stale and the copy dies with "Memory access fault by GPU ... on address <host address>" -- as a
+// write into a read-only page (download into a range once pinned as an upload source) or as a read through a dead
+// mapping (upload).  Seen about once in 25 runs of the GPU test suite, whose tests allocate and free large numpy
+// arrays all the time, as QuadratureMap.update does with its gradient arrays.  So: page-locked or registered memory
+// is used directly; anything else goes through this page-locked staging (two halves in flight) and a CPU copy.
+constexpr size_t BOUNCE_BYTES = 16u << 20;
+static bool page_locked(const void* host) {
+  hipPointerAttribute_t attr{};
+  const bool locked = host && hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();   // "not a registered pointer" is the expected answer for ordinary memory
+  return locked;
+}
+struct Staging {
+  char* buf = nullptr;
+  hipEvent_t done[2] = {nullptr, nullptr};
+};
+static std::mutex g_staging_mu;
+static Staging g_staging[64];
+static int staging_for_current_device(Staging** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(-1, "device index %d out of range", dev);
+  Staging& s = g_staging[dev];
+  if (!s.buf) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.buf), 2 * BOUNCE_BYTES, hipHostMallocDefault));
+    for (hipEvent_t& e : s.done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  *out = &s;
+  return 0;
+}
+static size_t chunk_size(size_t c, size_t nchunks, size_t bytes) { return c + 1 < nchunks ? BOUNCE_BYTES : bytes - c * BOUNCE_BYTES; }
+
+// device -> caller-owned host memory; complete on return
+static int download_to_host(void* host, const void* dev, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if (page_locked(host)) {
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(g_staging_mu);
+  Staging* s = nullptr;
+  if (int rc = staging_for_current_device(&s)) return rc;
+  const size_t nchunks = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
+  for (size_t c = 0; c <= nchunks; ++c) {
+    if (c < nchunks) {
+      HIP_TRY(hipMemcpyAsync(s->buf + (c & 1) * BOUNCE_BYTES, static_cast<const char*>(dev) + c * BOUNCE_BYTES,
+                             chunk_size(c, nchunks, bytes), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(s->done[c & 1], st));
+    }
+    if (c > 0) {   // the previous chunk lands while this one is in flight
+      HIP_TRY(hipEventSynchronize(s->done[(c - 1) & 1]));
+      memcpy(static_cast<char*>(host) + (c - 1) * BOUNCE_BYTES, s->buf + ((c - 1) & 1) * BOUNCE_BYTES, chunk_size(c - 1, nchunks, bytes));
+    }
+  }
+  return 0;
+}
+
+// caller-owned host memory -> device; the host range may be reused on return (the device copy is complete too)
+static int upload_from_host(void* dev, const void* host, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if (page_locked(host)) {
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(g_staging_mu);
+  Staging* s = nullptr;
+  if (int rc = staging_for_current_device(&s)) return rc;
+  const size_t nchunks = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
+  for (size_t c = 0; c < nchunks; ++c) {
+    if (c >= 2) HIP_TRY(hipEventSynchronize(s->done[c & 1]));   // this half has left for the device
+    memcpy(s->buf + (c & 1) * BOUNCE_BYTES, static_cast<const char*>(host) + c * BOUNCE_BYTES, chunk_size(c, nchunks, bytes));
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(dev) + c * BOUNCE_BYTES, s->buf + (c & 1) * BOUNCE_BYTES, chunk_size(c, nchunks, bytes),
+                           hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(s->done[c & 1], st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
 int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos) {
   if (int rc = check_field(m, which, field)) return rc;
   if (!host_aos) return fail(-1, "null host pointer");
@@ -643,53 +763,12 @@ int dxm_set_state(dxm_material* m, int which, int field, const double* host_aos)
   map.n = dim;
   for (int c = 0; c < dim; ++c) map.slot[c] = d.isv_slot[field] + c;
   hipStream_t st = m->own_stream;
-  HIP_TRY(hipMemcpyAsync(m->d_field, host_aos, sizeof(double) * n * dim, hipMemcpyHostToDevice, st));
+  if (int rc = upload_from_host(m->d_field, host_aos, sizeof(double) * n * dim, st)) return rc;
   const int blocks = (int)((n * dim + 255) / 256);
   hipLaunchKernelGGL(unpack_isv_kernel, dim3(blocks), dim3(256), 0, st, state_of(m, which), m->ld, n,
                      m->d_field, map);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
-  return 0;
-}
-
-// Device -> host into memory the caller owns.  Never a DMA into pageable memory: the runtime page-locks such a range
-// on the fly and keeps the mapping in a cache keyed by address; a range it has once mapped READ-ONLY (the source of an
-// earlier pageable upload -- e.g. a strain array numpy has freed since) comes back from that cache when a later
-// allocation at the same address is the DESTINATION, and the copy dies with "Memory access fault ... Write access to a
-// read-only page" (seen once in ~25 runs of the GPU test suite, at get_final_state_dict into a fresh np.empty).
-// Page-locked or registered destinations are written directly; anything else goes through the handle's own page-locked
-// staging, two halves in flight, copied out by the CPU.
-constexpr size_t BOUNCE_BYTES = 16u << 20;
-static bool page_locked(const void* host) {
-  hipPointerAttribute_t attr{};
-  const bool locked = host && hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost;
-  (void)hipGetLastError();   // "not a registered pointer" is the expected answer for ordinary memory
-  return locked;
-}
-static int download_to_host(dxm_material* m, void* host, const void* dev, size_t bytes, hipStream_t st) {
-  if (page_locked(host)) {
-    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return 0;
-  }
-  if (!m->h_bounce) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_bounce), 2 * BOUNCE_BYTES, hipHostMallocDefault));
-    for (hipEvent_t& e : m->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  char* stage = reinterpret_cast<char*>(m->h_bounce);
-  const size_t nchunks = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
-  auto size_of = [&](size_t c) { return c + 1 < nchunks ? BOUNCE_BYTES : bytes - c * BOUNCE_BYTES; };
-  for (size_t c = 0; c <= nchunks; ++c) {
-    if (c < nchunks) {
-      HIP_TRY(hipMemcpyAsync(stage + (c & 1) * BOUNCE_BYTES, static_cast<const char*>(dev) + c * BOUNCE_BYTES, size_of(c),
-                             hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipEventRecord(m->bounce_done[c & 1], st));
-    }
-    if (c > 0) {   // the previous chunk lands while this one is in flight
-      HIP_TRY(hipEventSynchronize(m->bounce_done[(c - 1) & 1]));
-      memcpy(static_cast<char*>(host) + (c - 1) * BOUNCE_BYTES, stage + ((c - 1) & 1) * BOUNCE_BYTES, size_of(c - 1));
-    }
-  }
   return 0;
 }
 
@@ -711,7 +790,7 @@ int dxm_get_state(dxm_material* m, int which, int field, double* host_aos) {
   hipLaunchKernelGGL(pack_isv_kernel, dim3(blocks), dim3(256), 0, st, state_of(m, which), m->ld, n,
                      m->d_field, map);
   HIP_TRY(hipGetLastError());
-  return download_to_host(m, host_aos, m->d_field, sizeof(double) * n * dim, st);
+  return download_to_host(host_aos, m->d_field, sizeof(double) * n * dim, st);
 }
 
 int dxm_advance(dxm_material* m) {
@@ -1028,9 +1107,14 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 // entries, 72 instead of 288 B/point are moved into a page-locked landing area and worker threads rebuild
 // the block in the caller's array chunk by chunk, behind the transfer of the following chunks
 // (bit-identical to the full kernel; the elastic block is a constant and is only filled in).
+// host_grad: the caller's gradient array when it is in ordinary (pageable) memory, else nullptr.  It is never handed
+// to the runtime: worker threads copy chunk c into slot c % 8 of a page-locked ring and a small copy kernel moves it to
+// HBM over PCIe (what the runtime's own pageable path does with its staging buffers; no DMA engine is shared with the
+// downloads).
 template <class Upload>
 static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
-                            double* ct_aos, dxm_stats* stats, const MeshSource* fused = nullptr) {
+                            double* ct_aos, dxm_stats* stats, const MeshSource* fused = nullptr,
+                            const double* host_grad = nullptr) {
   const auto t_enter = std::chrono::steady_clock::now();
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
@@ -1043,8 +1127,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const int nfull = d.n_flux * d.n_grad;
   const int nt = tl == TL_COEF ? np : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : nfull);   // doubles per point in d_ct
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
-  if (packed) {
-    if (!constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * np, hipHostMallocDefault));
+  if (packed || host_grad) {
+    if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * np, hipHostMallocDefault));
     if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
       delete m->pool;
       m->pool = new HostPool(m->opt_host_threads);
@@ -1055,31 +1139,71 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   // the last chunk's host expansion is not hidden behind any transfer: many small chunks keep that tail short
   int nchunks = (int)(n / (packed ? (n >= 2097152 ? 65536 : 32768) : 131072));
   if (nchunks < 1) nchunks = 1;
-  if (!packed && nchunks > 8) nchunks = 8;
+  if (!packed && nchunks > (host_grad ? 32 : 8)) nchunks = host_grad ? 32 : 8;   // staged uploads start later: shorter chunks
   if (nchunks > m->opt_max_chunks) nchunks = m->opt_max_chunks;
   if (!m->opt_pipeline) nchunks = 1;
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));
   const int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
-  const bool flux_locked = page_locked(flux_aos), isv_locked = page_locked(isv_aos), ct_locked = page_locked(ct_aos);
+  if (host_grad) {
+    const int64_t need = csize * d.n_grad;
+    if (m->ring_slot_doubles < need) {
+      if (m->h_grad_ring) HIP_TRY(hipHostFree(m->h_grad_ring));
+      m->h_grad_ring = nullptr;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_grad_ring), sizeof(double) * need * 8, hipHostMallocDefault));
+      m->ring_slot_doubles = need;
+    }
+    for (hipEvent_t& e : m->ring_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const bool any = m->opt_pageable_dma;
+  const bool flux_locked = any || page_locked(flux_aos), isv_locked = any || page_locked(isv_aos), ct_locked = any || page_locked(ct_aos);
   int stats_off = 0, issued = 0, submitted = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
   // no worker may still be writing into the caller's array when this function returns, error paths included
   struct PoolDrain {
     HostPool* p;
-    ~PoolDrain() { if (p) p->wait(); }
-  } drain{packed ? m->pool : nullptr};
+    ~PoolDrain() {
+      if (!p) return;
+      for (int t = 0; t < 64; ++t) p->wait_copy(t);   // staging copies still read the caller's gradient array
+      p->wait();
+    }
+  } drain{(packed || host_grad) ? m->pool : nullptr};
   if (constant) m->pool->submit(m->elastic_lm, ct_aos, n, 0);   // nothing to wait for
+  // chunk p of the caller's pageable gradient array -> its ring slot, by the worker threads, asynchronously
+  auto stage_chunk = [&](int p) -> int {
+    const int64_t o = (int64_t)p * csize;
+    if (!host_grad || p >= nchunks || o >= n) return 0;
+    if (p >= 8) HIP_TRY(hipEventSynchronize(m->ring_done[p % 8]));   // the copy kernel of chunk p - 8 has read this slot
+    m->pool->copy_async(host_grad + o * d.n_grad, m->h_grad_ring + (int64_t)(p % 8) * m->ring_slot_doubles,
+                        sizeof(double) * ((n - o) < csize ? (n - o) : csize) * d.n_grad, p);
+    return 0;
+  };
+  for (int p = 0; p < 3; ++p) if (int rc = stage_chunk(p)) return rc;
   for (int c = 0; c < nchunks; ++c) {
     const int64_t off = (int64_t)c * csize;
     if (off >= n) break;
     const int64_t cnt = (n - off) < csize ? (n - off) : csize;
     hipStream_t st = streams[c & 1];
     if (int rc = upload(off, cnt, st)) return rc;
+    const double* gptr = fused ? m->d_flux : m->d_grad + off * d.n_grad;
+    if (host_grad) {
+      const int slot = c % 8;
+      double* dst = m->h_grad_ring + (int64_t)slot * m->ring_slot_doubles;
+      if (int rc = stage_chunk(c + 3)) return rc;   // keep three chunks ahead of the launches
+      m->pool->wait_copy(c);
+      // page-locked host memory is addressable from the device under the same pointer
+      const int64_t n16 = cnt * d.n_grad / 2;      // cnt is a multiple of 256 except in the last chunk; n_grad 6 or 9:
+      const int64_t tail = cnt * d.n_grad - 2 * n16;   // an odd count leaves one double for a plain copy
+      hipLaunchKernelGGL(ring_upload_kernel, dim3(32), dim3(256), 0, st, reinterpret_cast<const double2_t*>(dst),
+                         reinterpret_cast<double2_t*>(m->d_grad + off * d.n_grad), n16);
+      if (tail) HIP_TRY(hipMemcpyAsync(m->d_grad + off * d.n_grad + 2 * n16, dst + 2 * n16, sizeof(double), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(m->ring_done[slot], st));   // the slot is free once the copy kernel has read it
+    }
     int grid = 0;
     MeshSource src{};
     if (fused) { src = *fused; src.point0 = off; }
-    if (int rc = launch_range(m, off, cnt, fused ? m->d_flux : m->d_grad + off * d.n_grad, m->d_flux + off * d.n_flux,
+    if (int rc = launch_range(m, off, cnt, gptr, m->d_flux + off * d.n_flux,
                               m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr, tl))
       return rc;
     stats_off += grid;
@@ -1132,11 +1256,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   // destinations in ordinary (pageable) memory were left out above: they are filled through the page-locked staging now
   // (download_to_host; slower, and only a C caller that did not use dxm_host_alloc / dxm_host_register gets here)
   if (flux_aos && !flux_locked)
-    if (int rc = download_to_host(m, flux_aos, m->d_flux, sizeof(double) * n * d.n_flux, m->own_stream)) return rc;
+    if (int rc = download_to_host(flux_aos, m->d_flux, sizeof(double) * n * d.n_flux, m->own_stream)) return rc;
   if (isv_aos && total > 0 && !isv_locked)
-    if (int rc = download_to_host(m, isv_aos, m->d_isv, sizeof(double) * n * total, m->own_stream)) return rc;
+    if (int rc = download_to_host(isv_aos, m->d_isv, sizeof(double) * n * total, m->own_stream)) return rc;
   if (ct_aos && !constant && !packed && !ct_locked)
-    if (int rc = download_to_host(m, ct_aos, m->d_ct, sizeof(double) * n * nt, m->own_stream)) return rc;
+    if (int rc = download_to_host(ct_aos, m->d_ct, sizeof(double) * n * nt, m->own_stream)) return rc;
   HIP_TRY(hipEventRecord(m->last_event, m->own_stream));   // everything of this call is complete already
   m->last_event_recorded = true;
   const auto t_landed = std::chrono::steady_clock::now();
@@ -1159,15 +1283,18 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   }
   if (!grad_aos) return fail(-1, "null gradient pointer");
   DEVICE_GUARD(m);
+  // a page-locked gradient array is uploaded by DMA; so is a pageable one if the caller asked for it (option pageable_dma)
+  const bool locked_in = m->opt_pageable_dma || page_locked(grad_aos);
   if (int rc = ensure_host_path_buffers(m)) return rc;
   if (int rc = sync_last(m)) return rc;
   const int ng = d.n_grad;
   auto upload = [&](int64_t off, int64_t cnt, hipStream_t st) -> int {
-    HIP_TRY(hipMemcpyAsync(m->d_grad + off * ng, grad_aos + off * ng, sizeof(double) * cnt * ng,
-                           hipMemcpyHostToDevice, st));
+    if (locked_in)
+      HIP_TRY(hipMemcpyAsync(m->d_grad + off * ng, grad_aos + off * ng, sizeof(double) * cnt * ng,
+                             hipMemcpyHostToDevice, st));
     return 0;
   };
-  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats);
+  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats, nullptr, locked_in ? nullptr : grad_aos);
 }
 
 void* dxm_host_alloc(uint64_t bytes) {
@@ -1238,8 +1365,8 @@ static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, con
   ok = ok && hipMalloc(&mesh->d_coords, sizeof(double) * 3 * n_nodes) == hipSuccess;
   ok = ok && hipMalloc(&mesh->d_conn, sizeof(int32_t) * npc * n_cells) == hipSuccess;
   ok = ok && hipMalloc(&mesh->d_u, sizeof(double) * 3 * n_nodes) == hipSuccess;
-  ok = ok && hipMemcpy(mesh->d_coords, coords, sizeof(double) * 3 * n_nodes, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(mesh->d_conn, conn, sizeof(int32_t) * npc * n_cells, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && upload_from_host(mesh->d_coords, coords, sizeof(double) * 3 * n_nodes, nullptr) == 0;
+  ok = ok && upload_from_host(mesh->d_conn, conn, sizeof(int32_t) * npc * n_cells, nullptr) == 0;
   if (!ok) {
     fail(-3, "device allocation / upload of the mesh failed");
     dxm_mesh_destroy(mesh);
@@ -1305,10 +1432,10 @@ dxm_mesh* dxm_mesh_create_simplex(int tdim, const double* coords, int64_t n_vert
   ok = ok && hipMalloc(&mesh->d_dofmap, sizeof(int32_t) * nd * n_cells) == hipSuccess;
   ok = ok && hipMalloc(&mesh->d_dphi, sizeof(double) * nqp * nd * tdim) == hipSuccess;
   ok = ok && hipMalloc(&mesh->d_u, sizeof(double) * mesh->u_len) == hipSuccess;
-  ok = ok && hipMemcpy(mesh->d_coords, coords, sizeof(double) * 3 * n_vertices, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(mesh->d_conn, geom_conn, sizeof(int32_t) * nv * n_cells, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(mesh->d_dofmap, dofmap, sizeof(int32_t) * nd * n_cells, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(mesh->d_dphi, dphi, sizeof(double) * nqp * nd * tdim, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && upload_from_host(mesh->d_coords, coords, sizeof(double) * 3 * n_vertices, nullptr) == 0;
+  ok = ok && upload_from_host(mesh->d_conn, geom_conn, sizeof(int32_t) * nv * n_cells, nullptr) == 0;
+  ok = ok && upload_from_host(mesh->d_dofmap, dofmap, sizeof(int32_t) * nd * n_cells, nullptr) == 0;
+  ok = ok && upload_from_host(mesh->d_dphi, dphi, sizeof(double) * nqp * nd * tdim, nullptr) == 0;
   if (!ok) {
     fail(-3, "device allocation / upload of the mesh failed");
     dxm_mesh_destroy(mesh);
@@ -1413,8 +1540,8 @@ static int ensure_operator_buffers(dxm_mesh* mesh) {
   bool ok = hipMalloc(&d_ptr, sizeof(int64_t) * (mesh->n_nodes + 1)) == hipSuccess;
   ok = ok && hipMalloc(&d_adj, sizeof(int32_t) * ne) == hipSuccess;
   ok = ok && hipMalloc(&d_fe, sizeof(double) * ne * 3) == hipSuccess;
-  ok = ok && hipMemcpy(d_ptr, ptr.data(), sizeof(int64_t) * (mesh->n_nodes + 1), hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && upload_from_host(d_ptr, ptr.data(), sizeof(int64_t) * (mesh->n_nodes + 1), nullptr) == 0;
+  ok = ok && upload_from_host(d_adj, adj.data(), sizeof(int32_t) * ne, nullptr) == 0;
   if (!ok) {
     (void)hipGetLastError();
     if (d_ptr) (void)hipFree(d_ptr);
@@ -1496,7 +1623,7 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
   if (int rc = ensure_host_path_buffers(m, !fuse)) return rc;
   hipStream_t st = m->own_stream;
   if (int rc = sync_last(m)) return rc;
-  HIP_TRY(hipMemcpyAsync(mesh->d_u, u_host, sizeof(double) * mesh->u_len, hipMemcpyHostToDevice, st));
+  if (int rc = upload_from_host(mesh->d_u, u_host, sizeof(double) * mesh->u_len, st)) return rc;
   MeshSource src{};
   if (fuse) {
     src = mesh_source(mesh, mesh->d_u);
@@ -1653,6 +1780,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   else if (k == "packed_transfer") m->opt_packed_transfer = on;
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
   else if (k == "tune_verbose") m->opt_tune_verbose = on;
+  else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;
   else if (k == "packed_min_points") {
     if (!(value >= 0 && value <= 1e12)) return fail(-1, "packed_min_points must be >= 0");
     m->opt_packed_min_points = (int64_t)value;
@@ -1687,7 +1815,7 @@ int dxm_isv_host(dxm_material* m, int which, double* isv_aos) {
   if (int rc = sync_last(m)) return rc;
   if (!m->d_isv) HIP_TRY(hipMalloc(&m->d_isv, sizeof(double) * m->n * total));
   if (int rc = pack_isv_range(m, which, 0, m->n, m->d_isv, m->own_stream)) return rc;
-  return download_to_host(m, isv_aos, m->d_isv, sizeof(double) * m->n * total, m->own_stream);
+  return download_to_host(isv_aos, m->d_isv, sizeof(double) * m->n * total, m->own_stream);
 }
 
 int dxm_host_register(void* p, uint64_t bytes) {

@@ -222,7 +222,13 @@ int dxm_notify_replay(dxm_material* m);
  *                            bit-identical (default 1)
  *   "packed_min_points" >= 0 batch size from which packed_transfer applies (default 32768: below, waking the
  *                            worker threads costs what the bytes save)
- *   "host_threads"   1..256  worker threads of that rebuild (default 16)
+ *   "pageable_dma"   0 | 1   host-buffer form: 1 hands gradient / result arrays in ordinary (pageable) memory to the
+ *                            runtime's own transfer path instead of staging them through page-locked memory.  Faster
+ *                            (the strain upload then costs the host nothing), but exposed to the runtime's cache of
+ *                            on-the-fly page-locked ranges: with host arrays that are freed and reallocated between
+ *                            calls, about one process in 25 of the test suite died with "Memory access fault by GPU"
+ *                            (DESIGN.md section 1).  Default 0
+ *   "host_threads"   1..256  worker threads of that rebuild and of the staging copies (default 16)
  *   "fused_gradient" 1 | 0   displacement forms: evaluate the gradient inside the update kernel where the mesh
  *                            allows (default 1)
  *   "blocks_per_cu"  1..256  grid size of the update kernel in workgroups per CU (default 32 small strain,

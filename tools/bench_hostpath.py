@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 MIN_POINTS = None
+PAGEABLE_DMA = False
 
 
 LAW = "j2_linear"
@@ -51,6 +52,8 @@ def run(n, mode, reps, threads=None):
         m.set_option("host_threads", threads)
     if MIN_POINTS is not None:
         m.set_option("packed_min_points", MIN_POINTS)
+    if PAGEABLE_DMA:
+        m.set_option("pageable_dma", 1)
     nf = 9 if LAW == "fefp" else 6
     if mode in ("bound", "pinned_in"):
         flux_fn, jac_fn = np.zeros(n * nf), np.zeros(n * nf * nf)
@@ -88,9 +91,10 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--packed-min-points", type=int, default=None, help="option packed_min_points (library default 262144)")
     ap.add_argument("--law", default="j2_linear", choices=["j2_linear", "fefp"])
+    ap.add_argument("--pageable-dma", action="store_true", help="option pageable_dma = 1: the runtime's pageable transfer path (faster, fragile)")
     a = ap.parse_args()
-    global MIN_POINTS, LAW
-    MIN_POINTS, LAW = a.packed_min_points, a.law
+    global MIN_POINTS, LAW, PAGEABLE_DMA
+    MIN_POINTS, LAW, PAGEABLE_DMA = a.packed_min_points, a.law, a.pageable_dma
     for n in a.points:
         for mode in a.modes:
             for t in a.threads:
