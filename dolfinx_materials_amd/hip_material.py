@@ -530,8 +530,8 @@ class HIPMaterial:
 
     def set_option(self, name, value):
         """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"packed_transfer"``, ``"packed_min_points"``,
-        ``"host_threads"``, ``"max_chunks"``, ``"fused_gradient"``, ``"blocks_per_cu"``, ``"tune_max_skip_bytes"``,
-        ``"tune_verbose"``)."""
+        ``"pageable_dma"``, ``"host_threads"``, ``"max_chunks"``, ``"fused_gradient"``, ``"blocks_per_cu"``,
+        ``"tune_max_skip_bytes"``, ``"tune_verbose"``)."""
         self._chk(self._lib.dxm_set_option(self._require(), name.encode(), float(value)))
 
     def bind_outputs(self, flux=None, tangent=None):
