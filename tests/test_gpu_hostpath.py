@@ -258,3 +258,19 @@ def test_elastic_host_path_fills_the_constant_block_without_moving_it():
     fb, ib, cb = b.integrate(eps)
     assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.asarray(ia).shape == (n, 0)
     assert np.array_equal(ca[12345], onp.elastic_matrix(E, NU))
+
+
+@pytest.mark.parametrize("n", [1000, 300_001])
+def test_staged_and_runtime_uploads_give_the_same_bits(n):
+    """Default: the pageable strain array goes through the library's page-locked ring (worker-thread copies + copy
+    kernel); option pageable_dma = 1: the runtime transfers it itself.  Same results, bit for bit."""
+    a, b = _j2("voce"), _j2("voce")
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    b.set_option("pageable_dma", 1)
+    for eps in j2_history(n, seed=9, sig0=SIG0_V)[:3]:
+        fa, ia, ca = a.integrate(eps)
+        fb, ib, cb = b.integrate(eps)
+        assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(np.asarray(ia), np.asarray(ib))
+        a.data_manager.update()
+        b.data_manager.update()
