@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MIN_POINTS = None
 PAGEABLE_DMA = False
+FRESH_INPUT = False
 
 
 LAW = "j2_linear"
@@ -69,14 +70,16 @@ def run(n, mode, reps, threads=None):
     m.integrate(h[2])
     ts = []
     for _ in range(reps):
+        g = np.array(h[2]) if FRESH_INPUT else h[2]   # QuadratureMap.update builds a new gradient array per call
         t0 = time.perf_counter()
-        m.integrate(h[2])
+        m.integrate(g)
         ts.append(time.perf_counter() - t0)
+        del g
     dt = float(np.median(ts))
     bpp = 48 + 48 + (56 + 288 if mode == "r01" else 72)
     if LAW == "fefp":
         bpp = 72 + 72 + (56 + 648 if mode == "r01" else 432)
-    out = {"law": LAW, "mode": mode, "points": n, "host_threads": threads or 8, "host_path_ms": round(dt * 1e3, 3),
+    out = {"law": LAW, "fresh_input": FRESH_INPUT, "pageable_dma": PAGEABLE_DMA, "mode": mode, "points": n, "host_threads": threads or 8, "host_path_ms": round(dt * 1e3, 3),
            "min_ms": round(min(ts) * 1e3, 3), "Mpoints_per_s": round(n / dt / 1e6, 2), "pcie_bytes_per_point": bpp,
            "GBs_over_pcie": round(n * bpp / dt / 1e9, 2)}
     m.close()
@@ -91,10 +94,11 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--packed-min-points", type=int, default=None, help="option packed_min_points (library default 262144)")
     ap.add_argument("--law", default="j2_linear", choices=["j2_linear", "fefp"])
+    ap.add_argument("--fresh-input", action="store_true", help="a newly allocated gradient array per call, as QuadratureMap.update hands over")
     ap.add_argument("--pageable-dma", action="store_true", help="option pageable_dma = 1: the runtime's pageable transfer path (faster, fragile)")
     a = ap.parse_args()
-    global MIN_POINTS, LAW, PAGEABLE_DMA
-    MIN_POINTS, LAW, PAGEABLE_DMA = a.packed_min_points, a.law, a.pageable_dma
+    global MIN_POINTS, LAW, PAGEABLE_DMA, FRESH_INPUT
+    MIN_POINTS, LAW, PAGEABLE_DMA, FRESH_INPUT = a.packed_min_points, a.law, a.pageable_dma, a.fresh_input
     for n in a.points:
         for mode in a.modes:
             for t in a.threads:
