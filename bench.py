@@ -261,7 +261,7 @@ def pmc_child(args):
     n = args.points
     dev = torch.device("cuda", 0)
     hist = history(n, 1234)
-    eps = [torch.from_numpy(h).to(dev) for h in hist[:3]]
+    eps = [to_dev(h, dev) for h in hist[:3]]
     flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
     ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
     hard = jm.LinearHardening(SIG0, H) if args.law == "j2_linear" else jm.VoceHardening(350.0, 500.0, 1e3)
@@ -321,6 +321,28 @@ def live_traffic(args, kernel_prefix="small_strain_kernel<1"):
     write_b = means["WRITE_SIZE"][0] * 1024.0
     return read_b + write_b, {"source": "two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE; KiB) around `bench.py --pmc-child` in this run",
                               "hbm_read_bytes": read_b, "hbm_write_bytes": write_b, "launches_sampled": means["FETCH_SIZE"][1]}
+
+
+def to_dev(a, dev):
+    """numpy -> device through a page-locked staging tensor: pageable memory is never handed to the GPU runtime (its
+    cache of on-the-fly page-locked ranges goes stale when host addresses are recycled)."""
+    import torch
+
+    pin = torch.empty(a.shape, dtype=torch.float64, pin_memory=True)
+    pin.numpy()[...] = a
+    out = pin.to(dev)
+    torch.cuda.synchronize()
+    return out
+
+
+def to_cpu(t):
+    """device tensor -> CPU tensor through a page-locked staging tensor (gloo debug mode only)."""
+    import torch
+
+    pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pin.copy_(t)
+    torch.cuda.synchronize()
+    return pin.clone()
 
 
 def free_port():
@@ -452,7 +474,7 @@ def main():
     if args.law == "j2_voce":
         SIG0 = 350.0  # demos/jax/elastoplasticity/plane_elastoplasticity.py:60-71
     hist = history(n, seed)
-    eps = [torch.from_numpy(h).to(dev) for h in hist]
+    eps = [to_dev(h, dev) for h in hist]
     del hist
     flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
     ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
@@ -595,8 +617,8 @@ def main():
                     fn(my_ct, plan, out=g_ct)
                 else:
                     step(i)
-                    fn(flux.to(cdev), plan, out=g_flux)
-                    fn(ct.to(cdev), plan, out=g_ct)
+                    fn(to_cpu(flux), plan, out=g_flux)
+                    fn(to_cpu(ct), plan, out=g_ct)
 
             gstep(0)
             barrier()
@@ -653,8 +675,8 @@ def main():
                         allgather_tangent(my_c9, plan, out=g_ct, coef_all=coef_all)
                     else:
                         cmats[j].integrate_device(eps[j + 1].data_ptr(), flux.data_ptr(), ct9.data_ptr(), stream)
-                        allgather_rows(flux.to(cdev), plan, out=g_flux)
-                        allgather_tangent(ct9.to(cdev), plan, out=g_ct, coef_all=coef_all)
+                        allgather_rows(to_cpu(flux), plan, out=g_flux)
+                        allgather_tangent(to_cpu(ct9), plan, out=g_ct, coef_all=coef_all)
 
                 cstep(0)
                 barrier()

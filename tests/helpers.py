@@ -99,3 +99,30 @@ def triangle_grid(n, distort=0.2, seed=0):
             a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
             cells += [(a, b, c), (a, c, d)]
     return coords, np.array(cells, dtype=np.int32)
+
+
+# ---- host <-> device copies of the TESTS themselves ---------------------------------------------------------------
+# torch's `tensor.cpu()` / `torch.from_numpy(a).to(device)` hand pageable memory to the GPU runtime, whose cache of
+# on-the-fly page-locked ranges goes stale when numpy / torch recycle host addresses: about one suite run in 25 died
+# with "Memory access fault by GPU ... Write access to a read-only page" inside such a call.
+# The tests therefore stage through page-locked tensors, like the library does.
+def to_device(a, dev="cuda:0"):
+    """numpy array -> fp64 / int tensor on the device through a page-locked staging tensor."""
+    import torch
+
+    a = np.ascontiguousarray(a)
+    pin = torch.empty(a.shape, dtype=torch.from_numpy(a[:0] if a.ndim else a.reshape(1)[:0]).dtype, pin_memory=True)
+    pin.numpy()[...] = a
+    out = pin.to(dev)
+    torch.cuda.synchronize()
+    return out
+
+
+def to_host(t):
+    """device tensor -> numpy array through a page-locked staging tensor."""
+    import torch
+
+    pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pin.copy_(t)
+    torch.cuda.synchronize()
+    return pin.numpy().copy()

@@ -10,6 +10,8 @@ from dolfinx_materials_amd import _lib
 from dolfinx_materials_amd.jaxmat import JAXMaterial
 
 pytestmark = pytest.mark.gpu
+from helpers import to_device, to_host  # noqa: E402,F401
+
 
 
 def _mat(n=16):
@@ -104,13 +106,13 @@ def test_device_path_on_a_non_default_torch_stream():
     f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
     c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
     with torch.cuda.stream(side):
-        g = torch.from_numpy(eps_h).to(dev, non_blocking=True) * 1.0   # produced on the side stream
+        g = to_device(eps_h) * 1.0   # produced on the side stream
         m.integrate_device(g.data_ptr(), f.data_ptr(), c.data_ptr(), side.cuda_stream)
         total = f.sum()                                                 # consumed on the side stream
     side.synchronize()
     ref = onp.j2_update(eps_h, np.zeros((n, 6)), np.zeros(n), 70e3, 0.3, onp.LinearHardening(250.0, 5e3))
     assert abs(float(total) - ref["sig"].sum()) < 1e-6 * np.abs(ref["sig"]).sum()
-    assert np.abs(f.cpu().numpy() - ref["sig"]).max() < 1e-9 * np.abs(ref["sig"]).max()
+    assert np.abs(to_host(f) - ref["sig"]).max() < 1e-9 * np.abs(ref["sig"]).max()
 
 
 def test_device_path_is_graph_capturable():
@@ -123,7 +125,7 @@ def test_device_path_is_graph_capturable():
     dev = torch.device("cuda:0")
     m = _mat(n)
     h = j2_history(n)
-    g = [torch.from_numpy(x).to(dev) for x in h[:3]]
+    g = [to_device(x) for x in h[:3]]
     f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
     c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
     # eager reference: three updates from the same s0, last one wins
@@ -190,7 +192,7 @@ def test_tune_placement_preserves_state_and_results():
     mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V)))
     mat.set_data_manager(n)
     st = torch.cuda.current_stream().cuda_stream
-    g = [torch.from_numpy(x).to(dev) for x in h[:3]]
+    g = [to_device(x) for x in h[:3]]
     flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
     ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
     mat.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)

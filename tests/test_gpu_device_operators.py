@@ -12,6 +12,8 @@ from dolfinx_materials_amd.conventions import tangent_from_coefficients
 from dolfinx_materials_amd.gradient import Hex8Mesh, gauss_points_hex
 
 pytestmark = pytest.mark.gpu
+from helpers import to_device, to_host  # noqa: E402,F401
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
 S = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
 R2 = np.sqrt(2.0)
@@ -88,18 +90,18 @@ def test_force_apply_and_diagonal_match_numpy_on_a_distorted_mesh(n):
     sig = rng.standard_normal((len(conn) * 8, 6))
     x = rng.standard_normal(3 * nn)
     ct = tangent_from_coefficients(coef).reshape(-1, 36)
-    d_sig, d_x, d_coef, d_ct = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sig, x, coef, ct))
+    d_sig, d_x, d_coef, d_ct = (to_device(np.ascontiguousarray(a)) for a in (sig, x, coef, ct))
     y = torch.full((3 * nn,), float("nan"), dtype=torch.float64, device=dev)
     mesh.internal_force_device(d_sig.data_ptr(), y.data_ptr(), st)
     torch.cuda.synchronize()
     ref = host_force(g, wdet, conn, nn, sig)
-    assert np.abs(y.cpu().numpy() - ref).max() < 1e-13 * np.abs(ref).max()
+    assert np.abs(to_host(y) - ref).max() < 1e-13 * np.abs(ref).max()
     ref = host_apply(g, wdet, conn, nn, ct, x)
     for layout, field in (("coef", d_coef), ("full", d_ct)):
         y.fill_(float("nan"))
         mesh.tangent_apply_device(field.data_ptr(), d_x.data_ptr(), y.data_ptr(), layout=layout, stream=st)
         torch.cuda.synchronize()
-        assert np.abs(y.cpu().numpy() - ref).max() < 1e-12 * np.abs(ref).max(), layout
+        assert np.abs(to_host(y) - ref).max() < 1e-12 * np.abs(ref).max(), layout
     # deterministic: a second application gives the same bits
     y2 = torch.empty_like(y)
     mesh.tangent_apply_device(d_ct.data_ptr(), d_x.data_ptr(), y2.data_ptr(), layout="full", stream=st)
@@ -110,7 +112,7 @@ def test_force_apply_and_diagonal_match_numpy_on_a_distorted_mesh(n):
         diag = np.array([host_apply(g, wdet, conn, nn, ct, np.eye(3 * nn)[j])[j] for j in range(3 * nn)])
         mesh.tangent_diagonal_device(d_coef.data_ptr(), y.data_ptr(), st)
         torch.cuda.synchronize()
-        assert np.abs(y.cpu().numpy() - diag).max() < 1e-12 * diag.max() and diag.min() > 0
+        assert np.abs(to_host(y) - diag).max() < 1e-12 * diag.max() and diag.min() > 0
 
 
 def test_apply_equals_the_assembled_block_csr_matrix_of_the_host_loop():
@@ -128,18 +130,18 @@ def test_apply_equals_the_assembled_block_csr_matrix_of_the_host_loop():
     mesh = Hex8Mesh(m.coords, m.conn.astype(np.int32))
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
-    d_sig, d_x, d_coef = (torch.from_numpy(a).to(dev) for a in (sig, x, coef))
+    d_sig, d_x, d_coef = (to_device(a) for a in (sig, x, coef))
     y = torch.empty(m.ndof, dtype=torch.float64, device=dev)
     mesh.tangent_apply_device(d_coef.data_ptr(), d_x.data_ptr(), y.data_ptr(), stream=st)
     torch.cuda.synchronize()
     ref = K @ x
-    assert np.abs(y.cpu().numpy() - ref).max() < 1e-12 * np.abs(ref).max()
+    assert np.abs(to_host(y) - ref).max() < 1e-12 * np.abs(ref).max()
     mesh.internal_force_device(d_sig.data_ptr(), y.data_ptr(), st)
     torch.cuda.synchronize()
-    assert np.abs(y.cpu().numpy() - r).max() < 1e-12 * np.abs(r).max()
+    assert np.abs(to_host(y) - r).max() < 1e-12 * np.abs(r).max()
     mesh.tangent_diagonal_device(d_coef.data_ptr(), y.data_ptr(), st)
     torch.cuda.synchronize()
-    assert np.abs(y.cpu().numpy() - K.diagonal()).max() < 1e-12 * K.diagonal().max()
+    assert np.abs(to_host(y) - K.diagonal()).max() < 1e-12 * K.diagonal().max()
 
 
 def test_operators_need_eight_points_per_cell():

@@ -11,6 +11,8 @@ from oracle import constitutive_np as onp
 from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, eps_yield
 
 pytestmark = pytest.mark.gpu
+from helpers import to_device, to_host  # noqa: E402,F401
+
 N = 10_000_000
 
 
@@ -36,7 +38,7 @@ def test_j2_full_size_device_path(kind):
     st = torch.cuda.current_stream().cuda_stream
     idx = torch.arange(0, N, 9973, device=dev)
     idx = torch.cat([idx, torch.tensor([N - 1, N - 2, N - 63, N - 64, N - 65], device=dev)])
-    eps_s = eps_hat[idx].cpu().numpy()
+    eps_s = to_host(eps_hat[idx])
     epsp, p = np.zeros((len(idx), 6)), np.zeros(len(idx))
     p_prev = torch.zeros(N, dtype=torch.float64, device=dev)
     for k, fac in enumerate([1 / 3, 2 / 3, 1.0, 0.5]):
@@ -47,8 +49,8 @@ def test_j2_full_size_device_path(kind):
         assert rc == 0 and stats["n_nan"] == 0 and stats["n_points"] == N
         ref = onp.j2_update(eps_s * fac, epsp, p, E, NU, hard_o)
         safe = np.abs(ref["f_trial"]) > 1e-9 * hard_o.sig0
-        for got, exp in ((sig[idx].cpu().numpy(), ref["sig"]), (ct[idx].cpu().numpy().reshape(-1, 6, 6), ref["Ct"]),
-                         (isv[idx, 0].cpu().numpy(), ref["p"]), (isv[idx, 1:].cpu().numpy(), ref["epsp"])):
+        for got, exp in ((to_host(sig[idx]), ref["sig"]), (to_host(ct[idx]).reshape(-1, 6, 6), ref["Ct"]),
+                         (to_host(isv[idx, 0]), ref["p"]), (to_host(isv[idx, 1:]), ref["epsp"])):
             assert np.abs(got[safe] - exp[safe]).max() <= 1e-12 * max(np.abs(exp).max(), 1e-300)
         # whole-batch properties
         c3 = ct.view(N, 6, 6)
@@ -58,7 +60,7 @@ def test_j2_full_size_device_path(kind):
         assert abs(frac - ref["plastic"].mean()) < 0.05
         if k == 3:
             assert stats["n_plastic"] == 0
-            C = torch.from_numpy(onp.elastic_matrix(E, NU)).to(dev)
+            C = to_device(onp.elastic_matrix(E, NU))
             assert float((sig - sig_prev - (eps - eps_prev) @ C.T).abs().max()) < 1e-9 * float(sig_prev.abs().max())
         # a repeated update from the same s0 is bit-identical (no cross-point interference)
         chk = (float(sig.sum()), float(ct.sum()))
@@ -98,10 +100,10 @@ def test_fefp_full_size_device_path():
         mat.isv_device(1, isv.data_ptr(), st)
         rc, stats = mat.stats()
         assert rc == 0 and stats["n_nan"] == 0 and stats["n_not_converged"] == 0
-        ref = onp.fefp_update(F[idx].cpu().numpy(), cp, p, E, NU, hard_o)
+        ref = onp.fefp_update(to_host(F[idx]), cp, p, E, NU, hard_o)
         safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_F
-        for got, exp in ((P[idx].cpu().numpy(), ref["P"]), (ct[idx].cpu().numpy().reshape(-1, 9, 9), ref["Ct"]),
-                         (isv[idx, 0].cpu().numpy(), ref["p"]), (isv[idx, 1:].cpu().numpy(), ref["be_bar"])):
+        for got, exp in ((to_host(P[idx]), ref["P"]), (to_host(ct[idx]).reshape(-1, 9, 9), ref["Ct"]),
+                         (to_host(isv[idx, 0]), ref["p"]), (to_host(isv[idx, 1:]), ref["be_bar"])):
             assert np.abs(got[safe] - exp[safe]).max() <= 1e-11 * max(np.abs(exp).max(), 1e-300)
         # det(be_bar) = 1 over the whole batch (Mandel -> tensor on the device)
         b = isv[:, 1:]

@@ -12,6 +12,8 @@ from oracle import oracle_c
 from helpers import E, NU, SIG0_V, SIGU_V, B_V
 
 pytestmark = pytest.mark.gpu
+from helpers import to_device, to_host  # noqa: E402,F401
+
 TOL = 1e-11
 
 
@@ -88,7 +90,7 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
             # integrate_device and may move the resident state to another allocation)
             d = rng.standard_normal((n, 6))
             eps = 0.6 * eps + d * (rng.uniform(0, 3.0, n) * ey / np.linalg.norm(d, axis=1))[:, None]
-            d_eps = torch.from_numpy(eps).to(dev)
+            d_eps = to_device(eps)
             st = torch.cuda.current_stream().cuda_stream
             if op == "device":
                 m.integrate_device(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr(), st)
@@ -97,7 +99,7 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
             torch.cuda.synchronize()
             ref = model.integrate(eps)
             scale = max(np.abs(ref["sig"]).max(), SIG0_V)
-            assert close(d_flux.cpu().numpy(), ref["sig"], scale) and close(d_ct.cpu().numpy(), ref["Ct"].reshape(n, 36), np.abs(ref["Ct"]).max())
+            assert close(to_host(d_flux), ref["sig"], scale) and close(to_host(d_ct), ref["Ct"].reshape(n, 36), np.abs(ref["Ct"]).max())
             assert m.stats()[1]["n_plastic"] == ref["n_plastic"]
             known["final"] = False      # the host-side stress mirror does not follow the device-pointer forms
             held = None

@@ -14,6 +14,8 @@ from oracle import constitutive_np as onp
 from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, j2_history
 
 pytestmark = pytest.mark.gpu
+from helpers import to_device, to_host  # noqa: E402,F401
+
 
 
 def _j2(kind="linear", **kw):
@@ -151,7 +153,7 @@ def test_launch_generation_tells_when_a_captured_graph_is_stale():
     m = _j2()
     m.set_data_manager(n)
     h = j2_history(n, seed=21)
-    g = [torch.from_numpy(x).to(dev) for x in h]
+    g = [to_device(x) for x in h]
     f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
     c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
     st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
@@ -177,8 +179,8 @@ def test_launch_generation_tells_when_a_captured_graph_is_stale():
         assert rc == 0 and stats["n_nan"] == 0
         ref = onp.j2_update(h[k], epsp, p, E, NU, hard)
         safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_LIN
-        assert np.abs(f.cpu().numpy()[safe] - ref["sig"][safe]).max() <= 1e-12 * np.abs(ref["sig"]).max()
-        assert np.abs(c.cpu().numpy().reshape(n, 6, 6)[safe] - ref["Ct"][safe]).max() <= 1e-12 * np.abs(ref["Ct"]).max()
+        assert np.abs(to_host(f)[safe] - ref["sig"][safe]).max() <= 1e-12 * np.abs(ref["sig"]).max()
+        assert np.abs(to_host(c).reshape(n, 6, 6)[safe] - ref["Ct"][safe]).max() <= 1e-12 * np.abs(ref["Ct"]).max()
         epsp, p = ref["epsp"], ref["p"]
         m.data_manager.update()
         assert m.launch_generation != gen and (m.launch_generation ^ gen) == 1
@@ -197,7 +199,7 @@ def test_stats_after_the_launch_stream_is_gone():
     dev = torch.device("cuda:0")
     m = _j2()
     m.set_data_manager(n)
-    g = torch.from_numpy(j2_history(n)[2]).to(dev)
+    g = to_device(j2_history(n)[2])
     f = torch.zeros((n, 6), dtype=torch.float64, device=dev)
     c = torch.zeros((n, 36), dtype=torch.float64, device=dev)
     side = torch.cuda.Stream()
