@@ -124,7 +124,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
     kernel, is the whole cost when the consumer lives on the host."""
     h = history(n, seed)
 
-    def timed(bind, pageable_dma=False):
+    def timed(bind, pageable_dma=False, fresh=False):
         m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
         m.set_data_manager(n)
         if pageable_dma:
@@ -137,15 +137,22 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
         m.integrate(h[1])
         ts = []
         for _ in range(reps):
+            g = np.array(h[1]) if fresh else h[1]   # QuadratureMap.update builds a new gradient array per call
             t0 = time.perf_counter()
-            m.integrate(h[1])
+            m.integrate(g)
             ts.append(time.perf_counter() - t0)
+            del g
         m.close()
         return float(np.median(ts))
 
     dt_own, dt, dt_fast = timed(False), timed(True), timed(True, pageable_dma=True)
+    dt_fresh, dt_fresh_fast = timed(True, fresh=True), timed(True, pageable_dma=True, fresh=True)
     out = {"value": round(n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_call": round(dt * 1e3, 3), "points": n,
            "into_the_materials_own_arrays": {"value": round(n / dt_own / 1e6, 2), "ms_per_call": round(dt_own * 1e3, 3)},
+           "new_strain_array_every_call": {"value": round(n / dt_fresh / 1e6, 2), "ms_per_call": round(dt_fresh * 1e3, 3),
+                                           "with_option_pageable_dma": round(n / dt_fresh_fast / 1e6, 2),
+                                           "note": "what QuadratureMap.update hands over (quadrature_map.py:304-313): the runtime's pageable path "
+                                                   "has to page-lock the array again each time, the staged default does not care"},
            "with_option_pageable_dma": {"value": round(n / dt_fast / 1e6, 2), "ms_per_call": round(dt_fast * 1e3, 3),
                                         "note": "the pageable strain array handed to the runtime's own transfer path instead of the library's page-locked "
                                                 "staging ring: faster, but exposed to the runtime's cache of on-the-fly page-locked ranges (DESIGN.md section 1)"},
