@@ -48,7 +48,9 @@ def main():
     else:
         path = fefp_path(n)
         mk, hist = (lambda: jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F))), [path[9], path[18]]
-    g = [torch.from_numpy(h).to(dev) for h in hist]
+    from helpers import to_device
+
+    g = [to_device(h) for h in hist]
     del hist
     st = torch.cuda.current_stream().cuda_stream
     _lib.load()  # torch first, then HIP (one runtime)

@@ -79,7 +79,9 @@ def main():
     m.set_data_manager(n)
     ng, nf = m._info.n_grad, m._info.n_flux
     u = coords * np.array([scale, -0.4 * scale, -0.4 * scale]) + rng.standard_normal(coords.shape) * 0.1 * scale / a.cells
-    ud = torch.from_numpy(u.ravel().copy()).to(dev)
+    from helpers import to_device
+
+    ud = to_device(u.ravel().copy())
     grad = torch.empty((n, ng), dtype=torch.float64, device=dev)
     flux = torch.empty((n, nf), dtype=torch.float64, device=dev)
     ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)

@@ -85,7 +85,9 @@ def main():
         m = JAXMaterial(beh, tangent_layout="sym" if sym else "full")
         m.set_data_manager(n)
         ng, nf = m._info.n_grad, m._info.n_flux
-        g = [torch.from_numpy(h).to(dev) for h in hist]
+        from helpers import to_device
+
+        g = [to_device(h) for h in hist]
         del hist
         flux = torch.empty((n, nf), dtype=torch.float64, device=dev)
         ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)

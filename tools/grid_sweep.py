@@ -40,7 +40,9 @@ def main():
     else:
         hist = j2_history(n)[1:3]
         mk = lambda: jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN))  # noqa: E731
-    g = [torch.from_numpy(h).to(dev) for h in hist]
+    from helpers import to_device
+
+    g = [to_device(h) for h in hist]
     ng = g[0].shape[1]
     flux = torch.empty((n, ng), dtype=torch.float64, device=dev)
     ct = torch.empty((n, ng * ng), dtype=torch.float64, device=dev)

@@ -26,7 +26,9 @@ def main():
     n = 10_000_000
     dev = torch.device("cuda:0")
     h = j2_history(n)
-    g1, g2 = torch.from_numpy(h[1]).to(dev), torch.from_numpy(h[2]).to(dev)
+    from helpers import to_device
+
+    g1, g2 = to_device(h[1]), to_device(h[2])
     flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
     ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream().cuda_stream

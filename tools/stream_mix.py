@@ -30,7 +30,9 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     el = jm.LinearElasticIsotropic(E=bench.E, nu=bench.NU)
     gen = torch.Generator(device=dev).manual_seed(7)
-    hist = [torch.from_numpy(h).to(dev) for h in bench.history(n, 1234)]
+    from helpers import to_device
+
+    hist = [to_device(h) for h in bench.history(n, 1234)]
     Fg = torch.randn((n, 9), generator=gen, device=dev, dtype=torch.float64) * (0.2 * 2e-2)
     Fg[:, 0] += 1 + 2e-2
     Fg[:, 1] += 1 - 1e-2

@@ -24,7 +24,9 @@ def main():
     n = 10_000_000
     el = jm.LinearElasticIsotropic(E=E, nu=NU)
     hist = j2_history(n)[1:3]
-    g = [torch.from_numpy(h).to(dev) for h in hist]
+    from helpers import to_device
+
+    g = [to_device(h) for h in hist]
     flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
     ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
