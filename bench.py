@@ -118,6 +118,57 @@ def cpu_baseline(sample, seed, budget_s=14.0):
     return out
 
 
+def as_reference_update(qmap):
+    """What the reference's ``QuadratureMap.update()`` does AROUND ``material.integrate`` per global Newton iteration,
+    restated for a ``field_map.FieldMapBase`` (numpy stand-ins for the quadrature Functions): the cost a user of the
+    unmodified reference class pays with any material behind it.  quadrature_map.py:304-313 (every gradient scattered
+    into its Function, gathered back through ``dofs``, concatenated), :321-324 (integrate, then three full-array NaN
+    passes -- the ISV one is where a lazily fetched array gets downloaded), :331-334 + utils.py:136-143 (flux, every
+    internal state variable and the flattened tangent scattered through an index rebuilt on every call)."""
+    m = qmap.material
+    if not qmap._initialized:
+        state = {name: f.values[qmap.dofs] for name, f in {**qmap.fluxes, **qmap.internal_state_variables}.items()}
+        for name, g in qmap.gradients.items():
+            g.eval(qmap.cells)
+            state[name] = g.function.values[qmap.dofs, :]
+        m.set_initial_state_dict(state)
+        qmap._initialized = True
+    blocks = []
+    for name in m.gradients:
+        g = qmap.gradients[name]
+        g.eval(qmap.cells)
+        blocks.append(g.function.values[qmap.dofs, :])
+    flux, isv, ct = m.integrate(np.concatenate(blocks, axis=1))
+    assert not np.any(np.isnan(flux))
+    assert not np.any(np.isnan(isv))
+    assert not np.any(np.isnan(ct))
+
+    def scatter(field, array):
+        flat = np.asarray(array).ravel()
+        width = len(flat) // len(qmap.cells)                       # nqp * dim values per cell
+        index = np.add.outer(qmap.cells * width, np.arange(width)).ravel()
+        field.x.array[index] = flat
+
+    for fields, sizes, block in ((qmap.fluxes, m.fluxes, flux), (qmap.internal_state_variables, m.internal_state_variables, isv)):
+        col = 0
+        for name, dim in sizes.items():
+            w = max(1, dim)
+            scatter(fields[name], block[:, col:col + w])
+            col += w
+    scatter(qmap.jacobian_flatten, ct)
+
+
+def as_reference_advance(qmap):
+    """quadrature_map.py:350-360 in the same terms: roll the state, final flux / ISVs scattered into the Functions."""
+    m = qmap.material
+    m.data_manager.update()
+    final = m.get_final_state_dict()
+    for name, f in {**qmap.fluxes, **qmap.internal_state_variables}.items():
+        flat = np.asarray(final[name]).ravel()
+        width = len(flat) // len(qmap.cells)
+        f.x.array[np.add.outer(qmap.cells * width, np.arange(width)).ravel()] = flat
+
+
 def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
     """PCIe-inclusive rate of the drop-in form: numpy arrays in, numpy arrays out (`integrate(gradients)` as
     QuadratureMap.update calls it, quadrature_map.py:321).  Context only, never `value`: the transfer, not the
@@ -145,6 +196,92 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
         m.close()
         return float(np.median(ts))
 
+    def update_cadence(accelerated, reps, nqp=8):
+        """One ``QuadratureMap.update()`` at n points (n / 8 hexahedra with 8 Gauss points), numpy stand-ins for the
+        quadrature Functions (field_map.py): the reference's cadence around ``integrate`` (as_reference_update above)
+        against ``quadrature_map.AcceleratedUpdate``.  The gradient "expression" hands out the precomputed strain rows."""
+        from dolfinx_materials_amd.field_map import FieldMapBase, QuadratureFieldMap
+
+        ncell = n // nqp
+        npts = ncell * nqp
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
+        q = (QuadratureFieldMap if accelerated else FieldMapBase)(ncell, nqp, m)
+        q.register_gradient("strain", None)
+
+        class Ready:
+            """Stand-in for the compiled gradient expression at zero cost on both sides: the reference's cadence gets a
+            ready (ncell, nqp * 6) array back, as from ``Expression.eval(mesh, cells)``; the accelerated one finds the
+            values already where ``Expression.eval(mesh, cells, values=...)`` would have written them."""
+            rows = None
+
+            def eval(self, mesh, cells, values=None):
+                if values is None:
+                    return self.rows
+                if values.ctypes.data != self.rows.ctypes.data:
+                    values[...] = self.rows
+                return values
+
+        ready = q.gradients["strain"].expression = Ready()
+
+        def set_strain(k):
+            if accelerated:   # in the gradient Function's own memory
+                ready.rows = q.gradients["strain"].function.x.array.reshape(ncell, nqp * 6)
+                ready.rows[...] = h[k][:npts].reshape(ncell, nqp * 6)
+            else:
+                ready.rows = h[k][:npts].reshape(ncell, nqp * 6)
+
+        set_strain(0)
+        in_integrate = []
+        inner = m.integrate
+
+        def timed_integrate(g, dt=0):
+            t0 = time.perf_counter()
+            out = inner(g, dt)
+            in_integrate.append(time.perf_counter() - t0)
+            return out
+
+        m.integrate = timed_integrate
+        step = q.update if accelerated else (lambda: as_reference_update(q))
+        step()
+        (q.advance if accelerated else (lambda: as_reference_advance(q)))()
+        set_strain(1)
+        step()
+        ts = []
+        del in_integrate[:]
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        (q.advance if accelerated else (lambda: as_reference_advance(q)))()
+        t_adv = time.perf_counter() - t0
+        fields = {"stress": q.fluxes["stress"].x.array, "jacobian": q.jacobian_flatten.x.array, "p": q.internal_state_variables["p"].x.array,
+                  "epsp": q.internal_state_variables["epsp"].x.array}
+        dt_ = float(np.median(ts))
+        rec = {"value": round(npts / dt_ / 1e6, 2), "unit": "Mpoints/s", "ms_per_update": round(dt_ * 1e3, 2), "points": npts,
+               "ms_inside_integrate": round(float(np.median(in_integrate)) * 1e3, 2), "ms_per_advance": round(t_adv * 1e3, 2), "updates_timed": reps}
+        return rec, fields, (q, m)
+
+    def cadence_pair():
+        fast, f_fields, keep_f = update_cadence(True, reps)
+        try:
+            slow, s_fields, keep_s = update_cadence(False, 2)
+        except MemoryError as exc:
+            return {"accelerated_update": fast, "as_reference_update": {"error": repr(exc)}}
+        same = all(np.array_equal(f_fields[k], s_fields[k]) for k in f_fields)
+        for q_, m_ in (keep_f, keep_s):
+            if hasattr(q_, "close"):
+                q_.close()
+            m_.close()
+        fast["note"] = ("quadrature_map.AcceleratedUpdate (field_map.QuadratureFieldMap): flux / jacobian_flatten memory bound as the material's output arrays, "
+                        "gradient evaluated into its page-locked Function memory and uploaded by DMA, NaN count from the kernel's status record, "
+                        "internal state variables downloaded at advance()")
+        slow["note"] = ("the reference's cadence around the same HIPMaterial.integrate: gradient scattered into its Function and gathered back, concatenate, three np.isnan "
+                        "passes (the ISV one downloads 56 B/point), flux / ISVs / tangent scattered through a per-call np.add.outer index "
+                        "(quadrature_map.py:304-334, utils.py:136-143)")
+        return {"accelerated_update": fast, "as_reference_update": slow, "fields_bit_identical": bool(same),
+                "accelerated_over_reference": round(slow["ms_per_update"] / fast["ms_per_update"], 2)}
+
     dt_own, dt, dt_fast = timed(False), timed(True), timed(True, pageable_dma=True)
     dt_fresh, dt_fresh_fast = timed(True, fresh=True), timed(True, pageable_dma=True, fresh=True)
     out = {"value": round(n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_call": round(dt * 1e3, 3), "points": n,
@@ -162,6 +299,10 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
                    "and the (N,6,6) block rebuilt by 16 host threads with the kernel's own expression, bit-identical to the full download; "
                    "`value`: results delivered into caller-owned arrays (bind_outputs: the x.array of the quadrature Functions), the pageable strain array "
                    "staged through a page-locked ring by the worker threads (no DMA from or into pageable memory)"}
+    try:
+        out.update(cadence_pair())
+    except Exception as exc:  # context only
+        out["accelerated_update"] = {"error": repr(exc)}
     return out
 
 

@@ -180,13 +180,59 @@ _custom_libs = {}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+def jit_cache_dir() -> str:
+    """Where the JIT-compiled copies of the library live: ``$DXM_JIT_CACHE``, else
+    ``$XDG_CACHE_HOME/dolfinx_materials_amd/jit`` (``~/.cache/...``), else a per-user directory under the
+    system's temporary directory when the home directory is not writable.  Never inside the package."""
+    import tempfile
+
+    cand = []
+    if os.environ.get("DXM_JIT_CACHE"):
+        cand.append(os.environ["DXM_JIT_CACHE"])
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    cand.append(os.path.join(base, "dolfinx_materials_amd", "jit"))
+    cand.append(os.path.join(tempfile.gettempdir(), f"dolfinx_materials_amd_jit_{os.getuid()}"))
+    for d in cand:
+        try:
+            os.makedirs(d, exist_ok=True)
+            if os.access(d, os.W_OK | os.X_OK):
+                return d
+        except OSError:
+            continue
+    raise DxmError(f"no writable directory for the JIT cache among {cand}")
+
+
+JIT_CACHE_MAX = int(os.environ.get("DXM_JIT_CACHE_MAX", "32"))
+
+
+def _evict_jit_cache(root: str, keep: str) -> None:
+    """Least-recently-used eviction: at most ``JIT_CACHE_MAX`` compiled laws stay in the cache (``keep`` always does).
+    A library another process has loaded stays mapped after its file is unlinked."""
+    import shutil
+
+    try:
+        entries = []
+        for name in os.listdir(root):
+            lib = os.path.join(root, name, "libdxmat_custom.so")
+            if os.path.isfile(lib):
+                entries.append((os.stat(lib).st_mtime, os.path.join(root, name)))
+        entries.sort(reverse=True)
+        for _, d in entries[JIT_CACHE_MAX:]:
+            if os.path.abspath(d) != os.path.abspath(keep):
+                shutil.rmtree(d, ignore_errors=True)
+    except OSError:
+        pass   # housekeeping only
+
+
 def load_custom(expr_R: str, expr_dR: str) -> C.CDLL:
-    """Build (once, cached under ``dolfinx_materials_amd/_jit/``) and load a copy of libdxmat whose
+    """Build (once, cached under :func:`jit_cache_dir`) and load a copy of libdxmat whose
     "voce" kernels integrate a user-supplied isotropic hardening law: ``expr_R`` / ``expr_dR`` are C
     expressions for R(p) and dR/dp in the variables ``p``, ``sig0`` and ``c[0..5]``.  This is the
     counterpart of handing a Python ``yield_stress(p)`` callable to jaxmat and letting ``jax.jit``
     compile it on the first pass (``tests/test_FeFp_jax.py:14-19``, ``jaxmat.py:214-216``): here
-    hipcc compiles the fused gfx950 kernels with the law inlined (a few seconds)."""
+    hipcc compiles the fused gfx950 kernels with the law inlined (a few seconds).  The cache key is the
+    law together with the kernel sources; the least recently used entries beyond ``DXM_JIT_CACHE_MAX``
+    (32) are evicted."""
     import hashlib
 
     key = (expr_R, expr_dR)
@@ -198,7 +244,8 @@ def load_custom(expr_R: str, expr_dR: str) -> C.CDLL:
     h.update(expr_R.encode() + b"\0" + expr_dR.encode())
     for f in srcs:
         h.update(open(f, "rb").read())
-    out_dir = os.path.join(_HERE, "_jit", h.hexdigest()[:16])
+    root = jit_cache_dir()
+    out_dir = os.path.join(root, h.hexdigest()[:16])
     out = os.path.join(out_dir, "libdxmat_custom.so")
     if not os.path.exists(out):
         os.makedirs(out_dir, exist_ok=True)
@@ -222,6 +269,12 @@ def load_custom(expr_R: str, expr_dR: str) -> C.CDLL:
                 pass
             raise DxmError(f"compiling the custom hardening law failed:\n{r.stderr[-2000:]}")
         os.replace(tmp, out)
+        _evict_jit_cache(root, out_dir)
+    else:
+        try:
+            os.utime(out)   # recently used
+        except OSError:
+            pass
     _share_hip_runtime_with_torch()
     lib = _bind(C.CDLL(out))
     assert lib.dxm_has_custom_hardening() == 1

@@ -557,8 +557,11 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
     }
     if (law == DXM_LAW_ELASTIC_ISO || law == DXM_LAW_J2_LINEAR || law == DXM_LAW_J2_VOCE) m->blocks_per_cu = 32;
   }
-  // one record per workgroup and launch; sized for the largest grid dxm_set_option("blocks_per_cu") allows
-  m->stats_capacity = m->num_cu * 256;
+  // one record per workgroup and launch.  A single launch has at most num_cu * 256 workgroups (the largest grid
+  // dxm_set_option("blocks_per_cu") allows); the chunked host path appends the records of up to DXM_MAX_CHUNKS
+  // launches, each of min(ceil(chunk / 256), num_cu * blocks_per_cu) workgroups: never more than one record per
+  // 256 points plus one partial block per chunk
+  m->stats_capacity = (int)std::min<int64_t>(INT32_MAX, std::max<int64_t>((int64_t)m->num_cu * 256, (npoints + 255) / 256 + DXM_MAX_CHUNKS));
   if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {
     fail(-3, "hipMalloc of stats failed"); return bail();
   }
@@ -596,8 +599,9 @@ int dxm_law(const dxm_material* m) { return m ? m->law : -1; }
 
 int dxm_set_params(dxm_material* m, const double* params, int n_params) {
   if (!m || !params) return fail(-1, "null argument");
+  if (int rc = build_params(m, params, n_params)) return rc;   // nothing changed: captured graphs stay valid
   ++m->epoch;
-  return build_params(m, params, n_params);
+  return 0;
 }
 
 int dxm_set_tangent_layout(dxm_material* m, int layout) {
@@ -620,8 +624,9 @@ int dxm_set_newton(dxm_material* m, int maxit, double rtol) {
   if (maxit < 1 || !(rtol > 0.0)) return fail(-1, "invalid Newton controls maxit=%d rtol=%g", maxit, rtol);
   m->maxit = maxit;
   m->rtol = rtol;
+  if (int rc = build_params(m, m->raw_params.data(), (int)m->raw_params.size())) return rc;
   ++m->epoch;
-  return build_params(m, m->raw_params.data(), (int)m->raw_params.size());
+  return 0;
 }
 
 static int check_field(const dxm_material* m, int which, int field) {
@@ -668,22 +673,32 @@ static int materialize_s1(dxm_material* m) {
 // arrays all the time, as QuadratureMap.update does with its gradient arrays.  So: page-locked or registered memory
 // is used directly; anything else goes through this page-locked staging (two halves in flight) and a CPU copy.
 constexpr size_t BOUNCE_BYTES = 16u << 20;
-static bool page_locked(const void* host) {
+static bool page_locked_byte(const void* host) {
   hipPointerAttribute_t attr{};
   const bool locked = host && hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost;
   (void)hipGetLastError();   // "not a registered pointer" is the expected answer for ordinary memory
   return locked;
 }
+// Both ends of [host, host + bytes): an array that starts inside a registered / page-locked block but extends past it
+// (a view into a larger buffer, a dxm_host_register of a shorter length) must take the staged route too.
+static bool page_locked(const void* host, size_t bytes) {
+  if (!page_locked_byte(host)) return false;
+  return bytes <= 1 || page_locked_byte(static_cast<const char*>(host) + bytes - 1);
+}
 struct Staging {
   char* buf = nullptr;
   hipEvent_t done[2] = {nullptr, nullptr};
 };
-static std::mutex g_staging_mu;
+static std::mutex g_staging_mu[64];   // one per device: handles on different GPUs stage concurrently
 static Staging g_staging[64];
+static int current_device_index(int* dev) {
+  HIP_TRY(hipGetDevice(dev));
+  if (*dev < 0 || *dev >= 64) return fail(-1, "device index %d out of range", *dev);
+  return 0;
+}
 static int staging_for_current_device(Staging** out) {
   int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return fail(-1, "device index %d out of range", dev);
+  if (int rc = current_device_index(&dev)) return rc;
   Staging& s = g_staging[dev];
   if (!s.buf) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.buf), 2 * BOUNCE_BYTES, hipHostMallocDefault));
@@ -697,12 +712,14 @@ static size_t chunk_size(size_t c, size_t nchunks, size_t bytes) { return c + 1 
 // device -> caller-owned host memory; complete on return
 static int download_to_host(void* host, const void* dev, size_t bytes, hipStream_t st) {
   if (bytes == 0) return 0;
-  if (page_locked(host)) {
+  if (page_locked(host, bytes)) {
     HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
   }
-  std::lock_guard<std::mutex> lk(g_staging_mu);
+  int devi = 0;
+  if (int rc = current_device_index(&devi)) return rc;
+  std::lock_guard<std::mutex> lk(g_staging_mu[devi]);
   Staging* s = nullptr;
   if (int rc = staging_for_current_device(&s)) return rc;
   const size_t nchunks = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
@@ -723,12 +740,14 @@ static int download_to_host(void* host, const void* dev, size_t bytes, hipStream
 // caller-owned host memory -> device; the host range may be reused on return (the device copy is complete too)
 static int upload_from_host(void* dev, const void* host, size_t bytes, hipStream_t st) {
   if (bytes == 0) return 0;
-  if (page_locked(host)) {
+  if (page_locked(host, bytes)) {
     HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
   }
-  std::lock_guard<std::mutex> lk(g_staging_mu);
+  int devi = 0;
+  if (int rc = current_device_index(&devi)) return rc;
+  std::lock_guard<std::mutex> lk(g_staging_mu[devi]);
   Staging* s = nullptr;
   if (int rc = staging_for_current_device(&s)) return rc;
   const size_t nchunks = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
@@ -1156,9 +1175,28 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     for (hipEvent_t& e : m->ring_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const bool any = m->opt_pageable_dma;
-  const bool flux_locked = any || page_locked(flux_aos), isv_locked = any || page_locked(isv_aos), ct_locked = any || page_locked(ct_aos);
+  const bool flux_locked = any || page_locked(flux_aos, sizeof(double) * n * d.n_flux);
+  const bool isv_locked = any || page_locked(isv_aos, sizeof(double) * n * total);
+  const bool ct_locked = any || page_locked(ct_aos, sizeof(double) * n * tangent_size(m));
   int stats_off = 0, issued = 0, submitted = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
+  // An early return (a failing HIP call part-way through the chunk loop) leaves kernels, ring copies and downloads of
+  // the earlier chunks in flight on both streams, into the caller's arrays: wait for them before returning, so that the
+  // caller may free or reuse its arrays, and leave the handle as after a launch whose completion is unknown.
+  struct InFlight {
+    dxm_material* m;
+    bool completed = false;
+    ~InFlight() {
+      if (completed) return;
+      (void)hipStreamSynchronize(m->own_stream);
+      if (m->pipe_stream) (void)hipStreamSynchronize(m->pipe_stream);
+      (void)hipGetLastError();
+      m->launched = true;
+      m->last_event_recorded = false;   // sync_last falls back to the whole device
+      m->s1_alias = false;              // parts of s1 have been rewritten
+      m->last_grid = 0;
+    }
+  } inflight{m};
   // no worker may still be writing into the caller's array when this function returns, error paths included
   struct PoolDrain {
     HostPool* p;
@@ -1266,6 +1304,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const auto t_landed = std::chrono::steady_clock::now();
   if (packed) m->pool->wait();
   if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] all landed at +%.2f ms, workers done %.2f ms later\n", std::chrono::duration<double, std::milli>(t_landed - t_issued).count(), ms_since(t_landed));
+  inflight.completed = true;
   return dxm_get_stats(m, stats);
 }
 
@@ -1284,7 +1323,7 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   if (!grad_aos) return fail(-1, "null gradient pointer");
   DEVICE_GUARD(m);
   // a page-locked gradient array is uploaded by DMA; so is a pageable one if the caller asked for it (option pageable_dma)
-  const bool locked_in = m->opt_pageable_dma || page_locked(grad_aos);
+  const bool locked_in = m->opt_pageable_dma || page_locked(grad_aos, sizeof(double) * n * d.n_grad);
   if (int rc = ensure_host_path_buffers(m)) return rc;
   if (int rc = sync_last(m)) return rc;
   const int ng = d.n_grad;

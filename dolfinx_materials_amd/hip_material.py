@@ -284,20 +284,32 @@ class HIPMaterial:
                 self.close()
                 raise
         ng, nf = self._info.n_grad, self._info.n_flux
-        nisv = self._info.n_isv_total
         # host mirrors of the fields that are not device state (gradient and flux of s0 / s1)
         self._grad = [self._initial_gradient(), self._initial_gradient()]
         self._flux = [np.zeros((self._n, nf)), np.zeros((self._n, nf))]
-        # output arrays owned by the material, page-locked so that D2H runs at full PCIe rate
-        ct_shape = {"full": (self._n, nf, ng), "sym": (self._n, nf * (nf + 1) // 2), "coef": (self._n, 9)}[self.tangent_layout]
-        self._pinned = [_lib.PinnedArray((self._n, nisv)), _lib.PinnedArray(ct_shape),
-                        _lib.PinnedArray((self._n, nf)), _lib.PinnedArray((self._n, nf))]
-        self._out_isv, self._out_ct = self._pinned[0].array, self._pinned[1].array
-        self._out_isv[...] = 0.0
-        self._out_ct[...] = 0.0
-        self._flux_buf = [self._pinned[2].array, self._pinned[3].array]
+        # output arrays owned by the material: page-locked so that D2H runs at full PCIe rate, allocated when the first
+        # host-buffer call needs them (a bound array or a device-pointer caller never does)
+        self._ct_shape = {"full": (self._n, nf, ng), "sym": (self._n, nf * (nf + 1) // 2), "coef": (self._n, 9)}[self.tangent_layout]
+        self._pinned = {}
+        self._out_isv = self._out_ct = None
+        self._flux_buf = []
         self._flux_next = 0
         self.data_manager = DataManager(self, self._n)
+
+    def _own(self, key, shape):
+        if key not in self._pinned:
+            self._pinned[key] = _lib.PinnedArray(shape)
+            self._pinned[key].array[...] = 0.0
+        return self._pinned[key].array
+
+    def _ensure_outputs(self, isv=False):
+        nf = self._info.n_flux
+        if self._out_ct is None:
+            self._out_ct = self._own("tangent", self._ct_shape)
+        if not self._flux_buf:
+            self._flux_buf = [self._own("flux0", (self._n, nf)), self._own("flux1", (self._n, nf))]
+        if isv and self._out_isv is None:
+            self._out_isv = self._own("isv", (self._n, self._info.n_isv_total))
 
     def _initial_gradient(self):
         g = np.zeros((self._n, self._info.n_grad))
@@ -312,9 +324,9 @@ class HIPMaterial:
             self._lib.dxm_destroy(self._handle)
             self._handle = None
         self._unbind()
-        for p in getattr(self, "_pinned", []):
+        for p in getattr(self, "_pinned", {}).values():
             p.release()
-        self._pinned = []
+        self._pinned = {}
         self._out_isv = self._out_ct = None
         self._flux_buf = []
 
@@ -391,8 +403,8 @@ class HIPMaterial:
 
     def _advance(self):
         self._chk(self._lib.dxm_advance(self._require()))
-        self._grad[0] = self._grad[1]
-        # a bound flux array is overwritten by the next integrate: the s0 mirror keeps its own copy then
+        # a bound gradient / flux array is overwritten by the next update: the s0 mirrors keep their own copies then
+        self._grad[0] = self._grad[1].copy() if "gradient" in self._bound else self._grad[1]
         self._flux[0] = self._flux[1].copy() if "flux" in self._bound else self._flux[1]
 
     def _revert(self):
@@ -421,11 +433,12 @@ class HIPMaterial:
             g = _as_c(gradients)
             if g.shape != (self._n, ng):
                 raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
+            eager = not self.lazy_isv
+            self._ensure_outputs(isv=eager)
             flux = self._next_flux_buffer()
             st = Stats()
         timer_name = "jaxmat: Constitutive update" if self._warm else "jaxmat: First pass (includes jit compilation)"
         self._warm = True
-        eager = not self.lazy_isv
         with _Timer(timer_name):
             rc = self._lib.dxm_integrate(
                 h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv) if eager else None, _ptr(self._out_ct), C.byref(st)
@@ -440,11 +453,12 @@ class HIPMaterial:
             self._grad[1] = g
             self._flux[1] = flux
             self._serial += 1
-            isv = self._out_isv if eager else LazyISV(self, self._out_isv.shape)
+            isv = self._out_isv if eager else LazyISV(self, (self._n, self._info.n_isv_total))
         return flux, isv, self._out_ct
 
     def _fetch_isv(self):
         """Download the ISVs of the current s1 (for :class:`LazyISV`)."""
+        self._ensure_outputs(isv=True)
         self._chk(self._lib.dxm_isv_host(self._require(), S1, _ptr(self._out_isv)))
         return self._out_isv
 
@@ -471,9 +485,10 @@ class HIPMaterial:
         u = _as_c(u).reshape(-1)
         if u.size != mesh.displacement_size:
             raise ValueError(f"u must have {mesh.displacement_size} entries, got {u.size}")
+        eager = not self.lazy_isv
+        self._ensure_outputs(isv=eager)
         flux = self._next_flux_buffer()
         st = Stats()
-        eager = not self.lazy_isv
         rc = self._lib.dxm_integrate_displacement(
             h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(self._out_isv) if eager else None, _ptr(self._out_ct), C.byref(st)
         )
@@ -483,7 +498,7 @@ class HIPMaterial:
             warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
         self._flux[1] = flux
         self._serial += 1
-        return flux, (self._out_isv if eager else LazyISV(self, self._out_isv.shape)), self._out_ct
+        return flux, (self._out_isv if eager else LazyISV(self, (self._n, self._info.n_isv_total))), self._out_ct
 
     def integrate_device(self, grad_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
         """Device-pointer form: asynchronous launch on ``stream`` (a ``hipStream_t`` value, e.g.
@@ -542,7 +557,7 @@ class HIPMaterial:
         returns; call after ``set_data_manager``.  ``None`` keeps the material-owned buffer."""
         self._require()
         nf, ng = self._info.n_flux, self._info.n_grad
-        want = {"flux": (flux, self._n * nf), "tangent": (tangent, self._out_ct.size)}
+        want = {"flux": (flux, self._n * nf), "tangent": (tangent, int(np.prod(self._ct_shape)))}
         for key, (arr, size) in want.items():
             if arr is None:
                 continue
@@ -555,13 +570,60 @@ class HIPMaterial:
         if "flux" in self._bound:
             self._flux_buf = [self._bound["flux"].reshape(self._n, nf)]
         if "tangent" in self._bound:
-            self._out_ct = self._bound["tangent"].reshape(self._out_ct.shape)
+            self._out_ct = self._bound["tangent"].reshape(self._ct_shape)
+
+    def bind_inputs(self, gradient=None):
+        """Page-lock a caller-owned gradient array in place (``dxm_host_register``) -- e.g. the ``x.array`` of the
+        gradient's quadrature Function, which ``Expression.eval(..., values=)`` fills per update: ``integrate`` on
+        (a view of) that memory then uploads by DMA instead of staging the array through the library's page-locked
+        ring chunk by chunk.  The array must stay alive until ``close()`` / ``set_data_manager``."""
+        self._require()
+        if gradient is None:
+            return
+        size = self._n * self._info.n_grad
+        if not (isinstance(gradient, np.ndarray) and gradient.dtype == np.float64 and gradient.flags.c_contiguous and gradient.size == size):
+            raise ValueError(f"gradient must be a C-contiguous float64 array with {size} entries")
+        self._unbind("gradient")
+        if gradient.nbytes:
+            self._chk(self._lib.dxm_host_register(_ptr(gradient), gradient.nbytes))
+        self._bound["gradient"] = gradient
+
+    def pinned_array(self, shape):
+        """A zero-initialised fp64 array in page-locked host memory that owns its block (``_lib.PinnedArray``)."""
+        a = _lib.PinnedArray(shape).array
+        a[...] = 0.0
+        return a
+
+    def read_final_state(self, name, out):
+        """Field ``name`` of the final state s1 into the caller's C-contiguous ``(N, dim)`` fp64 array -- internal
+        state variables come straight from the device into it (``dxm_get_state``); the flux is the array the last
+        ``integrate`` delivered (nothing to do when ``out`` is that memory, i.e. a bound Function)."""
+        h = self._require()
+        if name not in self.variables:
+            raise ValueError(f"unknown field {name!r}")
+        dim = max(1, self.variables[name])
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.size == self._n * dim):
+            raise ValueError(f"out must be a C-contiguous float64 array with {self._n * dim} entries")
+        if name in (self._fname, self._gname):
+            src = (self._flux if name == self._fname else self._grad)[1]
+            if src.ctypes.data != out.ctypes.data:
+                out.reshape(src.shape)[...] = src
+        elif self._n:
+            self._chk(self._lib.dxm_get_state(h, S1, self.internal_state_variable_names.index(name), _ptr(out)))
+        return out
 
     def _unbind(self, key=None):
         for k in ([key] if key else list(self._bound)):
             arr = self._bound.pop(k, None)
-            if arr is not None and arr.nbytes:
+            if arr is None:
+                continue
+            if arr.nbytes:
                 self._lib.dxm_host_unregister(_ptr(arr))
+            # back to the material's own buffers (allocated when next needed)
+            if k == "flux":
+                self._flux_buf = []
+            elif k == "tangent":
+                self._out_ct = None
 
     def place_state(self, mode, chunk_bytes=2 << 20, seed=0):
         """``dxm_place_state``: rebuild the resident state in a fresh block (0) or from physical chunks mapped in

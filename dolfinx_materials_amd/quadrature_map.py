@@ -1,0 +1,286 @@
+"""``QuadratureMap`` with the exchange around the hot call re-organised for this engine.
+
+The reference's ``QuadratureMap.update()`` (``dolfinx_materials/quadrature_map.py:297-334``) spends, per global
+Newton iteration and around ``material.integrate``: a scatter of the evaluated gradient into its quadrature Function
+and a fancy-index gather back out of it (``quadrature_function.py:45-51``, ``quadrature_map.py:255-257``), a
+``np.concatenate`` copy (``:313``), three full-array ``np.isnan`` passes (``:322-324``) and three scatters through an
+index that ``_update_vals`` rebuilds on every call (``utils.py:136-143``: ``np.add.outer(cells * bs, arange(bs))`` --
+for the 36-wide tangent of 1e7 points a 3.6e8-entry int64 array, 2.9 GB).  None of it is arithmetic of the law.
+
+:class:`AcceleratedUpdate` is a mixin that overrides ``update() / advance() / initialize_state()`` in terms of the
+reference class's public attribute surface only -- ``material, mesh, cells, dofs, gradients, fluxes,
+internal_state_variables, external_state_variables, jacobian_flatten, rotation_func, _initialized`` -- and does the
+same job with what the engine offers:
+
+* a map over all cells (``dofs`` is the identity; the default, ``quadrature_map.py:66-70``) **binds** the ``x.array``
+  of the flux and ``jacobian_flatten`` Functions as the material's output arrays (``HIPMaterial.bind_outputs``
+  page-locks them in place): ``integrate`` delivers into them and nothing is scattered.  The gradient expression is
+  evaluated straight into its own Function's memory (``Expression.eval(mesh, cells, values=...)``), which is page-locked
+  too, so it is uploaded by DMA without a staging copy -- no gather, no concatenate;
+* a map over a subset of cells keeps a persistent page-locked gradient buffer and scatters rows through ``self.dofs``,
+  the point index the constructor already built (``quadrature_map.py:231-233, :259-260``) -- nothing is rebuilt per call;
+* NaNs are taken from the kernel's status record (``material.last_stats["n_nan"]``) instead of three host passes;
+* internal state variables cross PCIe when the increment is accepted (``advance``), not in every Newton iteration
+  (``refresh_internal_state_variables()`` / ``isv_every_update = True`` for callers that want them earlier);
+* optionally the gradient is evaluated on the GPU from the displacement vector (``register_device_gradient``).
+
+With a material that offers none of this (any duck-typed ``Material``: the oracle-backed one of the tests, a
+``generic.Material`` subclass) the same methods fall back to plain row copies and host-side NaN checks; results are
+identical either way (``tests/test_quadrature_map.py``, ``tests/test_gpu_quadrature_map.py``).
+
+``QuadratureMap`` below is ``type("QuadratureMap", (AcceleratedUpdate, dolfinx_materials.quadrature_map.QuadratureMap), {})``
+when the reference package imports (the third import swap of INTEGRATION.md section 1);
+``field_map.QuadratureFieldMap`` is the same mixin over a dolfinx-free stand-in base, which is how this code path is
+tested where dolfinx is absent.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def rows_of(fun, dim):
+    """``(points, dim)`` view of the memory of a quadrature Function (``utils.py:98-104``): point = cell * nqp + q,
+    component fastest."""
+    return fun.x.array.reshape(-1, max(1, int(dim)))
+
+
+def _same_memory(a, b):
+    return a.size == b.size and a.ctypes.data == b.ctypes.data
+
+
+class _Plan:
+    """What is decided once per map (first ``update`` / ``advance``), not once per call."""
+
+    identity = False          # dofs == arange(all points of the Functions): rows are the Functions' memory itself
+    bound = False             # flux + jacobian_flatten are the material's output arrays
+    npoints = 0
+    grad_buffers = None       # subset maps: persistent (page-locked where the material can) gradient rows per name
+    device_gradient = None    # (mesh, displacement callable)
+
+
+class AcceleratedUpdate:
+    """Mixin: ``update / advance / initialize_state`` of ``QuadratureMap`` around a batched engine."""
+
+    #: write the internal state variables into their Functions in every ``update()`` like the reference
+    #: (``quadrature_map.py:332``) instead of at ``advance()`` only
+    isv_every_update = False
+
+    # ---- set-up, once ------------------------------------------------------------------------------------------
+    def _accel_plan(self):
+        plan = self.__dict__.get("_accel")
+        if plan is not None:
+            return plan
+        plan = _Plan()
+        m = self.material
+        dofs = np.asarray(self.dofs)
+        plan.npoints = len(dofs)
+        widths = {name: max(1, int(dim)) for name, dim in {**m.fluxes, **m.internal_state_variables}.items()}
+        total = {len(rows_of(f, widths[name])) for name, f in {**self.fluxes, **self.internal_state_variables}.items()}
+        total.add(len(self.jacobian_flatten.x.array) // self._jacobian_width())
+        plan.identity = len(total) == 1 and total.pop() == plan.npoints and bool(np.array_equal(dofs, np.arange(plan.npoints)))
+        plan.grad_buffers = {}
+        # results straight into the Functions: one flux, full-width tangent, and a material that can take caller arrays
+        if plan.identity and plan.npoints > 0 and len(self.fluxes) == 1 and hasattr(m, "bind_outputs"):
+            (flux_fun,) = self.fluxes.values()
+            ct = self.jacobian_flatten.x.array
+            if getattr(m, "tangent_size", self._jacobian_width()) == self._jacobian_width():
+                m.bind_outputs(flux=flux_fun.x.array, tangent=ct)
+                plan.bound = True
+        self.__dict__["_accel"] = plan
+        return plan
+
+    def _jacobian_width(self):
+        return int(sum(int(np.prod(shape)) for shape in self.material.tangent_blocks.values())) or 1
+
+    def register_device_gradient(self, mesh, displacement):
+        """Evaluate the gradient on the GPU from the nodal vector ``displacement()`` returns (``gradient.Hex8Mesh`` /
+        ``Tet4Mesh`` / ``SimplexMesh``; ``*.from_dolfinx(V, degree)`` builds them from a function space, and
+        ``lambda: u.x.array`` is the callable): only that vector is uploaded per update, the step before the path
+        (``quadrature_function.py:45-51``) runs inside the update kernel.  Needs a map over all cells in mesh order."""
+        plan = self._accel_plan()
+        if not plan.identity or mesh.npoints != plan.npoints:
+            raise ValueError("device gradient evaluation needs a map over all cells of the mesh")
+        if not hasattr(self.material, "integrate_displacement"):
+            raise ValueError("this material cannot evaluate gradients on the device")
+        plan.device_gradient = (mesh, displacement)
+
+    def close(self):
+        """Give the Functions' memory back: un-page-lock the arrays bound to the material.  Call before the Functions
+        are destroyed when the map and the material do not die together."""
+        plan = self.__dict__.pop("_accel", None)
+        if plan is not None and hasattr(self.material, "_unbind"):
+            self.material._unbind()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- rows in / rows out ------------------------------------------------------------------------------------
+    def _take(self, fun, dim):
+        """Rows of ``fun`` that belong to this map, in the order the material sees them (a view for a map over all
+        cells, a gathered copy otherwise: ``_get_vals(field)[self.dofs]``, ``quadrature_map.py:271, :283-289``)."""
+        r = rows_of(fun, dim)
+        return r if self._accel_plan().identity else r[self.dofs]
+
+    def _put(self, fun, dim, values):
+        dst = rows_of(fun, dim)
+        src = np.asarray(values, dtype=np.float64).reshape(self._accel_plan().npoints, dst.shape[1])
+        if self._accel_plan().identity:
+            if not _same_memory(src, dst):          # bound outputs are already in place
+                dst[...] = src
+        else:
+            dst[self.dofs] = src
+
+    def _put_columns(self, funs, sizes, block):
+        block = np.asarray(block)
+        if len(sizes) == 1:
+            ((name, dim),) = sizes.items()
+            self._put(funs[name], dim, block)
+            return
+        col = 0
+        for name, dim in sizes.items():
+            w = max(1, int(dim))
+            self._put(funs[name], dim, block[:, col:col + w])
+            col += w
+
+    # ---- gradients -----------------------------------------------------------------------------------------------
+    def _evaluate_into(self, grad, out_rows):
+        """``Expression.eval`` with the destination given (dolfinx >= 0.8 takes ``values=``): the compiled expression
+        writes the rows of this map's cells, in this map's order, straight into ``out_rows``.  False when the
+        expression object cannot do that."""
+        expr = getattr(grad, "expression", None)
+        if expr is None or not self.__dict__.get("_accel_eval_into", True):
+            return False
+        try:
+            expr.eval(self.mesh, self.cells, values=out_rows.reshape(len(self.cells), -1))
+            return True
+        except TypeError:
+            self.__dict__["_accel_eval_into"] = False   # an older Expression.eval(mesh, cells): ask once only
+            return False
+
+    def _gradient_rows(self, name, dim):
+        plan = self._accel_plan()
+        grad = self.gradients[name]
+        if plan.identity:
+            rows = rows_of(grad.function, dim)
+            if name not in plan.grad_buffers:   # page-lock the Function's memory once: uploaded by DMA, no staging copy
+                pin = getattr(self.material, "bind_inputs", None)
+                if pin is not None and rows.size:
+                    pin(gradient=grad.function.x.array)
+                plan.grad_buffers[name] = rows
+            if not self._evaluate_into(grad, rows):
+                grad.eval(self.cells)           # the reference's route: scatter through the expression's dof table
+            return rows
+        buf = plan.grad_buffers.get(name)
+        if buf is None:
+            alloc = getattr(self.material, "pinned_array", None)
+            buf = plan.grad_buffers[name] = alloc((plan.npoints, max(1, int(dim)))) if alloc else np.empty((plan.npoints, max(1, int(dim))))
+        if not self._evaluate_into(grad, buf):
+            buf[...] = self.get_gradient_vals(grad, self.cells)
+        return buf
+
+    def _gradient_block(self):
+        sizes = self.material.gradients
+        blocks = [self._gradient_rows(name, dim) for name, dim in sizes.items()]
+        return blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=1)
+
+    # ---- the path ------------------------------------------------------------------------------------------------
+    def initialize_state(self):
+        """Initial state of the material from the current content of the flux / internal-state Functions and the
+        gradients at the current configuration (``quadrature_map.py:281-295``)."""
+        m = self.material
+        state = {}
+        plan = self._accel_plan()
+        if plan.device_gradient is None:
+            for name, dim in m.gradients.items():
+                if name in self.gradients:
+                    state[name] = np.array(self._gradient_rows(name, dim))
+        for funs, sizes in ((self.fluxes, m.fluxes), (self.internal_state_variables, m.internal_state_variables)):
+            for name, dim in sizes.items():
+                state[name] = np.array(self._take(funs[name], dim))
+        m.set_initial_state_dict(state)
+        self._initialized = True
+
+    def update(self):
+        """One constitutive update of the map's points (once per global Newton iteration, ``solvers.py:173-176``)."""
+        if not self._initialized:
+            self.initialize_state()
+        m = self.material
+        plan = self._accel_plan()
+        if getattr(self, "external_state_variables", None):
+            self.update_external_state_variables()
+        rotate = getattr(m, "rotation_matrix", None) is not None
+        if plan.device_gradient is not None:
+            mesh, displacement = plan.device_gradient
+            flux, isv, tangent = m.integrate_displacement(mesh, displacement())
+        else:
+            grad = self._gradient_block()
+            if rotate:   # in place, on the rows (quadrature_map.py:315-318); a bound gradient Function is re-evaluated next call
+                m.rotate_gradients(grad.ravel(), self.rotation_func.x.array)
+            flux, isv, tangent = m.integrate(grad)
+        stats = getattr(m, "last_stats", None)
+        if stats is not None and "n_nan" in stats:
+            assert stats["n_nan"] == 0, "non-finite constitutive update"
+        else:   # quadrature_map.py:322-324
+            assert not np.any(np.isnan(flux))
+            assert not np.any(np.isnan(isv))
+            assert not np.any(np.isnan(tangent))
+        if rotate:
+            m.rotate_fluxes(np.asarray(flux).ravel(), self.rotation_func.x.array)
+            m.rotate_tangent_operator(np.asarray(tangent).ravel(), self.rotation_func.x.array)
+        self._put_columns(self.fluxes, m.fluxes, flux)
+        self._put(self.jacobian_flatten, self._jacobian_width(), tangent)
+        self._last_isv = isv
+        if self.isv_every_update:
+            self.refresh_internal_state_variables()
+
+    def refresh_internal_state_variables(self):
+        """Internal state variables of the last ``update()`` into their Functions (what the reference does in every
+        update, ``quadrature_map.py:332, :343-348``); with the engine this is where they are downloaded."""
+        sizes = self.material.internal_state_variables
+        if sizes and getattr(self, "_last_isv", None) is not None:
+            self._put_columns(self.internal_state_variables, sizes, np.asarray(self._last_isv))
+
+    def advance(self):
+        """Accept the increment: initial state <- final state in the material, final flux and internal state
+        variables into the Functions (``quadrature_map.py:350-360``)."""
+        m = self.material
+        m.data_manager.update()
+        plan = self._accel_plan()
+        reader = getattr(m, "read_final_state", None)
+        final = None
+        for funs, sizes in ((self.fluxes, m.fluxes), (self.internal_state_variables, m.internal_state_variables)):
+            for name, dim in sizes.items():
+                if plan.identity and reader is not None:
+                    reader(name, rows_of(funs[name], dim))     # device -> the Function's memory, no intermediate array
+                    continue
+                if final is None:
+                    final = m.get_final_state_dict()
+                self._put(funs[name], dim, final[name])
+
+
+def _reference_class():
+    try:
+        from dolfinx_materials.quadrature_map import QuadratureMap as reference
+    except Exception:   # dolfinx / ufl / basix / mpi4py / the reference package are not installed
+        return None
+    return reference
+
+
+_reference = _reference_class()
+if _reference is not None:
+    QuadratureMap = type("QuadratureMap", (AcceleratedUpdate, _reference), {
+        "__doc__": "``dolfinx_materials.quadrature_map.QuadratureMap`` (same constructor, same attributes, same forms) with "
+                   "``update() / advance() / initialize_state()`` of :class:`AcceleratedUpdate`.",
+        "__module__": __name__,
+    })
+else:
+    class QuadratureMap:   # pragma: no cover - only reached where dolfinx is absent
+        """Placeholder where the reference package does not import: constructing it says what is missing."""
+
+        def __init__(self, *args, **kwargs):
+            raise ImportError(
+                "dolfinx_materials_amd.quadrature_map.QuadratureMap extends dolfinx_materials.quadrature_map.QuadratureMap: "
+                "install dolfinx and dolfinx_materials (dolfinx-free callers use dolfinx_materials_amd.field_map.QuadratureFieldMap)")

@@ -347,8 +347,10 @@ class TracedLaw:
         self.R_node, self.dR_node = trace(func)
         self.expr_R, self.expr_dR = emit_c(self.R_node), emit_c(self.dR_node)
         self.sig0 = float(evaluate(self.R_node, 0.0))
-        if not (self.sig0 > 0.0) or not math.isfinite(self.sig0):
-            raise ValueError(f"yield_stress(0) = {self.sig0}: the initial yield stress must be finite and positive")
+        # R(0) = 0 is a legitimate law (a power law rising from zero): the kernels floor their Newton tolerance at
+        # 2e-8 mu for it, and materials.CustomHardening accepts it
+        if not (self.sig0 >= 0.0) or not math.isfinite(self.sig0):
+            raise ValueError(f"yield_stress(0) = {self.sig0}: the initial yield stress must be finite and non-negative")
         # the trace must reproduce the callable itself (guards against value-dependent Python control flow)
         pts = np.array([0.0, 1e-4, 1e-3, 1e-2, 1e-1])
         try:

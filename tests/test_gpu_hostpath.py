@@ -276,3 +276,31 @@ def test_staged_and_runtime_uploads_give_the_same_bits(n):
         assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(np.asarray(ia), np.asarray(ib))
         a.data_manager.update()
         b.data_manager.update()
+
+
+def test_host_path_beyond_one_status_record_per_workgroup_of_a_single_launch():
+    """2e7 points through the chunked host-buffer form: 32 chunks of 2442 workgroups each append 78 144 block records,
+    more than the largest single launch (256 CUs x 256) the status buffer used to be sized for -- `dxm_integrate` then
+    failed part-way with "internal: stats buffer too small".  Strided sample against the oracle, whole batch through
+    the status record."""
+    n = 20_000_000
+    rng = np.random.default_rng(77)
+    eps = rng.standard_normal((n, 6))
+    eps *= (rng.uniform(0.0, 4.0, n) * SIG0_LIN / (2 * (E / 2 / (1 + NU))) * np.sqrt(2.0 / 3.0) / np.linalg.norm(eps, axis=1))[:, None]
+    m = _j2(tangent_layout="coef")        # 72 B/point of tangent: keeps the host arrays of this test at ~4 GB
+    m.set_data_manager(n)
+    sig, isv, coef = m.integrate(eps)
+    assert m.last_stats["n_points"] == n and m.last_stats["n_nan"] == 0 and m.last_stats["n_not_converged"] == 0
+    idx = np.concatenate([np.arange(0, n, 40_009), [n - 1, n - 255, n - 256, n - 257]])
+    ref = onp.j2_update(eps[idx], np.zeros((len(idx), 6)), np.zeros(len(idx)), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
+    safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_LIN
+    assert np.abs(sig[idx][safe] - ref["sig"][safe]).max() <= 1e-12 * np.abs(ref["sig"]).max()
+    from dolfinx_materials_amd.conventions import tangent_from_coefficients
+    assert np.abs(tangent_from_coefficients(coef[idx])[safe] - ref["Ct"][safe]).max() <= 1e-12 * np.abs(ref["Ct"]).max()
+    # the plastic count of the whole batch: same yield test on the host (points at the surface excluded from neither side)
+    mu = E / 2 / (1 + NU)
+    dev = eps.copy()
+    dev[:, :3] -= eps[:, :3].mean(axis=1)[:, None]
+    seq = np.sqrt(1.5) * 2 * mu * np.linalg.norm(dev, axis=1)
+    assert abs(m.last_stats["n_plastic"] - int((seq > SIG0_LIN).sum())) <= int((np.abs(seq - SIG0_LIN) < 1e-9 * SIG0_LIN).sum())
+    m.close()

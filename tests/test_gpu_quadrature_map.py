@@ -1,0 +1,163 @@
+"""``quadrature_map.AcceleratedUpdate`` with the engine behind it (``field_map.QuadratureFieldMap`` = the mixin over the
+dolfinx-free stand-in base): after every operation the flux / tangent / internal-state fields must be BIT-identical to
+what the reference's update cadence (``bench.as_reference_update``: ``quadrature_map.py:297-360`` + ``utils.py:136-143``)
+leaves in the same fields with a second ``HIPMaterial`` behind it, and within 1e-12 of the same cadence with the oracle
+material.  Maps over all cells deliver straight into the fields' memory (bound, page-locked in place), maps over a subset
+scatter rows; sizes on both sides of the packed-transfer threshold (32 768 points)."""
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from bench import as_reference_advance, as_reference_update
+from dolfinx_materials_amd.field_map import FieldMapBase, QuadratureFieldMap
+from dolfinx_materials_amd.hip_material import LazyISV
+from dolfinx_materials_amd.jaxmat import JAXMaterial
+from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, SIG0_F, SIGU_F, B_F, fefp_path, j2_history
+from oracle import constitutive_np as onp
+from oracle_material import OracleJ2Material
+
+pytestmark = pytest.mark.gpu
+
+
+def _behavior(law):
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if law == "j2_linear":
+        return jm.vonMisesIsotropicHardening(el, jm.LinearHardening(SIG0_LIN, H_LIN))
+    if law == "j2_voce":
+        return jm.vonMisesIsotropicHardening(el, jm.VoceHardening(SIG0_V, SIGU_V, B_V))
+    return jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F))
+
+
+def _fields(q):
+    return {**{k: f.x.array for k, f in q.fluxes.items()}, **{k: f.x.array for k, f in q.internal_state_variables.items()},
+            "jacobian": q.jacobian_flatten.x.array}
+
+
+@pytest.mark.parametrize("law,ncell,nqp,subset", [
+    ("j2_linear", 37, 4, False), ("j2_linear", 37, 4, True), ("j2_voce", 5001, 8, False), ("j2_voce", 9001, 8, True),
+    ("fefp", 23, 4, False), ("fefp", 4601, 8, True)])
+def test_accelerated_map_is_bit_identical_to_the_reference_cadence(law, ncell, nqp, subset):
+    n = ncell * nqp
+    rng = np.random.default_rng(11)
+    cells = np.sort(rng.choice(ncell, size=(ncell * 9) // 10, replace=False)).astype(np.int32) if subset else None
+    if law == "fefp":
+        hist, gname, ng = fefp_path(n, nsteps=6, eps=3e-2)[::2], "F", 9
+    else:
+        hist, gname, ng = j2_history(n, seed=3, sig0=SIG0_V if law == "j2_voce" else SIG0_LIN), "strain", 6
+    now = {"g": hist[0]}
+    ev = lambda c: now["g"].reshape(ncell, nqp, ng)[c].reshape(-1, ng)   # noqa: E731
+    fast = QuadratureFieldMap(ncell, nqp, JAXMaterial(_behavior(law)), cells=cells)
+    slow = FieldMapBase(ncell, nqp, JAXMaterial(_behavior(law)), cells=cells)
+    fast.isv_every_update = True
+    for q in (fast, slow):
+        q.register_gradient(gname, ev)
+    if law == "fefp":   # first call at F = I, as the reference demos do (finite_strain_elastoplasticity.py:181-184)
+        now["g"] = np.tile(np.array([1.0, 1, 1, 0, 0, 0, 0, 0, 0]), (n, 1))
+        fast.update()
+        as_reference_update(slow)
+    for k, g in enumerate(hist):
+        now["g"] = g
+        for rep in range(2):
+            fast.update()
+            as_reference_update(slow)
+            for name in _fields(slow):
+                assert np.array_equal(_fields(fast)[name], _fields(slow)[name]), (k, rep, name)
+        fast.advance()
+        as_reference_advance(slow)
+        for name in _fields(slow):
+            assert np.array_equal(_fields(fast)[name], _fields(slow)[name]), (k, "advance", name)
+    assert fast._bound == (not subset)
+    fast.close()
+    fast.material.close()
+    slow.material.close()
+
+
+@pytest.mark.parametrize("subset", [False, True])
+def test_accelerated_map_matches_the_oracle_material_behind_the_reference_cadence(subset):
+    ncell, nqp = 4200, 8          # 33 600 points: the packed transfer of the bound path
+    n = ncell * nqp
+    cells = np.arange(0, ncell, 2, dtype=np.int32) if subset else None
+    hist = j2_history(n, seed=8, sig0=SIG0_V)
+    now = {"g": hist[0]}
+    ev = lambda c: now["g"].reshape(ncell, nqp, 6)[c].reshape(-1, 6)   # noqa: E731
+    fast = QuadratureFieldMap(ncell, nqp, JAXMaterial(_behavior("j2_voce")), cells=cells)
+    ref = FieldMapBase(ncell, nqp, OracleJ2Material(E, NU, onp.VoceHardening(SIG0_V, SIGU_V, B_V)), cells=cells)
+    for q in (fast, ref):
+        q.register_gradient("strain", ev)
+    scale = {"stress": SIG0_V, "jacobian": E, "p": 1e-2, "epsp": 1e-2}
+    for g in hist:
+        now["g"] = g
+        fast.update()
+        as_reference_update(ref)
+        for name in ("stress", "jacobian"):
+            assert np.abs(_fields(fast)[name] - _fields(ref)[name]).max() <= 1e-12 * scale[name], name
+        fast.advance()
+        as_reference_advance(ref)
+        for name in _fields(ref):
+            assert np.abs(_fields(fast)[name] - _fields(ref)[name]).max() <= 1e-12 * scale[name], name
+    fast.close()
+    fast.material.close()
+
+
+def test_bound_map_delivers_into_the_fields_memory_and_fetches_isvs_at_advance_only():
+    ncell, nqp = 5000, 8
+    n = ncell * nqp
+    hist = j2_history(n, seed=2)
+    now = {"g": hist[1]}
+    m = JAXMaterial(_behavior("j2_linear"))
+    q = QuadratureFieldMap(ncell, nqp, m)
+    q.register_gradient("strain", lambda c: now["g"].reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    q.update()
+    assert q._bound and set(m._bound) == {"flux", "tangent", "gradient"}
+    assert m._bound["flux"].ctypes.data == q.fluxes["stress"].x.array.ctypes.data
+    assert m._bound["tangent"].ctypes.data == q.jacobian_flatten.x.array.ctypes.data
+    assert m._bound["gradient"].ctypes.data == q.gradients["strain"].function.x.array.ctypes.data
+    assert isinstance(q._last_isv, LazyISV) and not q._last_isv.fetched        # nothing looked at the ISVs
+    assert not q.internal_state_variables["p"].x.array.any() and m.last_stats["n_plastic"] > 0
+    now["g"] = hist[2]
+    q.update()
+    assert not q._last_isv.fetched
+    q.advance()
+    ref = onp.j2_update(hist[2], np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
+    assert np.abs(q.internal_state_variables["p"].x.array - ref["p"]).max() < 1e-14
+    assert np.abs(q.internal_state_variables["epsp"].values - ref["epsp"]).max() < 1e-14
+    assert np.abs(q.fluxes["stress"].values - ref["sig"]).max() < 1e-12 * SIG0_LIN
+    # the s0 mirrors are the material's own copies: the next update overwrites the bound arrays, not them
+    s0 = m.get_initial_state_dict()
+    now["g"] = hist[3]
+    q.update()
+    assert np.array_equal(s0["strain"], hist[2]) and np.abs(s0["stress"] - ref["sig"]).max() < 1e-12 * SIG0_LIN
+    q.close()
+    assert not m._bound
+    m.close()
+
+
+def test_device_gradient_through_the_map_equals_the_host_gradient_route():
+    from dolfinx_materials_amd.gradient import Hex8Mesh
+
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from hex_fem import HexMesh
+
+    mesh = HexMesh(6)
+    rng = np.random.default_rng(5)
+    u = 2e-3 * rng.standard_normal(mesh.ndof)
+    maps = []
+    for device in (False, True):
+        q = QuadratureFieldMap(mesh.num_cells, mesh.nqp, JAXMaterial(_behavior("j2_linear")))
+        q.register_gradient("strain", lambda cells: mesh.strain(u, cells))
+        if device:
+            q.register_device_gradient(Hex8Mesh(mesh.coords, mesh.conn), lambda: u)
+        q.update()
+        q.advance()
+        maps.append(q)
+    for name in _fields(maps[0]):
+        a, b = _fields(maps[0])[name], _fields(maps[1])[name]
+        assert np.abs(a - b).max() <= 1e-11 * max(np.abs(a).max(), 1e-300), name
+    with pytest.raises(ValueError):
+        QuadratureFieldMap(mesh.num_cells, mesh.nqp, JAXMaterial(_behavior("j2_linear")), cells=np.array([0, 1], dtype=np.int32)
+                           ).register_device_gradient(Hex8Mesh(mesh.coords, mesh.conn), lambda: u)
+    for q in maps:
+        q.close()
+        q.material.close()

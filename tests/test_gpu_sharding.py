@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, j2_history
+from helpers import E, NU, SIG0_LIN, H_LIN, SIG0_V, SIGU_V, B_V, j2_history, to_device
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -135,7 +135,7 @@ def test_coefficient_gather_payload_is_rebuilt_bit_for_bit_on_the_device(gpu_ava
     c36, c9, out = (torch.empty((n, k), dtype=torch.float64, device=dev) for k in (36, 9, 36))
     lib = _lib.load()
     for eps in j2_history(n, seed=8, sig0=SIG0_V):
-        g = torch.from_numpy(eps).to(dev)
+        g = to_device(eps, dev)   # through a page-locked staging tensor
         full.integrate_device(g.data_ptr(), f.data_ptr(), c36.data_ptr(), st)
         coef.integrate_device(g.data_ptr(), f.data_ptr(), c9.data_ptr(), st)
         out.fill_(float("nan"))

@@ -1,0 +1,214 @@
+"""CPU tests of ``quadrature_map.AcceleratedUpdate`` through ``field_map.QuadratureFieldMap``,
+the same mixin over the dolfinx-free stand-in base: after every operation the flux / tangent / internal-state fields must
+be bit-identical to what the reference's update cadence produces (``bench.as_reference_update``: the per-call scatter,
+gather, concatenate, NaN passes and index rebuild of ``quadrature_map.py:297-360`` + ``utils.py:136-143`` around the same
+``material.integrate``).  The material is the oracle-backed one; a variant of it offers the engine's optional members
+(bound outputs, page-locked inputs, status record, final state into caller memory) so that those branches run here too."""
+import numpy as np
+import pytest
+
+from bench import as_reference_advance, as_reference_update
+from dolfinx_materials_amd.field_map import FieldMapBase, QuadratureFieldMap
+from dolfinx_materials_amd.quadrature_map import AcceleratedUpdate, QuadratureMap
+from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
+from oracle import constitutive_np as onp
+from oracle_material import OracleJ2Material
+
+
+class EngineLikeMaterial(OracleJ2Material):
+    """The oracle material with the optional members ``AcceleratedUpdate`` looks for on an engine material."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.calls = []
+        self._out = {}
+
+    tangent_size = 36
+
+    def bind_outputs(self, flux=None, tangent=None):
+        self.calls.append("bind_outputs")
+        self._out = {"flux": flux, "tangent": tangent}
+
+    def bind_inputs(self, gradient=None):
+        self.calls.append("bind_inputs")
+        self._gradient_memory = gradient
+
+    def _unbind(self):
+        self.calls.append("unbind")
+        self._out = {}
+
+    def integrate(self, g, dt=0):
+        if getattr(self, "_gradient_memory", None) is not None:   # the map must hand over the registered memory itself
+            assert np.asarray(g).ctypes.data == self._gradient_memory.ctypes.data
+        flux, isv, ct = super().integrate(g, dt)
+        if self._out:
+            self._out["flux"].reshape(flux.shape)[...] = flux
+            self._out["tangent"].reshape(ct.shape)[...] = ct
+            flux, ct = self._out["flux"].reshape(flux.shape), self._out["tangent"].reshape(ct.shape)
+            self.s1["stress"] = flux
+        return flux, isv, ct
+
+    def read_final_state(self, name, out):
+        self.calls.append(f"read:{name}")
+        src = self.s1[name]
+        if src.ctypes.data != out.ctypes.data:
+            out[...] = src.reshape(out.shape)
+
+
+def _hard():
+    return onp.LinearHardening(SIG0_LIN, H_LIN)
+
+
+def _fields(qmap):
+    return {**{k: f.x.array for k, f in qmap.fluxes.items()}, **{k: f.x.array for k, f in qmap.internal_state_variables.items()},
+            "jacobian": qmap.jacobian_flatten.x.array}
+
+
+@pytest.mark.parametrize("material", [OracleJ2Material, EngineLikeMaterial])
+@pytest.mark.parametrize("subset", [False, True])
+def test_accelerated_update_equals_the_reference_cadence(material, subset):
+    ncell, nqp = 13, 4
+    cells = np.array([0, 2, 3, 7, 11, 12], dtype=np.int32) if subset else None
+    hist = j2_history(ncell * nqp, seed=3)
+    strain = {"now": hist[0]}
+    ev = lambda c: strain["now"].reshape(ncell, nqp, 6)[c].reshape(-1, 6)   # noqa: E731
+    fast = QuadratureFieldMap(ncell, nqp, material(E, NU, _hard()), cells=cells)
+    slow = FieldMapBase(ncell, nqp, OracleJ2Material(E, NU, _hard()), cells=cells)
+    fast.isv_every_update = True   # the reference writes the ISV fields in every update
+    for q in (fast, slow):
+        q.register_gradient("strain", ev)
+    for k, eps in enumerate(hist):
+        strain["now"] = eps
+        for rep in range(2):   # two Newton iterations per increment from the same initial state
+            fast.update()
+            as_reference_update(slow)
+            for name in _fields(slow):
+                assert np.array_equal(_fields(fast)[name], _fields(slow)[name]), (k, rep, name)
+        fast.advance()
+        as_reference_advance(slow)
+        for name in _fields(slow):
+            assert np.array_equal(_fields(fast)[name], _fields(slow)[name]), (k, "advance", name)
+        assert np.array_equal(fast.material.s0["p"], slow.material.s0["p"])
+    if not subset:   # rows outside a subset map stay untouched (zero)
+        assert np.abs(_fields(fast)["jacobian"]).min() >= 0.0
+    else:
+        other = np.setdiff1d(np.arange(ncell), cells)
+        assert not fast.fluxes["stress"].values.reshape(ncell, -1)[other].any()
+        assert not fast.jacobian_flatten.values.reshape(ncell, -1)[other].any()
+
+
+def test_internal_state_variables_are_written_at_advance_only_by_default():
+    ncell, nqp = 5, 4
+    eps = j2_history(ncell * nqp, seed=9)[2]
+    q = QuadratureFieldMap(ncell, nqp, OracleJ2Material(E, NU, _hard()))
+    q.register_gradient("strain", lambda c: eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    q.update()
+    assert q.fluxes["stress"].x.array.any() and not q.internal_state_variables["p"].x.array.any()
+    q.refresh_internal_state_variables()
+    p_now = q.internal_state_variables["p"].x.array.copy()
+    assert p_now.any()
+    q.advance()
+    assert np.array_equal(q.internal_state_variables["p"].x.array, p_now)
+
+
+def test_map_over_all_cells_binds_the_functions_memory_and_scatters_nothing():
+    ncell, nqp = 6, 8
+    eps = j2_history(ncell * nqp, seed=4)[2]
+    m = EngineLikeMaterial(E, NU, _hard())
+    q = QuadratureFieldMap(ncell, nqp, m)
+    q.register_gradient("strain", lambda c: eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    q.update()
+    assert q._bound and q.covers_everything
+    assert m.calls.count("bind_outputs") == 1 and m.calls.count("bind_inputs") == 1
+    assert m._out["flux"].ctypes.data == q.fluxes["stress"].x.array.ctypes.data
+    assert m._out["tangent"].ctypes.data == q.jacobian_flatten.x.array.ctypes.data
+    assert m._gradient_memory.ctypes.data == q.gradients["strain"].function.x.array.ctypes.data
+    assert np.array_equal(q.gradients["strain"].function.values, eps)   # evaluated straight into the Function
+    q.update()
+    assert m.calls.count("bind_outputs") == 1 and m.calls.count("bind_inputs") == 1   # once per map, not per call
+    q.advance()
+    assert [c for c in m.calls if c.startswith("read:")] == ["read:stress", "read:p", "read:epsp"]
+    q.close()
+    assert m.calls[-1] == "unbind"
+
+
+def test_subset_map_does_not_bind_and_keeps_one_gradient_buffer():
+    ncell, nqp = 6, 4
+    eps = j2_history(ncell * nqp, seed=4)[2]
+    m = EngineLikeMaterial(E, NU, _hard())
+    q = QuadratureFieldMap(ncell, nqp, m, cells=np.array([1, 4], dtype=np.int32))
+    q.register_gradient("strain", lambda c: eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    q.update()
+    buf = q._accel_plan().grad_buffers["strain"]
+    q.update()
+    assert not q._bound and "bind_outputs" not in m.calls
+    assert q._accel_plan().grad_buffers["strain"] is buf and buf.shape == (2 * nqp, 6)
+
+
+def test_expression_without_a_values_argument_takes_the_references_route():
+    """dolfinx < 0.8: ``Expression.eval(mesh, cells)`` has no ``values=``; the map then lets the QuadratureExpression
+    scatter into its Function as the reference does (``quadrature_function.py:45-51``)."""
+    ncell, nqp = 4, 4
+    eps = j2_history(ncell * nqp, seed=6)[2]
+
+    class OldExpression:
+        def eval(self, mesh, cells):
+            return eps.reshape(ncell, nqp * 6)[cells]
+
+    for cells in (None, np.array([0, 3], dtype=np.int32)):
+        q = QuadratureFieldMap(ncell, nqp, OracleJ2Material(E, NU, _hard()), cells=cells)
+        ref = FieldMapBase(ncell, nqp, OracleJ2Material(E, NU, _hard()), cells=cells)
+        for qq in (q, ref):
+            qq.register_gradient("strain", lambda c: eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+        q.gradients["strain"].expression = OldExpression()
+        q.update()
+        as_reference_update(ref)
+        assert np.array_equal(q.fluxes["stress"].x.array, ref.fluxes["stress"].x.array)
+        assert q.__dict__["_accel_eval_into"] is False
+
+
+def test_nan_from_the_status_record_or_from_the_arrays():
+    ncell, nqp = 2, 4
+    bad = np.full((ncell * nqp, 6), np.nan)
+    for mat in (OracleJ2Material(E, NU, _hard()), EngineLikeMaterial(E, NU, _hard())):
+        q = QuadratureFieldMap(ncell, nqp, mat)
+        q.register_gradient("strain", lambda c: bad.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+        with pytest.raises(AssertionError):
+            q.update()
+    plain = OracleJ2Material(E, NU, _hard())
+    q = QuadratureFieldMap(ncell, nqp, plain)
+    q.register_gradient("strain", lambda c: bad.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    orig = plain.integrate
+    plain.integrate = lambda g, dt=0: (lambda r: (setattr(plain, "last_stats", None), r)[1])(orig(g, dt))   # no status record
+    with pytest.raises(AssertionError):
+        q.update()
+
+
+def test_the_mixin_only_uses_the_reference_classs_attribute_surface():
+    """Every ``self.<name>`` the mixin reads that it does not define itself is an attribute / method of the reference's
+    ``QuadratureMap`` (``quadrature_map.py:51-130, :197-260``) -- checked against the stand-in base, which offers
+    exactly that list, and against the source text of the mixin."""
+    import inspect
+    import re
+
+    src = inspect.getsource(AcceleratedUpdate)
+    used = set(re.findall(r"self\.([A-Za-z_][A-Za-z_0-9]*)", src))
+    own = {n for n in vars(AcceleratedUpdate)} | {"__dict__", "_last_isv"}
+    reference_surface = {"material", "mesh", "cells", "dofs", "gradients", "fluxes", "internal_state_variables",
+                         "external_state_variables", "jacobian_flatten", "rotation_func", "_initialized",
+                         "get_gradient_vals", "update_external_state_variables"}
+    assert used - own <= reference_surface, sorted(used - own - reference_surface)
+    base = FieldMapBase(2, 1, OracleJ2Material(E, NU, _hard()))
+    for name in reference_surface - {"update_external_state_variables"}:
+        assert hasattr(base, name), name
+
+
+def test_quadrature_map_placeholder_says_what_is_missing():
+    pytest.importorskip  # noqa: B018
+    try:
+        import dolfinx_materials  # noqa: F401
+    except Exception:
+        with pytest.raises(ImportError, match="dolfinx"):
+            QuadratureMap(None, 2, None)
+    else:
+        assert issubclass(QuadratureMap, AcceleratedUpdate)
