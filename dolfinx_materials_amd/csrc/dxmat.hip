@@ -13,6 +13,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <cstdarg>
@@ -673,6 +674,26 @@ static int materialize_s1(dxm_material* m) {
 // arrays all the time, as QuadratureMap.update does with its gradient arrays.  So: page-locked or registered memory
 // is used directly; anything else goes through this page-locked staging (two halves in flight) and a CPU copy.
 constexpr size_t BOUNCE_BYTES = 16u << 20;
+// Host ranges this library has page-locked itself (dxm_host_alloc, dxm_host_register): start -> bytes.
+static std::mutex g_locked_mu;
+static std::map<uintptr_t, size_t> g_locked_ranges;
+static std::atomic<int> g_query_foreign{1};   // ask the runtime about pointers that are not in the table (option "query_foreign_pointers")
+static void note_locked(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_locked_mu);
+  g_locked_ranges[reinterpret_cast<uintptr_t>(p)] = bytes;
+}
+static void forget_locked(const void* p) {
+  std::lock_guard<std::mutex> lk(g_locked_mu);
+  g_locked_ranges.erase(reinterpret_cast<uintptr_t>(p));
+}
+static bool in_locked_table(const void* host, size_t bytes) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(host);
+  std::lock_guard<std::mutex> lk(g_locked_mu);
+  auto it = g_locked_ranges.upper_bound(a);
+  if (it == g_locked_ranges.begin()) return false;
+  --it;
+  return a >= it->first && a + bytes <= it->first + it->second;
+}
 static bool page_locked_byte(const void* host) {
   hipPointerAttribute_t attr{};
   const bool locked = host && hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost;
@@ -682,6 +703,9 @@ static bool page_locked_byte(const void* host) {
 // Both ends of [host, host + bytes): an array that starts inside a registered / page-locked block but extends past it
 // (a view into a larger buffer, a dxm_host_register of a shorter length) must take the staged route too.
 static bool page_locked(const void* host, size_t bytes) {
+  if (!host) return false;
+  if (in_locked_table(host, bytes)) return true;
+  if (!g_query_foreign.load()) return false;
   if (!page_locked_byte(host)) return false;
   return bytes <= 1 || page_locked_byte(static_cast<const char*>(host) + bytes - 1);
 }
@@ -1216,6 +1240,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                         sizeof(double) * ((n - o) < csize ? (n - o) : csize) * d.n_grad, p);
     return 0;
   };
+  double ms_wait_copy = 0.0, ms_first_copy = 0.0;   // tune_verbose: time the issue loop spent waiting for staging copies
   for (int p = 0; p < 3; ++p) if (int rc = stage_chunk(p)) return rc;
   for (int c = 0; c < nchunks; ++c) {
     const int64_t off = (int64_t)c * csize;
@@ -1228,10 +1253,18 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       const int slot = c % 8;
       double* dst = m->h_grad_ring + (int64_t)slot * m->ring_slot_doubles;
       if (int rc = stage_chunk(c + 3)) return rc;   // keep three chunks ahead of the launches
-      m->pool->wait_copy(c);
+      {
+        const auto tw = std::chrono::steady_clock::now();
+        m->pool->wait_copy(c);
+        const double w = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+        ms_wait_copy += w;
+        if (c == 0) ms_first_copy = w;
+      }
       // page-locked host memory is addressable from the device under the same pointer
       const int64_t n16 = cnt * d.n_grad / 2;      // cnt is a multiple of 256 except in the last chunk; n_grad 6 or 9:
       const int64_t tail = cnt * d.n_grad - 2 * n16;   // an odd count leaves one double for a plain copy
+      // (on the chunk's own stream: a third stream carrying all uploads ahead of the kernels was measured at 46-62 ms per
+      // 1e7 points against 31-33, profiles/r03_hostpath_fresh_array.md)
       hipLaunchKernelGGL(ring_upload_kernel, dim3(32), dim3(256), 0, st, reinterpret_cast<const double2_t*>(dst),
                          reinterpret_cast<double2_t*>(m->d_grad + off * d.n_grad), n16);
       if (tail) HIP_TRY(hipMemcpyAsync(m->d_grad + off * d.n_grad + 2 * n16, dst + 2 * n16, sizeof(double), hipMemcpyHostToDevice, st));
@@ -1303,9 +1336,13 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   m->last_event_recorded = true;
   const auto t_landed = std::chrono::steady_clock::now();
   if (packed) m->pool->wait();
+  if (m->opt_tune_verbose && host_grad) fprintf(stderr, "[dxm host path] %d chunks of %lld points; issue loop waited %.2f ms for staging copies (first chunk %.2f ms)\n", nchunks, (long long)csize, ms_wait_copy, ms_first_copy);
   if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] all landed at +%.2f ms, workers done %.2f ms later\n", std::chrono::duration<double, std::milli>(t_landed - t_issued).count(), ms_since(t_landed));
   inflight.completed = true;
-  return dxm_get_stats(m, stats);
+  const auto t_stats = std::chrono::steady_clock::now();
+  const int rc_stats = dxm_get_stats(m, stats);
+  if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] status records summed in %.3f ms; %.2f ms since entry\n", ms_since(t_stats), ms_since(t_enter));
+  return rc_stats;
 }
 
 extern "C" {
@@ -1323,9 +1360,15 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   if (!grad_aos) return fail(-1, "null gradient pointer");
   DEVICE_GUARD(m);
   // a page-locked gradient array is uploaded by DMA; so is a pageable one if the caller asked for it (option pageable_dma)
+  const auto t_in = std::chrono::steady_clock::now();
   const bool locked_in = m->opt_pageable_dma || page_locked(grad_aos, sizeof(double) * n * d.n_grad);
+  const auto t_q = std::chrono::steady_clock::now();
   if (int rc = ensure_host_path_buffers(m)) return rc;
   if (int rc = sync_last(m)) return rc;
+  if (m->opt_tune_verbose)
+    fprintf(stderr, "[dxm host path] classifying the gradient pointer took %.3f ms, buffers + wait for the previous call %.3f ms\n",
+            std::chrono::duration<double, std::milli>(t_q - t_in).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q).count());
   const int ng = d.n_grad;
   auto upload = [&](int64_t off, int64_t cnt, hipStream_t st) -> int {
     if (locked_in)
@@ -1344,11 +1387,15 @@ void* dxm_host_alloc(uint64_t bytes) {
     fail(-3, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
     return nullptr;
   }
+  note_locked(p, bytes);
   return p;
 }
 
 int dxm_host_free(void* p) {
-  if (p) HIP_TRY(hipHostFree(p));
+  if (p) {
+    forget_locked(p);
+    HIP_TRY(hipHostFree(p));
+  }
   return 0;
 }
 
@@ -1820,6 +1867,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
   else if (k == "tune_verbose") m->opt_tune_verbose = on;
   else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;
+  else if (k == "query_foreign_pointers") g_query_foreign.store(on ? 1 : 0);   // process-wide
   else if (k == "packed_min_points") {
     if (!(value >= 0 && value <= 1e12)) return fail(-1, "packed_min_points must be >= 0");
     m->opt_packed_min_points = (int64_t)value;
@@ -1861,11 +1909,15 @@ int dxm_host_register(void* p, uint64_t bytes) {
   if (!p || bytes == 0) return fail(-1, "null / empty host range");
   hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
   if (e != hipSuccess) return fail(-3, "hipHostRegister(%p, %llu) failed: %s", p, (unsigned long long)bytes, hipGetErrorString(e));
+  note_locked(p, bytes);
   return 0;
 }
 
 int dxm_host_unregister(void* p) {
-  if (p) HIP_TRY(hipHostUnregister(p));
+  if (p) {
+    forget_locked(p);
+    HIP_TRY(hipHostUnregister(p));
+  }
   return 0;
 }
 

@@ -42,6 +42,40 @@ def _as_c(a, shape=None) -> np.ndarray:
     return a
 
 
+class _Reaper:
+    """Drops the last reference to large arrays on a helper thread.
+
+    ``integrate`` keeps the caller's gradient array as the gradient of the final state (no copy), so the array of the
+    PREVIOUS call dies inside the next ``integrate`` -- and ``QuadratureMap.update`` builds a new one per call
+    (``quadrature_map.py:304-313``): freeing 480 MB (1e7 points) is a 17 ms ``munmap`` (28 ms without transparent huge
+    pages) on the calling thread, more than half of what the whole PCIe-bound call takes
+    (``profiles/r03_hostpath_fresh_array.md``).  The array is handed to this thread when the call that replaced it
+    returns: the free then runs beside whatever the caller does next (a ``munmap`` running beside the chunk pipeline
+    itself slows that by 10-15 ms: it was tried)."""
+
+    def __init__(self):
+        self._q = None
+
+    def drop(self, obj):
+        if obj is None or getattr(obj, "nbytes", 0) < (8 << 20):
+            return
+        if self._q is None:
+            import queue
+            import threading
+
+            self._q = queue.SimpleQueue()
+            threading.Thread(target=self._run, name="dxm-array-reaper", daemon=True).start()
+        self._q.put(obj)
+
+    def _run(self):
+        while True:
+            item = self._q.get()
+            del item   # the munmap happens here
+
+
+_reaper = _Reaper()
+
+
 class LazyISV(np.lib.mixins.NDArrayOperatorsMixin):
     """The ``isv`` array of ``integrate`` -- ``(N, sum isv)``, the ``_hcat_mixed`` of ``jaxmat.py:227-229`` --
     fetched from the device on first use.  Internal state variables are consumed when an increment has
@@ -404,8 +438,13 @@ class HIPMaterial:
     def _advance(self):
         self._chk(self._lib.dxm_advance(self._require()))
         # a bound gradient / flux array is overwritten by the next update: the s0 mirrors keep their own copies then
+        old = (self._grad[0], self._flux[0])
         self._grad[0] = self._grad[1].copy() if "gradient" in self._bound else self._grad[1]
         self._flux[0] = self._flux[1].copy() if "flux" in self._bound else self._flux[1]
+        for a in old:   # the mirrors of the increment before: freed off this thread
+            if a is not self._grad[0] and a is not self._flux[0] and not any(a is b for b in self._flux_buf):
+                _reaper.drop(a)
+        del old, a
 
     def _revert(self):
         self._chk(self._lib.dxm_revert(self._require()))
@@ -437,6 +476,8 @@ class HIPMaterial:
             self._ensure_outputs(isv=eager)
             flux = self._next_flux_buffer()
             st = Stats()
+            old = self._grad[1]
+            self._grad[1] = g
         timer_name = "jaxmat: Constitutive update" if self._warm else "jaxmat: First pass (includes jit compilation)"
         self._warm = True
         with _Timer(timer_name):
@@ -450,10 +491,13 @@ class HIPMaterial:
                 warnings.warn(
                     f"local Newton did not converge at {rc} quadrature points", RuntimeWarning
                 )
-            self._grad[1] = g
             self._flux[1] = flux
             self._serial += 1
             isv = self._out_isv if eager else LazyISV(self, (self._n, self._info.n_isv_total))
+            # the gradient array of the previous call: released off this thread, after the transfers of this call
+            if old is not g and old is not self._grad[0]:
+                _reaper.drop(old)
+            del old
         return flux, isv, self._out_ct
 
     def _fetch_isv(self):
