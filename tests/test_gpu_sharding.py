@@ -33,7 +33,7 @@ def _worker(rank, world, port, n, law, q):
 
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.jaxmat import JAXMaterial
-    from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p
+    from dolfinx_materials_amd.sharding import ShardPlan, allgather_rows, allgather_rows_p2p, allgather_tangent
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -43,8 +43,10 @@ def _worker(rank, world, port, n, law, q):
         lo, hi = plan.range(rank)
         sig0 = SIG0_LIN if law == "linear" else SIG0_V
         hard = jm.LinearHardening(SIG0_LIN, H_LIN) if law == "linear" else jm.VoceHardening(SIG0_V, SIGU_V, B_V)
-        mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard), device=0)
+        beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard)
+        mat, cmat = JAXMaterial(beh, device=0), JAXMaterial(beh, device=0, tangent_layout="coef")
         mat.set_data_manager(hi - lo)
+        cmat.set_data_manager(hi - lo)
         out = []
         for eps in j2_history(n, seed=77, sig0=sig0):  # same global batch on every rank; each takes its block
             sig, isv, ct = mat.integrate(eps[lo:hi])
@@ -53,33 +55,41 @@ def _worker(rank, world, port, n, law, q):
             g_ct = allgather_rows(torch.from_numpy(np.array(ct).reshape(-1, 36)), plan)
             g_isv = allgather_rows_p2p(torch.from_numpy(np.array(isv)), plan)
             assert torch.equal(g_ct, allgather_rows_p2p(torch.from_numpy(np.array(ct).reshape(-1, 36)), plan))
+            # the third schedule: the nine coefficients per point on the wire, blocks rebuilt on every rank
+            _, _, coef = cmat.integrate(eps[lo:hi])
+            for p2p in (False, True):
+                g_ct9 = allgather_tangent(torch.from_numpy(np.array(coef)), plan, p2p=p2p)
+                assert (g_ct9 - g_ct).abs().max() <= 1e-15 * g_ct.abs().max()
             out.append((g_sig.numpy(), g_isv.numpy(), g_ct.numpy()))
             mat.data_manager.update()
+            cmat.data_manager.update()
         if rank == 0:
             q.put(out)
         mat.close()
+        cmat.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,law", [(4096, "linear"), (10_001, "voce")])
-def test_two_ranks_with_hipmaterial_per_shard_match_single_process_oracle(gpu_available, n, law):
+@pytest.mark.parametrize("world,n,law", [(2, 4096, "linear"), (2, 10_001, "voce"), (8, 10_003, "voce"), (8, 4096, "linear")])
+def test_ranks_with_hipmaterial_per_shard_match_single_process_oracle(gpu_available, world, n, law):
+    """Two ranks, and the eight of one node with a ragged 8-way plan (10 003 points: blocks of 1251 and 1250), all on
+    GPU 0 of the box: collective, point-to-point schedule with 7 peers and the coefficient gather."""
     if not gpu_available:
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
 
     from oracle import constitutive_np as onp
 
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, law, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    got = q.get(timeout=900)
     for p in procs:
-        p.join(timeout=300)
+        p.join(timeout=900)
         assert p.exitcode == 0
     sig0 = SIG0_LIN if law == "linear" else SIG0_V
     hard = onp.LinearHardening(SIG0_LIN, H_LIN) if law == "linear" else onp.VoceHardening(SIG0_V, SIGU_V, B_V)
@@ -111,6 +121,31 @@ def test_bench_starts_its_own_ranks(gpu_available):
     assert pg["ranks_in_group"] == 2 and pg["ranks_counted_by_all_reduce"] == 2 and pg["launcher"] == "self"
     assert out["gather_inclusive"]["value"] > 0 and out["gather_inclusive"]["p2p_schedule"]["value"] > 0
     assert out["value"] > out["gather_inclusive"]["value"]
+
+
+def test_bench_with_eight_ranks_on_one_gpu_carries_the_cfg3_block(gpu_available):
+    """What an 8-GPU driver runs is `python bench.py --gpus 8`: here the same command in the debug share mode (all ranks on
+    GPU 0, gloo), small batches: eight ranks counted by the all-reduce, the cfg 2 weak-scaling headline with its gather
+    legs, and the `cfg3` block (Voce, its own points per rank) with the three reassembly schedules at >= 10 steps."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--points", "200000",
+                        "--cfg3-points", "25000", "--steps", "6", "--warmup", "2", "--cpu-sample", "100000", "--gather-steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["law"] == "j2_linear" and out["value"] > 0
+    pg = out["process_group"]
+    assert pg["ranks_in_group"] == 8 and pg["ranks_counted_by_all_reduce"] == 8 and pg["launcher"] == "self"
+    c3 = out["cfg3"]
+    assert "error" not in c3 and c3["points_per_gpu"] == 25000 and c3["points_total"] == 200000 and c3["value"] > 0
+    assert "Voce" in c3["workload"] and c3["kernel"].startswith("small_strain_kernel<2")
+    g = c3["gather_inclusive"]
+    assert g["steps"] >= 10 and g["value"] > 0 and g["p2p_schedule"]["value"] > 0 and g["coefficient_gather"]["value"] > 0
+    assert out["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.parametrize("n", [64, 1000, 250_007])

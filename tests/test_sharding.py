@@ -43,6 +43,8 @@ def _worker(rank, world, port, n, q):
         eps = j2_history(n, seed=77)[2]  # same global batch on every rank; each takes its block
         hard = onp.LinearHardening(SIG0_LIN, H_LIN)
         r = onp.j2_update(eps[lo:hi], np.zeros((hi - lo, 6)), np.zeros(hi - lo), E, NU, hard)
+        if hi == lo:   # a rank without points (fewer points than ranks): empty blocks of the right widths
+            r = dict(sig=np.zeros((0, 6)), Ct=np.zeros((0, 6, 6)), plastic=np.zeros(0, dtype=bool), p=np.zeros(0))
         sig = allgather_rows(torch.from_numpy(r["sig"]), plan)
         ct = allgather_rows(torch.from_numpy(r["Ct"].reshape(-1, 36)), plan)
         # the point-to-point schedule must reassemble the very same arrays
@@ -79,18 +81,19 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [64, 101])
-def test_two_rank_update_and_allgather_matches_single_process(n):
-    world = 2
+@pytest.mark.parametrize("world,n", [(2, 64), (2, 101), (8, 64), (8, 10_003), (8, 5)])
+def test_sharded_update_and_allgather_matches_single_process(world, n):
+    """Two ranks and the eight of one node (even, ragged, and fewer points than ranks: some ranks own nothing): the
+    collective, the point-to-point schedule with 7 peers, the in-place forms and the coefficient gather."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    sig, ct = q.get(timeout=120)
+    sig, ct = q.get(timeout=600)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=600)
         assert p.exitcode == 0
     eps = j2_history(n, seed=77)[2]
     ref = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
