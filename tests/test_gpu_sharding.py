@@ -110,7 +110,7 @@ def test_bench_starts_its_own_ranks(gpu_available):
         pytest.skip("no GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--points", "300000",
-                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-other-laws", "--gather-steps", "1"],
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-other-laws", "--gather-steps", "1", "--cfg3-points", "20000"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
