@@ -202,8 +202,8 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
     kernel, is the whole cost when the consumer lives on the host."""
     h = history(n, seed)
 
-    def timed(bind, pageable_dma=False, fresh=False):
-        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
+    def timed(bind, pageable_dma=False, fresh=False, devices=None):
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index, devices=devices)
         m.set_data_manager(n)
         if pageable_dma:
             m.set_option("pageable_dma", 1)
@@ -330,6 +330,18 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
         out.update(cadence_pair())
     except Exception as exc:  # context only
         out["accelerated_update"] = {"error": repr(exc)}
+    # one process, all GPUs of the node: G handles, G chunk pipelines, G PCIe links into the same host arrays
+    try:
+        import torch
+
+        G = torch.cuda.device_count()
+        if G > 1:
+            dt_g = timed(True, fresh=True, devices=list(range(G)))
+            out["devices"] = {"value": round(n / dt_g / 1e6, 2), "unit": "Mpoints/s", "ms_per_call": round(dt_g * 1e3, 3), "gpus": G, "points": n,
+                              "note": "HIPMaterial(behavior, devices=[0..G-1]): contiguous point blocks, one handle and one chunk pipeline per GPU, every "
+                                      "GPU's DMA delivering into its rows of the one bound host array; no collective (new strain array every call)"}
+    except Exception as exc:  # context only
+        out["devices"] = {"error": repr(exc)}
     return out
 
 

@@ -159,7 +159,7 @@ class HIPMaterial:
     """A constitutive behaviour integrated on an MI355X through ``libdxmat.so``."""
 
     def __init__(self, behavior, jit=True, device: int = 0, gradient_name=None, flux_name=None, tangent_layout="full",
-                 lazy_isv=True):
+                 lazy_isv=True, devices=None):
         """``JAXMaterial(behavior, jit=True)`` (``jaxmat.py:144``): ``jit`` is accepted for signature
         compatibility and has no effect -- the kernels are compiled ahead of time (or, for a traced /
         custom hardening law, by hipcc on construction).
@@ -171,7 +171,14 @@ class HIPMaterial:
         ``(N, 9)`` (``conventions.tangent_from_coefficients``; an assembly can use the rank structure directly).
 
         ``lazy_isv=True``: the ``isv`` array ``integrate`` returns is a :class:`LazyISV`, downloaded when it
-        is first looked at; ``False`` downloads it in every call like the reference."""
+        is first looked at; ``False`` downloads it in every call like the reference.
+
+        ``devices=[0, 1, ..., G-1]``: ONE process, G GPUs.  The points are cut into G contiguous blocks
+        (``sharding.ShardPlan``), each block has its own ``dxm_material`` handle with its state resident on its GPU,
+        and a host-buffer ``integrate`` runs the G chunk pipelines side by side, every GPU's DMA delivering straight
+        into its rows of the one host array -- G PCIe links for the PCIe-bound form, no collective, no gather
+        (north_star: "reassemble ... into the dolfinx quadrature Function", i.e. into host memory of one process,
+        ``quadrature_map.py:66-70``).  The device-pointer forms belong to one GPU and raise for such a material."""
         if tangent_layout not in ("full", "sym", "coef"):
             raise ValueError("tangent_layout must be 'full', 'sym' or 'coef'")
         if not isinstance(jit, (bool, type(None))):
@@ -182,7 +189,10 @@ class HIPMaterial:
         self._bound = {}
         self.tangent_layout = tangent_layout
         self.behavior = behavior
-        self.device = int(device)
+        self.devices = [int(d) for d in devices] if devices is not None else [int(device)]
+        if not self.devices:
+            raise ValueError("devices must name at least one GPU")
+        self.device = self.devices[0]
         custom = getattr(behavior, "custom_hardening", None)
         # a user-supplied hardening law lives in its own JIT-compiled copy of the library
         self._lib = _lib.load_custom(custom.expr_R, custom.expr_dR) if custom is not None else _lib.load()
@@ -190,7 +200,8 @@ class HIPMaterial:
         self._gname = gradient_name or behavior.gradient_name
         self._fname = flux_name or behavior.flux_name
         self.material_properties = dict(behavior.flat_properties())  # jaxmat.py:146
-        self._handle = None
+        self._parts = []      # (handle, first point, one past the last point, device): one per GPU
+        self._pool = None
         self._n = 0
         self.data_manager = None
         self.last_stats = None
@@ -261,7 +272,7 @@ class HIPMaterial:
 
     @property
     def kernel_name(self):
-        return self._lib.dxm_kernel_name(self._handle).decode() if self._handle else ""
+        return self._lib.dxm_kernel_name(self._parts[0][0]).decode() if self._parts else ""
 
     # ---- protocol: parameters ----------------------------------------------------------------
     def update_material_property(self, key, value):
@@ -284,39 +295,42 @@ class HIPMaterial:
         value = float(arr[0])
         setattr(obj, parts[-1], value)
         self.material_properties[key] = value
-        if self._handle:
+        if self._parts:
             prm = np.asarray(self.behavior.params(), dtype=np.float64)
-            self._chk(
-                self._lib.dxm_set_params(
-                    self._handle, prm.ctypes.data_as(C.POINTER(C.c_double)), prm.size
-                )
-            )
+            for h, *_ in self._parts:
+                self._chk(self._lib.dxm_set_params(h, prm.ctypes.data_as(C.POINTER(C.c_double)), prm.size))
 
     def set_newton(self, maxit=25, rtol=1e-14):
-        self._chk(self._lib.dxm_set_newton(self._require(), int(maxit), float(rtol)))
+        for h in self._handles():
+            self._chk(self._lib.dxm_set_newton(h, int(maxit), float(rtol)))
 
     # ---- protocol: life cycle ------------------------------------------------------------------
     def set_data_manager(self, ngauss):
         """Allocate device state for ``ngauss`` points (``generic.py:172-174``, ``jaxmat.py:195-197``)."""
         self.close()
         prm = np.asarray(self.behavior.params(), dtype=np.float64)
-        h = self._lib.dxm_create(
-            self.behavior.law,
-            prm.ctypes.data_as(C.POINTER(C.c_double)),
-            prm.size,
-            int(ngauss),
-            self.device,
-        )
-        if not h:
-            raise DxmError(f"dxm_create failed: {_lib.last_error(self._lib)}")
-        self._handle = h
         self._n = int(ngauss)
-        if self.tangent_layout != "full":
-            try:
-                self._chk(self._lib.dxm_set_tangent_layout(h, {"sym": 1, "coef": 2}[self.tangent_layout]))
-            except Exception:
-                self.close()
-                raise
+        # contiguous blocks, one per GPU (the first n % G blocks hold one point more: sharding.ShardPlan.bounds)
+        G = len(self.devices)
+        q, r = divmod(self._n, G)
+        lo = 0
+        try:
+            for k, dev in enumerate(self.devices):
+                hi = lo + q + (1 if k < r else 0)
+                h = self._lib.dxm_create(self.behavior.law, prm.ctypes.data_as(C.POINTER(C.c_double)), prm.size, hi - lo, dev)
+                if not h:
+                    raise DxmError(f"dxm_create failed: {_lib.last_error(self._lib)}")
+                self._parts.append((h, lo, hi, dev))
+                if self.tangent_layout != "full":
+                    self._chk(self._lib.dxm_set_tangent_layout(h, {"sym": 1, "coef": 2}[self.tangent_layout]))
+                lo = hi
+        except Exception:
+            self.close()
+            raise
+        if G > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=G, thread_name_prefix="dxm-device")
         ng, nf = self._info.n_grad, self._info.n_flux
         # host mirrors of the fields that are not device state (gradient and flux of s0 / s1)
         self._grad = [self._initial_gradient(), self._initial_gradient()]
@@ -354,9 +368,12 @@ class HIPMaterial:
     def close(self):
         """Release the device state.  Arrays already returned by ``integrate`` / the state dicts stay
         valid: their page-locked memory is owned by the arrays themselves (``_lib.PinnedArray``)."""
-        if getattr(self, "_handle", None):
-            self._lib.dxm_destroy(self._handle)
-            self._handle = None
+        for h, *_ in getattr(self, "_parts", []):
+            self._lib.dxm_destroy(h)
+        self._parts = []
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         self._unbind()
         for p in getattr(self, "_pinned", {}).values():
             p.release()
@@ -386,32 +403,55 @@ class HIPMaterial:
         self.close()
         return False
 
-    def _require(self):
-        if not self._handle:
+    def _handles(self):
+        """The handle of every block (one per GPU), in point order."""
+        if not self._parts:
             raise DxmError("set_data_manager(ngauss) must be called first")
-        return self._handle
+        return [p[0] for p in self._parts]
+
+    def _require(self):
+        """THE handle: for the calls that belong to one GPU (device pointers, streams, graphs, placement)."""
+        hs = self._handles()
+        if len(hs) > 1:
+            raise DxmError("this call addresses one GPU: not available for a material spread over several devices (devices=[...])")
+        return hs[0]
+
+    @property
+    def _handle(self):
+        return self._parts[0][0] if len(self._parts) == 1 else None
+
+    def _blocks(self, *arrays):
+        """(handle, first point, end, [address of the block's rows in each C-contiguous (N, ...) array | None]) per GPU."""
+        return [(h, lo, hi, [None if a is None else a.ctypes.data + lo * a.strides[0] for a in arrays]) for h, lo, hi, _ in self._parts]
+
+    def _run(self, calls):
+        """Run one callable per block: side by side on the per-GPU threads when there are several."""
+        if len(calls) <= 1 or self._pool is None:
+            return [c() for c in calls]
+        return [f.result() for f in [self._pool.submit(c) for c in calls]]
 
     # ---- protocol: state dictionaries ------------------------------------------------------------
     def _isv_dict(self, which):
-        h = self._require()
+        self._handles()
         out = {}
         for f, (name, dim) in enumerate(self.internal_state_variables.items()):
             a = np.empty((self._n, dim))
-            self._chk(self._lib.dxm_get_state(h, which, f, _ptr(a)))
+            self._run([lambda h=h, ptr=ptrs[0], f=f: self._chk(self._lib.dxm_get_state(h, which, f, ptr))
+                       for h, lo, hi, ptrs in self._blocks(a) if hi > lo])
             out[name] = a
         return out
 
     def get_initial_state_dict(self):
-        self._require()
+        self._handles()
         return {self._gname: self._grad[0], self._fname: self._flux[0], **self._isv_dict(S0)}
 
     def get_final_state_dict(self):
-        self._require()
+        self._handles()
         return {self._gname: self._grad[1], self._fname: self._flux[1], **self._isv_dict(S1)}
 
     def set_initial_state_dict(self, state):
         """``generic.py:200-201`` / ``quadrature_map.py:279,294``: any subset of the fields."""
-        h = self._require()
+        self._handles()
         isv_names = self.internal_state_variable_names
         unknown = [k for k in state if k not in self.variables]
         assert len(unknown) == 0, "Material state contains unknown field to update with."
@@ -425,18 +465,24 @@ class HIPMaterial:
             elif key == "be_bar" and self._info.n_grad == 9:
                 continue  # handled below together with F
             else:
-                self._chk(self._lib.dxm_set_state(h, S0, isv_names.index(key), _ptr(a)))
+                self._set_state(isv_names.index(key), a)
         if self._info.n_grad == 9 and ("be_bar" in state or self._gname in state):
             # the kernel's state is the isochoric Cp^-1 (hidden field 2), rebuilt from (F_n, be_bar_n)
             from .conventions import cp_bar_inv_from_be_bar
 
             be = _as_c(state["be_bar"], (self._n, 6)) if "be_bar" in state else self._isv_dict(S0)["be_bar"]
             cpi, be = cp_bar_inv_from_be_bar(self._grad[0], be)
-            self._chk(self._lib.dxm_set_state(h, S0, 1, _ptr(_as_c(be))))
-            self._chk(self._lib.dxm_set_state(h, S0, 2, _ptr(_as_c(cpi))))
+            self._set_state(1, _as_c(be))
+            self._set_state(2, _as_c(cpi))
+
+    def _set_state(self, field, a):
+        for h, lo, hi, ptrs in self._blocks(a):
+            if hi > lo:
+                self._chk(self._lib.dxm_set_state(h, S0, field, ptrs[0]))
 
     def _advance(self):
-        self._chk(self._lib.dxm_advance(self._require()))
+        for h in self._handles():
+            self._chk(self._lib.dxm_advance(h))
         # a bound gradient / flux array is overwritten by the next update: the s0 mirrors keep their own copies then
         old = (self._grad[0], self._flux[0])
         self._grad[0] = self._grad[1].copy() if "gradient" in self._bound else self._grad[1]
@@ -447,7 +493,8 @@ class HIPMaterial:
         del old, a
 
     def _revert(self):
-        self._chk(self._lib.dxm_revert(self._require()))
+        for h in self._handles():
+            self._chk(self._lib.dxm_revert(h))
         self._grad[1] = self._grad[0]
         self._flux[1] = self._flux[0]
         self._serial += 1   # s1 changed: lazy ISV views refetch
@@ -464,7 +511,7 @@ class HIPMaterial:
         state manager too (``generic.py:185-189``).  The gradient array is kept by reference as
         the s1 gradient mirror.
         """
-        h = self._require()
+        self._handles()
         ng, nf = self._info.n_grad, self._info.n_flux
         # the reference's four timer names (jaxmat.py:209, :215, :218, :223), so that scripts reading
         # timing("jaxmat: ...") keep working when dolfinx is present
@@ -475,18 +522,13 @@ class HIPMaterial:
             eager = not self.lazy_isv
             self._ensure_outputs(isv=eager)
             flux = self._next_flux_buffer()
-            st = Stats()
             old = self._grad[1]
             self._grad[1] = g
         timer_name = "jaxmat: Constitutive update" if self._warm else "jaxmat: First pass (includes jit compilation)"
         self._warm = True
         with _Timer(timer_name):
-            rc = self._lib.dxm_integrate(
-                h, _ptr(g), float(dt), _ptr(flux), _ptr(self._out_isv) if eager else None, _ptr(self._out_ct), C.byref(st)
-            )
+            rc = self._integrate_blocks(self._lib.dxm_integrate, None, g, float(dt), flux, self._out_isv if eager else None)
         with _Timer("jaxmat: jaxmat to dolfinx conversion"):
-            self._chk(rc)
-            self.last_stats = st.as_dict()
             if rc > 0:
                 warnings.warn(
                     f"local Newton did not converge at {rc} quadrature points", RuntimeWarning
@@ -503,8 +545,33 @@ class HIPMaterial:
     def _fetch_isv(self):
         """Download the ISVs of the current s1 (for :class:`LazyISV`)."""
         self._ensure_outputs(isv=True)
-        self._chk(self._lib.dxm_isv_host(self._require(), S1, _ptr(self._out_isv)))
+        self._run([lambda h=h, ptr=ptrs[0]: self._chk(self._lib.dxm_isv_host(h, S1, ptr))
+                   for h, lo, hi, ptrs in self._blocks(self._out_isv) if hi > lo])
         return self._out_isv
+
+    def _integrate_blocks(self, entry, mesh_handle, src, dt, flux, isv):
+        """``dxm_integrate`` (``mesh_handle`` None: every block reads its rows of the gradient array ``src``) or
+        ``dxm_integrate_displacement`` (one block: the whole displacement vector ``src``) per block, side by side over
+        the GPUs, each delivering into its rows of ``flux`` / ``isv`` / the tangent array.  Sets ``last_stats`` (sums over
+        the blocks) and returns the number of points whose local Newton did not converge."""
+        recs = [Stats() for _ in self._parts]
+        calls = []
+        for (h, lo, hi, p), st in zip(self._blocks(src if mesh_handle is None else None, flux, isv, self._out_ct), recs):
+            if mesh_handle is None:
+                calls.append(lambda h=h, p=p, st=st: entry(h, p[0], dt, p[1], p[2], p[3], C.byref(st)))
+            else:
+                calls.append(lambda h=h, p=p, st=st: entry(h, mesh_handle, _ptr(src), dt, p[1], p[2], p[3], C.byref(st)))
+        rcs = self._run(calls)
+        for rc in rcs:
+            self._chk(rc)
+        tot = {"n_points": 0, "n_plastic": 0, "n_not_converged": 0, "n_nan": 0, "max_local_iters": 0}
+        for st in recs:
+            d = st.as_dict()
+            for k in ("n_points", "n_plastic", "n_not_converged", "n_nan"):
+                tot[k] += d[k]
+            tot["max_local_iters"] = max(tot["max_local_iters"], d["max_local_iters"])
+        self.last_stats = tot
+        return sum(rc for rc in rcs if rc > 0)
 
     def _next_flux_buffer(self):
         """Two pinned flux buffers alternate so that the s0 mirror (the flux of the last converged
@@ -524,7 +591,7 @@ class HIPMaterial:
         :class:`~dolfinx_materials_amd.gradient.Tet4Mesh` or :class:`~dolfinx_materials_amd.gradient.SimplexMesh`):
         only ``u`` crosses PCIe on the way in (the step before the path,
         ``quadrature_function.py:45-51``)."""
-        h = self._require()
+        self._require()   # the mesh lives on one GPU
         nf, ng = self._info.n_flux, self._info.n_grad
         u = _as_c(u).reshape(-1)
         if u.size != mesh.displacement_size:
@@ -532,12 +599,7 @@ class HIPMaterial:
         eager = not self.lazy_isv
         self._ensure_outputs(isv=eager)
         flux = self._next_flux_buffer()
-        st = Stats()
-        rc = self._lib.dxm_integrate_displacement(
-            h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(self._out_isv) if eager else None, _ptr(self._out_ct), C.byref(st)
-        )
-        self._chk(rc)
-        self.last_stats = st.as_dict()
+        rc = self._integrate_blocks(self._lib.dxm_integrate_displacement, mesh._handle, u, float(dt), flux, self._out_isv if eager else None)
         if rc > 0:
             warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
         self._flux[1] = flux
@@ -591,7 +653,8 @@ class HIPMaterial:
         """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"packed_transfer"``, ``"packed_min_points"``,
         ``"pageable_dma"``, ``"host_threads"``, ``"max_chunks"``, ``"fused_gradient"``, ``"blocks_per_cu"``,
         ``"tune_max_skip_bytes"``, ``"tune_verbose"``)."""
-        self._chk(self._lib.dxm_set_option(self._require(), name.encode(), float(value)))
+        for h in self._handles():
+            self._chk(self._lib.dxm_set_option(h, name.encode(), float(value)))
 
     def bind_outputs(self, flux=None, tangent=None):
         """Deliver ``integrate`` results straight into caller-owned arrays -- e.g. the ``x.array`` of the flux and
@@ -599,7 +662,7 @@ class HIPMaterial:
         (``quadrature_map.py:331-334``, ``utils.py:136-143``; an identity scatter when the map covers all cells).
         The arrays are page-locked in place (``dxm_host_register``) and become the arrays ``integrate``
         returns; call after ``set_data_manager``.  ``None`` keeps the material-owned buffer."""
-        self._require()
+        self._handles()
         nf, ng = self._info.n_flux, self._info.n_grad
         want = {"flux": (flux, self._n * nf), "tangent": (tangent, int(np.prod(self._ct_shape)))}
         for key, (arr, size) in want.items():
@@ -621,7 +684,7 @@ class HIPMaterial:
         gradient's quadrature Function, which ``Expression.eval(..., values=)`` fills per update: ``integrate`` on
         (a view of) that memory then uploads by DMA instead of staging the array through the library's page-locked
         ring chunk by chunk.  The array must stay alive until ``close()`` / ``set_data_manager``."""
-        self._require()
+        self._handles()
         if gradient is None:
             return
         size = self._n * self._info.n_grad
@@ -642,7 +705,7 @@ class HIPMaterial:
         """Field ``name`` of the final state s1 into the caller's C-contiguous ``(N, dim)`` fp64 array -- internal
         state variables come straight from the device into it (``dxm_get_state``); the flux is the array the last
         ``integrate`` delivered (nothing to do when ``out`` is that memory, i.e. a bound Function)."""
-        h = self._require()
+        self._handles()
         if name not in self.variables:
             raise ValueError(f"unknown field {name!r}")
         dim = max(1, self.variables[name])
@@ -653,7 +716,10 @@ class HIPMaterial:
             if src.ctypes.data != out.ctypes.data:
                 out.reshape(src.shape)[...] = src
         elif self._n:
-            self._chk(self._lib.dxm_get_state(h, S1, self.internal_state_variable_names.index(name), _ptr(out)))
+            f = self.internal_state_variable_names.index(name)
+            rows = out.reshape(self._n, dim)
+            self._run([lambda h=h, ptr=ptrs[0]: self._chk(self._lib.dxm_get_state(h, S1, f, ptr))
+                       for h, lo, hi, ptrs in self._blocks(rows) if hi > lo])
         return out
 
     def _unbind(self, key=None):
