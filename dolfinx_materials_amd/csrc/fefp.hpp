@@ -32,12 +32,21 @@ constexpr int F2_REC = 73;   // record stride: 54 staged doubles per point, padd
                              // so that the owner lanes write conflict-free (18 l mod 32 distinct) and the
                              // point slots of a 32-lane read group land on (almost) disjoint banks
 // Wave-private LDS map (doubles): [out-tile, aliasing the F / PK1 staging | records].  A tangent round handles
-// F2_PPR points: two steps of 7 point slots x 9 columns.
-constexpr int F2_PPR = 14;
-constexpr int F2_NIT = (F2_PPR * 81 + 2 * WAVE - 1) / (2 * WAVE);   // 1 KiB wave stores per round
-constexpr int F2_OUT = F2_NIT * 2 * WAVE;                           // out-tile, padded to whole KiB
+// F2_PPR points in steps of 7 point slots x 9 columns.
+// 16 points per round: a round's 16 x 648 B of tangent start on a 128 B line of the (N, 81) array, so every 1 KiB wave
+// store covers whole lines.  With 14 points per round (the mapping's natural 2 x 7 point slots) the rounds started 112 /
+// 96 / 80 / 64 B past a line and every store instruction straddled two partial lines: an arithmetic-free kernel with this
+// kernel's streams, occupancy and compute gaps runs 1.63 ms per 1e7 points with 16-point rounds against 1.77 with 14
+// (tools/fefp_shape_probe.py, profiles/r03_fefp_shape_probe.md).  The price is a third, mostly idle, step per round
+// (7 + 7 + 2 point slots): 12 instead of 10 tangent steps per tile.
+constexpr int F2_PPR = 16;
+constexpr int F2_STEPS = (F2_PPR + 6) / 7;
+constexpr int F2_NIT = (F2_PPR * 81 + 2 * WAVE - 1) / (2 * WAVE);   // 1 KiB wave stores per round (the last one partial)
+constexpr int F2_OUT = F2_PPR * 81;                                 // out-tile; the copy-out's last, partial KiB reads on into the records
 constexpr int F2_COEF = ((F2_PPR * F2_REC + 1) / 2) * 2;
-constexpr int F2_LDS_PER_WAVE = F2_OUT + F2_COEF;                   // 2176 doubles: 69.6 KB per workgroup, 2 per CU
+constexpr int F2_LDS_PER_WAVE = F2_OUT + F2_COEF;                   // 2464 doubles: 78.8 KB per workgroup, 2 per CU
+static_assert(F2_OUT % 2 == 0 && (F2_NIT * 2 * WAVE - F2_OUT) <= F2_COEF, "16 B aligned records; the over-read stays inside the wave's region");
+static_assert(4 * F2_LDS_PER_WAVE * 8 <= 80 * 1024, "two workgroups per CU");
 static_assert(F2_OUT >= FEFP_STAGE, "the out-tile aliases the F / PK1 staging region");
 static_assert(8 * HEX_FUSED_REC <= F2_COEF, "the 8 cell records of a fused tile live in the coefficient region");
 
@@ -206,13 +215,13 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
 #pragma unroll
         for (int c = 0; c < 6; ++c) g6[c] = stream_load<3>(s0 + (int64_t)(FEFP_SLOT_CPI + c) * ld + gi);
       }
-      wave_lds_order();
+      wave_lds_sync();
       {
         const double* f = stage + lane * 9;
         F[0] = f[0]; F[4] = f[1]; F[8] = f[2]; F[1] = f[3]; F[3] = f[4];
         F[2] = f[5]; F[6] = f[6]; F[5] = f[7]; F[7] = f[8];
       }
-      wave_lds_order();
+      wave_lds_sync();
     } else {
       if constexpr (GRAD == 1) {
         // ---- 1'. one (cell, corner) per lane: node -> wave-private record in the coefficient region
@@ -228,7 +237,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           double2_t* d = reinterpret_cast<double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC + (lane & 7) * 6);
           d[0] = r0; d[1] = r1; d[2] = r2;
         }
-        wave_lds_order();
+        wave_lds_sync();
         {
           const double2_t* rec = reinterpret_cast<const double2_t*>(coef + (lane >> 3) * HEX_FUSED_REC);
           auto node = [&](int m, double* X, double* U) {
@@ -244,7 +253,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
             for (int k = 0; k < 9; ++k) F[k] = 0.0;
           }
         }
-        wave_lds_order();  // the coefficient region is rewritten by the tangent rounds
+        wave_lds_sync();  // the coefficient region is rewritten by the tangent rounds
       } else {
         if (valid) {
           const int64_t cell = (src.point0 + gi) / src.nqp;
@@ -436,7 +445,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
       f[0] = P[0]; f[1] = P[4]; f[2] = P[8]; f[3] = P[1]; f[4] = P[3];
       f[5] = P[2]; f[6] = P[6]; f[7] = P[5]; f[8] = P[7];
     }
-    wave_lds_order();
+    wave_lds_sync();
     if (npts == WAVE) {
       double2_t* gdst = reinterpret_cast<double2_t*>(Pout + base * 9);
 #pragma unroll
@@ -512,9 +521,9 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           rec[45 + t] = gs * G[DXM_SYM(t / 3, t % 3)];
         }
       }
-      wave_lds_order();
+      wave_lds_sync();
 #pragma unroll 1   // (unrolled: no spill, no gain: 1.758 vs 1.755 ms)
-      for (int st = 0; st < F2_PPR / 7; ++st) {
+      for (int st = 0; st < F2_STEPS; ++st) {
         const int ql = st * 7 + ps;                              // point inside the round
         if (lane < 63 && ql < cnt) {
           int ro = F2_OUT + ql * F2_REC;
@@ -549,7 +558,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           for (int r = 0; r < 9; ++r) o[r * 9] = x[r];
         }
       }
-      wave_lds_order();
+      wave_lds_sync();
       {
         int nv = npts - p0;                                      // valid points of this round
         nv = nv < 0 ? 0 : (nv > cnt ? cnt : nv);
@@ -591,7 +600,7 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
           }
         }
       }
-      wave_lds_order();
+      wave_lds_sync();
     }
   }
   // the workgroup reduction borrows the first words of every wave's own region (the tile loop is over)

@@ -148,3 +148,96 @@ extern "C" int stream_mix_state_only_launch(const void* s0, void* s1, int64_t ld
                      (double*)s1, ld, npoints / 64);
   return (int)hipGetLastError();
 }
+
+// FeFp-shaped variant with the kernel's TIME structure: per 64-point tile F (AoS, 288 pairs) + 7 SoA state slots in; a
+// "per-point phase" of `pre` dependent FMAs; 13 SoA slots + PK1 (288 pairs) out; then the 81-entry tangent in rounds of
+// `ppr` points, each round preceded by `per_round` dependent FMAs (the tangent evaluation of the round) and stored as
+// 1 KiB wave stores.  `prefetch` != 0 issues the next tile's loads before this tile's stores.  Residency is capped
+// with dynamic LDS by the launcher (70 KiB -> the FeFp kernel's 2 workgroups per CU).  No arithmetic of the law:
+// what this reaches is the ceiling of the kernel's memory shape + occupancy + compute gaps.
+__device__ __forceinline__ double spin(double x, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) x = __builtin_fma(x, 1.0000001, 1e-9);
+  return x;
+}
+
+// STATE: 0 = SoA slots, 8 B per lane (the shipped layout: 7 read + 13 written streams of 512 B wave accesses);
+//        1 = tile-blocked [tile][slot][64], moved as linear 16 B-per-lane accesses (same bytes, 2 streams);
+//        2 = no state traffic at all (what the other streams reach alone)
+template <bool PREFETCH, int STATE, bool ALIGNED = false>
+__global__ void __launch_bounds__(256) stream_mix_fefp_shape_kernel(const double* __restrict__ F, const double* __restrict__ s0,
+                                                                    double* __restrict__ s1, int64_t ld, double* __restrict__ P,
+                                                                    double* __restrict__ ct, int64_t ntiles, int pre, int per_round, int ppr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double2_t f[5];
+  double st[7];
+  double2_t st2[4];
+  auto load = [&](int64_t t) {
+    const int64_t base = t * 64;
+    const double2_t* f2 = reinterpret_cast<const double2_t*>(F + base * 9);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) f[k] = (k * 64 + lane < 288) ? f2[k * 64 + lane] : double2_t{0.0, 0.0};
+    if constexpr (STATE == 0) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) st[c] = s0[c * ld + base + lane];
+    } else if constexpr (STATE == 1) {
+      const double2_t* b = reinterpret_cast<const double2_t*>(s0 + t * (7 * 64));   // 224 pairs per tile
+#pragma unroll
+      for (int k = 0; k < 4; ++k) st2[k] = (k * 64 + lane < 224) ? b[k * 64 + lane] : double2_t{0.0, 0.0};
+    }
+  };
+  if (PREFETCH && wave < ntiles) load(wave);
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t base = t * 64;
+    if (!PREFETCH) load(t);
+    double2_t acc = f[0] + f[1] + f[2] + f[3] + f[4];
+    if constexpr (STATE == 0) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) acc.x += st[c];
+    } else if constexpr (STATE == 1) {
+      acc += st2[0] + st2[1] + st2[2] + st2[3];
+    }
+    acc.x = spin(acc.x, pre);
+    if (PREFETCH && t + nwaves < ntiles) load(t + nwaves);   // ahead of this tile's stores
+    if constexpr (STATE == 0) {
+#pragma unroll
+      for (int c = 0; c < 13; ++c) s1[c * ld + base + lane] = acc.x;
+    } else if constexpr (STATE == 1) {
+      double2_t* b = reinterpret_cast<double2_t*>(s1 + t * (13 * 64));   // 416 pairs per tile
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        if (k * 64 + lane < 416) b[k * 64 + lane] = acc;
+    }
+    double2_t* p2 = reinterpret_cast<double2_t*>(P + base * 9);
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (k * 64 + lane < 288) __builtin_nontemporal_store(acc, p2 + k * 64 + lane);
+    double2_t* c2 = reinterpret_cast<double2_t*>(ct + base * 81);
+    const int total = 64 * 81 / 2;   // 2592 pairs per tile
+    const int per = ppr * 81 / 2;    // pairs per round (ppr even)
+    for (int o = 0; o < total; o += per) {
+      acc.y = spin(acc.y, per_round);
+      const int end = o + per < total ? o + per : total;
+      if (ppr < 0 || !ALIGNED) {
+        for (int idx = o + lane; idx < end; idx += 64) __builtin_nontemporal_store(acc, c2 + idx);
+      } else {   // every wave store covers one 1 KiB-aligned KiB of the tile's tangent block: partial first / last store per round
+        for (int idx = (o & ~63) + lane; idx < end; idx += 64)
+          if (idx >= o) __builtin_nontemporal_store(acc, c2 + idx);
+      }
+    }
+  }
+}
+
+extern "C" int stream_mix_fefp_shape_launch(const void* F, const void* s0, void* s1, int64_t ld, void* P, void* ct, int64_t npoints,
+                                            int blocks, int lds_bytes, int pre, int per_round, int ppr, int prefetch, int state, void* stream) {
+#define DXM_SHAPE(PF, ST, AL)                                                                                                      \
+  hipLaunchKernelGGL((stream_mix_fefp_shape_kernel<PF, ST, AL>), dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (const double*)F, \
+                     (const double*)s0, (double*)s1, ld, (double*)P, (double*)ct, npoints / 64, pre, per_round, ppr)
+  if (state == 3) { DXM_SHAPE(false, 0, true); }   // SoA state, tangent stores on 1 KiB boundaries
+  else if (prefetch) { if (state == 0) DXM_SHAPE(true, 0, false); else if (state == 1) DXM_SHAPE(true, 1, false); else DXM_SHAPE(true, 2, false); }
+  else               { if (state == 0) DXM_SHAPE(false, 0, false); else if (state == 1) DXM_SHAPE(false, 1, false); else DXM_SHAPE(false, 2, false); }
+#undef DXM_SHAPE
+  return (int)hipGetLastError();
+}
