@@ -339,12 +339,142 @@ def trace(func):
     return R, diff(R)
 
 
+# ----------------------------------------------------------------------------------------------
+# jax: a callable written with jax.numpy (what the reference's users have, tests/test_FeFp_jax.py:14-15) is traced by
+# jax itself -- jax.make_jaxpr(yield_stress)(0.0) -- and its primitives are translated into the node tuples above
+# ----------------------------------------------------------------------------------------------
+_JAX_UNARY = {"exp": "exp", "expm1": "expm1", "log": "log", "log1p": "log1p", "sqrt": "sqrt", "cbrt": "cbrt", "tanh": "tanh",
+              "sinh": "sinh", "cosh": "cosh", "sin": "sin", "cos": "cos", "atan": "atan", "abs": "fabs"}
+_JAX_BINARY = {"add": add, "sub": sub, "mul": mul, "div": div, "pow": power}
+_JAX_COMPARE = {"ge", "gt", "le", "lt"}
+
+
+def from_jaxpr(closed):
+    """Node tuple of a scalar -> scalar ``ClosedJaxpr`` (``jax.make_jaxpr(f)(0.0)``).  Primitives: ``add sub mul div neg
+    exp expm1 log log1p pow integer_pow sqrt rsqrt cbrt tanh sinh cosh sin cos atan abs square max min select_n`` with
+    ``ge gt le lt`` predicates, ``convert_element_type`` / ``copy`` (identities for a scalar) and nested ``pjit`` /
+    ``custom_jvp_call`` bodies.  Only the data model of a jaxpr is used (``jaxpr.invars / constvars / eqns / outvars``,
+    ``eqn.primitive.name / invars / outvars / params``, ``Literal.val``, ``closed.consts``): jax itself is not imported."""
+    jaxpr = getattr(closed, "jaxpr", closed)
+    consts = list(getattr(closed, "consts", ()))
+    if len(jaxpr.invars) != 1 or len(jaxpr.outvars) != 1:
+        raise TypeError("yield_stress must map one scalar (p) to one scalar")
+    return _eval_jaxpr(jaxpr, consts, [VAR])[0]
+
+
+def _scalar_const(v):
+    a = np.asarray(v)
+    if a.size != 1:
+        raise TypeError("a traced yield_stress(p) can only close over scalars")
+    return const(float(a.reshape(())))
+
+
+def _eval_jaxpr(jaxpr, consts, args):
+    env = {}
+
+    def read(v):
+        if hasattr(v, "val"):   # jax.core.Literal
+            return _scalar_const(v.val)
+        return env[v]
+
+    for var, val in zip(jaxpr.constvars, consts):
+        env[var] = _scalar_const(val)
+    for var, val in zip(jaxpr.invars, args):
+        env[var] = val
+    for eqn in jaxpr.eqns:
+        name = eqn.primitive.name
+        ins = [read(v) for v in eqn.invars]
+        if name in _JAX_UNARY:
+            out = fn(_JAX_UNARY[name], ins[0])
+        elif name in _JAX_BINARY:
+            out = _JAX_BINARY[name](ins[0], ins[1])
+        elif name == "neg":
+            out = neg(ins[0])
+        elif name == "integer_pow":
+            out = power(ins[0], const(eqn.params["y"]))
+        elif name == "square":
+            out = mul(ins[0], ins[0])
+        elif name == "rsqrt":
+            out = div(const(1.0), fn("sqrt", ins[0]))
+        elif name == "max":
+            out = select(ins[0], ins[1], ins[0], ins[1])
+        elif name == "min":
+            out = select(ins[1], ins[0], ins[0], ins[1])
+        elif name in _JAX_COMPARE:
+            out = ("cmp", name, ins[0], ins[1])     # consumed by select_n only
+        elif name == "select_n":
+            pred, on_false, on_true = ins
+            if pred[0] != "cmp":
+                raise TypeError("select_n on something that is not a comparison of traced values")
+            _, op, a, b = pred
+            if op == "ge":
+                out = select(a, b, on_true, on_false)
+            elif op == "le":
+                out = select(b, a, on_true, on_false)
+            elif op == "lt":     # a < b  ==  not (a >= b)
+                out = select(a, b, on_false, on_true)
+            else:                # a > b  ==  not (b >= a)
+                out = select(b, a, on_false, on_true)
+        elif name in ("convert_element_type", "copy", "copy_p", "stop_gradient", "reshape", "squeeze", "broadcast_in_dim"):
+            out = ins[0]        # identities for a 0-d value
+        elif name in ("pjit", "closed_call", "core_call", "custom_jvp_call", "custom_vjp_call", "remat", "checkpoint"):
+            inner = eqn.params.get("jaxpr") or eqn.params.get("call_jaxpr") or eqn.params.get("fun_jaxpr")
+            inner_jaxpr = getattr(inner, "jaxpr", inner)
+            outs = _eval_jaxpr(inner_jaxpr, list(getattr(inner, "consts", ())), ins)
+            for var, val in zip(eqn.outvars, outs):
+                env[var] = val
+            continue
+        else:
+            raise TypeError(f"jax primitive '{name}' is not supported inside a traced yield_stress(p); supported: "
+                            f"{', '.join(sorted(list(_JAX_UNARY) + list(_JAX_BINARY) + ['neg', 'integer_pow', 'square', 'rsqrt', 'max', 'min', 'select_n']))}")
+        env[eqn.outvars[0]] = out
+    outs = [read(v) for v in jaxpr.outvars]
+    for o in outs:
+        if o[0] == "cmp":
+            raise TypeError("yield_stress(p) returns a comparison, not a stress")
+    return outs
+
+
+def trace_jax(func):
+    """``(R_node, dR_node)`` of a callable written with ``jax.numpy``; needs jax."""
+    import jax
+
+    prev = jax.config.read("jax_enable_x64") if hasattr(jax.config, "read") else None
+    try:
+        jax.config.update("jax_enable_x64", True)   # closed-over constants and literals in double precision
+        closed = jax.make_jaxpr(func)(0.0)
+    finally:
+        if prev is not None:
+            jax.config.update("jax_enable_x64", prev)
+    R = from_jaxpr(closed)
+    return R, diff(R)
+
+
+def _jax_available():
+    import importlib.util
+
+    return importlib.util.find_spec("jax") is not None
+
+
 class TracedLaw:
     """What the tracer produces: C expressions plus host evaluators (used by tests and for sig0)."""
 
-    def __init__(self, func):
+    def __init__(self, func, nodes=None):
         self.func = func
-        self.R_node, self.dR_node = trace(func)
+        if nodes is not None:
+            self.R_node, self.dR_node = nodes
+            self.how = "given"
+        else:
+            try:
+                self.R_node, self.dR_node = trace(func)
+                self.how = "numpy"
+            except TypeError:
+                # not written with numpy ufuncs and operators: a jax.numpy callable (the reference's usual form) is
+                # traced by jax itself where jax exists
+                if not _jax_available():
+                    raise
+                self.R_node, self.dR_node = trace_jax(func)
+                self.how = "jax"
         self.expr_R, self.expr_dR = emit_c(self.R_node), emit_c(self.dR_node)
         self.sig0 = float(evaluate(self.R_node, 0.0))
         # R(0) = 0 is a legitimate law (a power law rising from zero): the kernels floor their Newton tolerance at
@@ -359,7 +489,8 @@ class TracedLaw:
             direct = None
         if direct is not None:
             mine = evaluate(self.R_node, pts)
-            if not np.allclose(mine, direct, rtol=1e-12, atol=0.0):
+            # (a jax callable evaluates in single precision unless jax_enable_x64 is set)
+            if not np.allclose(mine, direct, rtol=1e-12 if self.how != "jax" else 1e-5, atol=0.0):
                 raise ValueError("the traced expression does not reproduce yield_stress(p) on sample points "
                                  "(value-dependent Python control flow cannot be traced)")
         slope = evaluate(self.dR_node, pts)

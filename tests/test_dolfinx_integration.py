@@ -18,10 +18,13 @@ pytestmark = pytest.mark.gpu
 E, NU, SIG0, H = 70e3, 0.3, 250.0, 5e3
 
 
-def _setup(n=3, deg_quad=2):
+def _setup(n=3, deg_quad=2, accelerated=False):
     import ufl
     from dolfinx import fem, mesh
-    from dolfinx_materials.quadrature_map import QuadratureMap
+    if accelerated:   # the third import swap of INTEGRATION.md section 1
+        from dolfinx_materials_amd.quadrature_map import QuadratureMap
+    else:
+        from dolfinx_materials.quadrature_map import QuadratureMap
     from dolfinx_materials.utils import symmetric_tensor_to_vector
     from mpi4py import MPI
 
@@ -38,10 +41,11 @@ def _setup(n=3, deg_quad=2):
     return domain, V, u, material, qmap, strain
 
 
-def test_update_fills_the_quadrature_functions_with_the_oracle_result():
+@pytest.mark.parametrize("accelerated", [False, True])
+def test_update_fills_the_quadrature_functions_with_the_oracle_result(accelerated):
     from oracle import constitutive_np as onp
 
-    domain, V, u, material, qmap, _ = _setup()
+    domain, V, u, material, qmap, _ = _setup(accelerated=accelerated)
     rng = np.random.default_rng(0)
     A = 4e-3 * rng.standard_normal((3, 3))
     x = V.tabulate_dof_coordinates()
@@ -59,12 +63,47 @@ def test_update_fills_the_quadrature_functions_with_the_oracle_result():
     assert np.abs(qmap.internal_state_variables["p"].x.array - ref["p"]).max() < 1e-12
 
 
-def test_snes_solve_reaches_the_closed_form_uniaxial_answer():
+def test_accelerated_quadrature_map_is_the_reference_class_with_three_methods_replaced():
+    """`dolfinx_materials_amd.quadrature_map.QuadratureMap`: same constructor, same attributes and forms; after the same
+    displacement history its Functions hold bit for bit what the reference class leaves in its own, the flux and
+    `jacobian_flatten` memory is the material's (page-locked) output, the gradient Function's memory its input."""
+    from dolfinx_materials.quadrature_map import QuadratureMap as Reference
+
+    from dolfinx_materials_amd.quadrature_map import AcceleratedUpdate, QuadratureMap
+
+    assert issubclass(QuadratureMap, Reference) and issubclass(QuadratureMap, AcceleratedUpdate)
+    ref = _setup(accelerated=False)
+    acc = _setup(accelerated=True)
+    rng = np.random.default_rng(3)
+    x = ref[1].tabulate_dof_coordinates()
+    for step in range(3):
+        A = (2e-3 + 2e-3 * step) * rng.standard_normal((3, 3))
+        for domain, V, u, material, qmap, _ in (ref, acc):
+            u.x.array[:] = (x @ A.T).reshape(-1)
+            qmap.update()
+            qmap.update()
+        for name in ("stress",):
+            assert np.array_equal(ref[4].fluxes[name].x.array, acc[4].fluxes[name].x.array)
+        assert np.array_equal(ref[4].jacobian_flatten.x.array, acc[4].jacobian_flatten.x.array)
+        for domain, V, u, material, qmap, _ in (ref, acc):
+            qmap.advance()
+        for name in ("p", "epsp"):
+            assert np.array_equal(ref[4].internal_state_variables[name].x.array, acc[4].internal_state_variables[name].x.array)
+    m, q = acc[3], acc[4]
+    assert set(m._bound) == {"flux", "tangent", "gradient"}
+    assert m._bound["flux"].ctypes.data == q.fluxes["stress"].x.array.ctypes.data
+    assert m._bound["tangent"].ctypes.data == q.jacobian_flatten.x.array.ctypes.data
+    assert m._bound["gradient"].ctypes.data == q.gradients["strain"].function.x.array.ctypes.data
+    q.close()
+
+
+@pytest.mark.parametrize("accelerated", [False, True])
+def test_snes_solve_reaches_the_closed_form_uniaxial_answer(accelerated):
     import ufl
     from dolfinx import fem
     from dolfinx_materials.solvers import NonlinearMaterialProblem
 
-    domain, V, u, material, qmap, strain = _setup(n=3)
+    domain, V, u, material, qmap, strain = _setup(n=3, accelerated=accelerated)
     du, v = ufl.TrialFunction(V), ufl.TestFunction(V)
     sig = qmap.fluxes["stress"]
     Res = ufl.dot(sig, strain(v)) * qmap.dx
