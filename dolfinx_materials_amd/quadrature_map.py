@@ -28,8 +28,8 @@ With a material that offers none of this (any duck-typed ``Material``: the oracl
 ``generic.Material`` subclass) the same methods fall back to plain row copies and host-side NaN checks; results are
 identical either way (``tests/test_quadrature_map.py``, ``tests/test_gpu_quadrature_map.py``).
 
-``QuadratureMap`` below is ``type("QuadratureMap", (AcceleratedUpdate, dolfinx_materials.quadrature_map.QuadratureMap), {})``
-when the reference package imports (the third import swap of INTEGRATION.md section 1);
+``QuadratureMap`` below is ``accelerate(dolfinx_materials.quadrature_map.QuadratureMap)`` -- ``type("QuadratureMap",
+(AcceleratedUpdate, reference), {})`` -- when the reference package imports (the third import swap of INTEGRATION.md section 1);
 ``field_map.QuadratureFieldMap`` is the same mixin over a dolfinx-free stand-in base, which is how this code path is
 tested where dolfinx is absent.
 """
@@ -261,6 +261,16 @@ class AcceleratedUpdate:
                 self._put(funs[name], dim, final[name])
 
 
+def accelerate(reference_class):
+    """``reference_class`` (``dolfinx_materials.quadrature_map.QuadratureMap``) with ``update() / advance() /
+    initialize_state()`` of :class:`AcceleratedUpdate`: same constructor, same attributes, same forms."""
+    return type("QuadratureMap", (AcceleratedUpdate, reference_class), {
+        "__doc__": "``dolfinx_materials.quadrature_map.QuadratureMap`` with ``update() / advance() / initialize_state()`` of "
+                   ":class:`dolfinx_materials_amd.quadrature_map.AcceleratedUpdate`.",
+        "__module__": __name__,
+    })
+
+
 def _reference_class():
     try:
         from dolfinx_materials.quadrature_map import QuadratureMap as reference
@@ -271,11 +281,7 @@ def _reference_class():
 
 _reference = _reference_class()
 if _reference is not None:
-    QuadratureMap = type("QuadratureMap", (AcceleratedUpdate, _reference), {
-        "__doc__": "``dolfinx_materials.quadrature_map.QuadratureMap`` (same constructor, same attributes, same forms) with "
-                   "``update() / advance() / initialize_state()`` of :class:`AcceleratedUpdate`.",
-        "__module__": __name__,
-    })
+    QuadratureMap = accelerate(_reference)
 else:
     class QuadratureMap:   # pragma: no cover - only reached where dolfinx is absent
         """Placeholder where the reference package does not import: constructing it says what is missing."""

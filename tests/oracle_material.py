@@ -27,6 +27,10 @@ class OracleJ2Material:
     internal_state_variables = {"p": 1, "epsp": 6}
     tangent_blocks = {("stress", "strain"): (6, 6)}
     rotation_matrix = None
+    material_properties = {}     # iterated by the reference's QuadratureMap.__init__ (quadrature_map.py:160-172)
+
+    def update_material_property(self, name, value):
+        raise AssertionError("no material property to update")
 
     @property
     def variables(self):

@@ -161,3 +161,32 @@ def test_device_gradient_through_the_map_equals_the_host_gradient_route():
     for q in maps:
         q.close()
         q.material.close()
+
+
+@pytest.mark.parametrize("case", ["full", "subset"])
+def test_engine_behind_the_map_reproduces_the_reference_classs_fields(case):
+    """``tests/golden/quadrature_map_ref.npz``: what the REFERENCE's own ``QuadratureMap.update() / advance()`` left in
+    its quadrature Functions (generated from ``/root/reference`` over numpy-backed doubles of dolfinx, with the oracle law
+    behind it); the accelerated map with the HIP kernels behind it must land every field in the same place, to 1e-12."""
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quadrature_map_ref.npz"))
+    ncell, nqp = int(gold["ncell"]), int(gold["nqp"])
+    cells = gold["subset"] if case == "subset" else None
+    beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=float(gold["E"]), nu=float(gold["nu"])),
+                                        jm.VoceHardening(float(gold["sig0"]), float(gold["sigu"]), float(gold["b"])))
+    now = {"k": 0}
+    q = QuadratureFieldMap(ncell, nqp, JAXMaterial(beh), cells=cells)
+    q.isv_every_update = True
+    q.register_gradient("strain", lambda c: gold["strains"][now["k"]].reshape(ncell, nqp * 6)[c])
+    scale = {"stress": float(gold["sig0"]), "jacobian": float(gold["E"]), "p": 1e-2, "epsp": 1e-2}
+    for i, (op, k) in enumerate(zip(gold["ops"], gold["strain_of_op"])):
+        if op == "update":
+            now["k"] = int(k)
+            q.update()
+        else:
+            q.advance()
+        for name in scale:
+            assert np.abs(_fields(q)[name] - gold[f"{case}_{i}_{name}"]).max() <= 1e-12 * scale[name], (case, i, op, name)
+    q.close()
+    q.material.close()

@@ -1,0 +1,98 @@
+"""The caller of the hot path, pinned by the reference's own code.
+
+``tests/golden/quadrature_map_ref.npz`` holds the quadrature fields that the REFERENCE's ``QuadratureMap`` leaves after a
+sequence of ``update()`` / ``advance()`` calls (generated in the build container by
+``tests/golden/make_quadrature_map_golden.py``: the reference's ``quadrature_map.py`` / ``quadrature_function.py`` /
+``utils.py`` run unmodified over numpy-backed doubles of what they call into dolfinx, ``oracle/dolfinx_doubles.py``).
+
+* everywhere: ``field_map.QuadratureFieldMap`` (= ``quadrature_map.AcceleratedUpdate`` over the stand-in base) with the same
+  oracle material replays the sequence and must reproduce the fixture bit for bit -- maps over all cells and over a subset;
+* where ``/root/reference`` exists: ``quadrature_map.accelerate(reference.QuadratureMap)`` -- the class a dolfinx user gets --
+  is built over the real class and must agree with the real class after every operation, also with a material that offers
+  the engine's optional members (bound outputs, page-locked inputs, status record)."""
+import os
+
+import numpy as np
+import pytest
+
+from dolfinx_materials_amd.field_map import QuadratureFieldMap
+from dolfinx_materials_amd.quadrature_map import AcceleratedUpdate, accelerate
+from oracle import constitutive_np as onp
+from oracle.ref_import import REFERENCE_ROOT, reference_available
+from oracle_material import OracleJ2Material
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quadrature_map_ref.npz"))
+NCELL, NQP = int(GOLD["ncell"]), int(GOLD["nqp"])
+FIELDS = ("stress", "jacobian", "p", "epsp")
+
+
+def _material():
+    return OracleJ2Material(float(GOLD["E"]), float(GOLD["nu"]), onp.VoceHardening(float(GOLD["sig0"]), float(GOLD["sigu"]), float(GOLD["b"])))
+
+
+def _fields(q):
+    return {"stress": q.fluxes["stress"].x.array, "jacobian": q.jacobian_flatten.x.array, "p": q.internal_state_variables["p"].x.array,
+            "epsp": q.internal_state_variables["epsp"].x.array}
+
+
+@pytest.mark.parametrize("case", ["full", "subset"])
+def test_field_map_reproduces_what_the_reference_class_left_in_its_functions(case):
+    cells = GOLD["subset"] if case == "subset" else None
+    now = {"k": 0}
+    q = QuadratureFieldMap(NCELL, NQP, _material(), cells=cells)
+    q.isv_every_update = True   # the reference writes the internal state variables in every update (quadrature_map.py:332)
+    q.register_gradient("strain", lambda c: GOLD["strains"][now["k"]].reshape(NCELL, NQP * 6)[c])
+    for i, (op, k) in enumerate(zip(GOLD["ops"], GOLD["strain_of_op"])):
+        if op == "update":
+            now["k"] = int(k)
+            q.update()
+        else:
+            q.advance()
+        for name in FIELDS:
+            assert np.array_equal(_fields(q)[name], GOLD[f"{case}_{i}_{name}"]), (case, i, op, name)
+
+
+@pytest.mark.skipif(not reference_available(), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("case,engine_like", [("full", False), ("subset", False), ("full", True), ("subset", True)])
+def test_accelerated_class_over_the_real_reference_class_equals_the_real_class(case, engine_like):
+    from oracle import dolfinx_doubles as dd
+    from test_quadrature_map import EngineLikeMaterial
+
+    cells = GOLD["subset"] if case == "subset" else None
+    with dd.installed(REFERENCE_ROOT) as qm:
+        Accelerated = accelerate(qm.QuadratureMap)
+        assert issubclass(Accelerated, qm.QuadratureMap) and Accelerated.update is AcceleratedUpdate.update
+        assert Accelerated.advance is AcceleratedUpdate.advance and Accelerated.initialize_state is AcceleratedUpdate.initialize_state
+        assert Accelerated.register_gradient is qm.QuadratureMap.register_gradient and Accelerated.derivative is qm.QuadratureMap.derivative
+        now = {"k": 0}
+        maps = []
+        for cls in (qm.QuadratureMap, Accelerated):
+            mat = _material()
+            if engine_like and cls is Accelerated:
+                mat = EngineLikeMaterial(float(GOLD["E"]), float(GOLD["nu"]), onp.VoceHardening(float(GOLD["sig0"]), float(GOLD["sigu"]), float(GOLD["b"])))
+            q = cls(dd.Mesh(NCELL, "hexahedron", 3), 2, mat, cells=cells)
+            q.register_gradient("strain", dd.PointwiseExpression(lambda c: GOLD["strains"][now["k"]].reshape(NCELL, NQP * 6)[c], 6))
+            maps.append(q)
+        ref, acc = maps
+        acc.isv_every_update = True
+        for i, (op, k) in enumerate(zip(GOLD["ops"], GOLD["strain_of_op"])):
+            for q in maps:
+                if op == "update":
+                    now["k"] = int(k)
+                    q.update()
+                else:
+                    q.advance()
+            for name in FIELDS:
+                assert np.array_equal(_fields(acc)[name], _fields(ref)[name]), (i, op, name)
+                assert np.array_equal(_fields(ref)[name], GOLD[f"{case}_{i}_{name}"])   # the fixture is what the real class does
+        if engine_like and case == "full":
+            assert acc._accel_plan().bound and "bind_outputs" in acc.material.calls and "bind_inputs" in acc.material.calls
+            # the gradient went straight into the reference's QuadratureExpression Function (Expression.eval(values=...))
+            assert np.array_equal(acc.gradients["strain"].function.x.array, GOLD["strains"][int(GOLD["strain_of_op"][-2])].ravel())
+        # update_initial_state stays the reference's method and feeds the accelerated update
+        for q in maps:
+            q.update_initial_state("p", 1e-3)
+            now["k"] = 2
+            q.update()
+        assert np.array_equal(_fields(acc)["stress"], _fields(ref)["stress"]) and np.array_equal(_fields(acc)["jacobian"], _fields(ref)["jacobian"])
+        acc.close()
