@@ -320,10 +320,11 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
            "with_option_pageable_dma": {"value": round(n / dt_fast / 1e6, 2), "ms_per_call": round(dt_fast * 1e3, 3),
                                         "note": "the pageable strain array handed to the runtime's own transfer path instead of the library's page-locked "
                                                 "staging ring: faster, but exposed to the runtime's cache of on-the-fly page-locked ranges (DESIGN.md section 1)"},
-           "pcie_bytes_per_point": {"h2d_strain": 48, "d2h_stress": 48, "d2h_tangent_coefficients": 72, "isv": "on demand (56)"},
-           "GBs_over_pcie": round(n * 168 / dt / 1e9, 1),
-           "note": "host buffers in and out through dxm_integrate: chunk-pipelined on two streams, the 9 coefficients of the tangent moved "
-                   "and the (N,6,6) block rebuilt by 16 host threads with the kernel's own expression, bit-identical to the full download; "
+           "pcie_bytes_per_point": {"h2d_strain": 48, "d2h_stress": 48, "d2h_tangent_coefficients": 32, "isv": "on demand (56)"},
+           "GBs_over_pcie": round(n * 128 / dt / 1e9, 1),
+           "note": "host buffers in and out through dxm_integrate: chunk-pipelined on two streams; of the tangent only (c1, c2, c3, w) cross PCIe -- the flow "
+                   "direction is dev(stress) w by construction of the kernel -- and the (N,6,6) block is rebuilt by 16 host threads with the kernel's own "
+                   "expression, bit-identical to the full download (what bounds the call now is those threads writing 288 B/point into host memory); "
                    "`value`: results delivered into caller-owned arrays (bind_outputs: the x.array of the quadrature Functions), the pageable strain array "
                    "staged through a page-locked ring by the worker threads (no DMA from or into pageable memory)"}
     try:

@@ -132,6 +132,16 @@ __device__ __forceinline__ void store_block_stats(BlockStats* out, unsigned long
   }
 }
 
+// 1/x from the hardware approximation plus two Newton-Raphson steps (<= 1 ulp for normal x):
+// 5 instructions instead of the ~14 of the IEEE division sequence; used where the operand is a
+// well-scaled positive quantity (J, |dev be|, Jacobian determinants, stress ratios).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // Cache policy of the streaming accesses, fixed at build time by the bits of DXM_NT:

@@ -142,6 +142,37 @@ static void expand_coef_tangent(const double* __restrict__ s, double* __restrict
   }
 }
 
+// The same block from 32 B/point: (c1, c2, c3, w) and the STRESS, which crosses PCIe anyway.  The kernel builds its
+// tangent with n = dev(sigma) w (small_strain.hpp, steps 3 and 5); the three lines that form n are repeated here with
+// every operation individually rounded (no contraction), so the block is the kernel's, bit for bit.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("fma")))
+#endif
+static void expand_pack4_tangent(const double* __restrict__ sg, const double* __restrict__ cw, double* __restrict__ d, int64_t n) {
+#pragma clang fp contract(off)
+  const bool aligned = (reinterpret_cast<uintptr_t>(d) & 15) == 0;
+  for (int64_t p = 0; p < n; ++p, sg += 6, cw += 4, d += 36) {
+    const double k1 = cw[0], k2 = cw[1], k3 = cw[2], w = cw[3];
+    const double third = (sg[0] + sg[1] + sg[2]) * SS_THIRD;
+    double nv[6];
+    nv[0] = (sg[0] - third) * w; nv[1] = (sg[1] - third) * w; nv[2] = (sg[2] - third) * w;
+    nv[3] = sg[3] * w; nv[4] = sg[4] * w; nv[5] = sg[5] * w;
+    double o[36];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
+        const double nij = nv[i] * nv[j];
+        o[i * 6 + j] = __builtin_fma(k3, nij, t0);
+      }
+    if (aligned) {
+      for (int k = 0; k < 36; k += 2)
+        __builtin_nontemporal_store(double2_t{o[k], o[k + 1]}, reinterpret_cast<double2_t*>(d + k));
+    } else {
+      for (int k = 0; k < 36; ++k) d[k] = o[k];
+    }
+  }
+}
+
 // FeFp: the 9x9 block from its 54 building blocks (fefp.hpp step 6):
 //   A[row=(i,J)][col=(k,L)] = Vc[col] Fi[J][i] + Wc[col] Sr[row] + U[i][L] Fi[J][k] + (i==k) g[L][J]
 // evaluated as the kernel evaluates it (one product, three fused multiply-adds, the Kronecker delta as a 0/1 factor).
@@ -177,8 +208,9 @@ static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, do
 
 // A few persistent worker threads per handle (created on the first host-path call that needs them).
 struct HostPool {
-  // stride 9: J2 coefficients -> 6x6, 54: FeFp building blocks -> 9x9, 0: constant block, -1: plain copy of n BYTES
-  struct Job { const double* src; double* dst; int64_t n; int stride; int tag; };
+  // stride 9: J2 coefficients -> 6x6, 4: (c1, c2, c3, w) + the stress rows `aux` -> 6x6, 54: FeFp building blocks -> 9x9,
+  // 0: constant block, -1: plain copy of n BYTES
+  struct Job { const double* src; double* dst; int64_t n; int stride; int tag; const double* aux; };
   std::vector<std::thread> threads;
   std::mutex mu;
   std::condition_variable cv, cv_done, cv_copy;
@@ -205,6 +237,7 @@ struct HostPool {
         queue.pop_front();
       }
       if (j.stride == 9) expand_coef_tangent(j.src, j.dst, j.n);
+      else if (j.stride == 4) expand_pack4_tangent(j.aux, j.src, j.dst, j.n);
       else if (j.stride == 54) expand_fefp_tangent(j.src, j.dst, j.n);
       else if (j.stride == -1) memcpy(j.dst, j.src, (size_t)j.n);
       else fill_const_tangent(j.src, j.dst, j.n);
@@ -216,12 +249,12 @@ struct HostPool {
     }
   }
   // rows [0, n) of one chunk, cut into one piece per thread
-  void submit(const double* src, double* dst, int64_t n, int stride) {
+  void submit(const double* src, double* dst, int64_t n, int stride, const double* aux = nullptr) {
     const int64_t pieces = (int64_t)threads.size();
     const int64_t per = (n + pieces - 1) / pieces;
     std::lock_guard<std::mutex> lk(mu);
     for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * stride, dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0});
+      queue.push_back(Job{src + o * stride, dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0, aux ? aux + o * 6 : nullptr});
       ++pending;
     }
     cv.notify_all();
@@ -243,7 +276,7 @@ struct HostPool {
       std::lock_guard<std::mutex> lk(mu);
       for (size_t o = 0; o < bytes; o += per) {
         queue.push_front(Job{reinterpret_cast<const double*>(static_cast<const char*>(src) + o),
-                             reinterpret_cast<double*>(static_cast<char*>(dst) + o), (int64_t)std::min(per, bytes - o), -1, tag});
+                             reinterpret_cast<double*>(static_cast<char*>(dst) + o), (int64_t)std::min(per, bytes - o), -1, tag, nullptr});
         ++pending_copy[tag];
       }
     }
@@ -293,7 +326,8 @@ struct dxm_material {
   int parity = 0;
   // options (dxm_set_option)
   bool opt_pipeline = true;               // chunk-pipelined host path
-  bool opt_packed_transfer = true;        // host path: move the 9 tangent coefficients, rebuild the 6x6 block on the host
+  int opt_packed_transfer = 2;            // host path: 0 move the full tangent; 1 its 9 coefficients (J2) / 54 building blocks (FeFp), block rebuilt
+                                          // on the host; 2 (small strain) only (c1, c2, c3, w), the direction rebuilt from the stress
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
   bool opt_tune_verbose = false;
@@ -873,14 +907,19 @@ static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64
   const MeshSource none{};
   const MeshSource& src = fused ? *fused : none;
   const int g = fused ? fused->kind : 0;   // where the strain comes from: array / hex8 x 8 / tet4 / Lagrange simplex
+  // J2 kernels: 2.25 KiB of unused dynamic LDS on top of the static 30.1 KiB keep FOUR workgroups (16 waves) per CU.  The
+  // linear-hardening kernel needs 95 VGPRs since the flow direction of the tangent comes from the stress (it was 103):
+  // a fifth wave per SIMD would fit and costs 0.65 % (0.8169 vs 0.8116 / 0.8123 ms per 1e7 points in one process,
+  // profiles/r03_j2_ab_pack4.jsonl); the elastic kernel keeps its five.
+  constexpr int dyn_lds = LAW == LAW_ELASTIC ? 0 : 2304;
 #define DXM_LAUNCH_SS(TL, G)                                                                              \
-  hipLaunchKernelGGL((small_strain_kernel<LAW, TL, G>), dim3(grid), dim3(BLOCK), 0, st, m->prm, cnt, grad, s0, s1, \
+  hipLaunchKernelGGL((small_strain_kernel<LAW, TL, G>), dim3(grid), dim3(BLOCK), dyn_lds, st, m->prm, cnt, grad, s0, s1, \
                      m->ld, flux, ct, bs, src)
 #define DXM_LAUNCH_SS_G(TL) do { if (g == 0) DXM_LAUNCH_SS(TL, 0); else if (g == 1) DXM_LAUNCH_SS(TL, 1); \
                                  else if (g == 2) DXM_LAUNCH_SS(TL, 2); else DXM_LAUNCH_SS(TL, 3); } while (0)
   if (tl == TL_SYM) DXM_LAUNCH_SS_G(TL_SYM);
   else if (tl == TL_FULL) DXM_LAUNCH_SS_G(TL_FULL);
-  else if constexpr (LAW != LAW_ELASTIC) DXM_LAUNCH_SS_G(TL_COEF);
+  else if constexpr (LAW != LAW_ELASTIC) { if (tl == TL_PACK4) DXM_LAUNCH_SS_G(TL_PACK4); else DXM_LAUNCH_SS_G(TL_COEF); }
 #undef DXM_LAUNCH_SS_G
 #undef DXM_LAUNCH_SS
 }
@@ -1165,13 +1204,17 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const bool packed = m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && ct_aos != nullptr && n >= m->opt_packed_min_points;
   const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
   const bool fefp = d.n_grad == 9;
-  const int tl = packed && !constant ? TL_COEF : m->tangent_layout;   // layout of this call's launches
-  const int np = fefp ? FEFP_REC : 9;                                   // doubles per point of the packed form
+  // small strain: (c1, c2, c3, w) only -- the direction n is rebuilt from the stress, which the caller receives in
+  // page-locked memory as part of the same chunk -- else the nine coefficients
+  const bool pack4 = packed && !constant && !fefp && m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
+                     (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux));
+  const int tl = packed && !constant ? (pack4 ? TL_PACK4 : TL_COEF) : m->tangent_layout;   // layout of this call's launches
+  const int np = fefp ? FEFP_REC : (pack4 ? 4 : 9);                     // doubles per point of the packed form
   const int nfull = d.n_flux * d.n_grad;
-  const int nt = tl == TL_COEF ? np : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : nfull);   // doubles per point in d_ct
+  const int nt = (tl == TL_COEF || tl == TL_PACK4) ? np : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : nfull);   // doubles per point in d_ct
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (packed || host_grad) {
-    if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * np, hipHostMallocDefault));
+    if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * (fefp ? FEFP_REC : 9), hipHostMallocDefault));
     if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
       delete m->pool;
       m->pool = new HostPool(m->opt_host_threads);
@@ -1303,7 +1346,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && !constant)
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
-        m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, np);
+        m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, np, pack4 ? flux_aos + o * d.n_flux : nullptr);
         ++submitted;
       }
   }
@@ -1320,7 +1363,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && !constant && c >= submitted) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-      m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, np);
+      m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, np, pack4 ? flux_aos + off * d.n_flux : nullptr);
       submitted = c + 1;
     }
   }
@@ -1863,7 +1906,10 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   const std::string k(name);
   const bool on = value != 0.0;
   if (k == "pipeline") m->opt_pipeline = on;
-  else if (k == "packed_transfer") m->opt_packed_transfer = on;
+  else if (k == "packed_transfer") {
+    if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(-1, "packed_transfer must be 0, 1 or 2");
+    m->opt_packed_transfer = (int)value;
+  }
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
   else if (k == "tune_verbose") m->opt_tune_verbose = on;
   else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;

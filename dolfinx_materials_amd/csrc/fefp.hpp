@@ -81,16 +81,6 @@ __device__ __forceinline__ void mmt(const double* A, const double* B, double* C)
     for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
 }
 
-// 1/x from the hardware approximation plus two Newton-Raphson steps (<= 1 ulp for normal x):
-// 5 instructions instead of the ~14 of the IEEE division sequence; used where the operand is a
-// well-scaled positive quantity (J, |dev be|, Jacobian determinants).
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  return r;
-}
-
 // hardening law and its slope, sharing the exponential
 template <int HARD>
 __device__ __forceinline__ void hardening(const LawParams& prm, double p, double& R, double& dR) {

@@ -84,12 +84,14 @@ __device__ __forceinline__ double2_t tangent_pair(const double* cf, int i, int j
 
 // TL: layout of the tangent output.  TL_FULL the 6x6 block, row-major (what jacobian_flatten holds,
 // quadrature_map.py:83-105); TL_SYM its 21 upper-triangle entries; TL_COEF the 9 coefficients
-// (c1, c2, c3, n[6]) of Ct = c1 1x1 + c2 I + c3 n x n themselves (72 B/point: what the host-buffer form moves
-// over PCIe before rebuilding the block on the host with the same expression, dxmat.hip).
-enum { TL_FULL = 0, TL_SYM = 1, TL_COEF = 2 };
+// (c1, c2, c3, n[6]) of Ct = c1 1x1 + c2 I + c3 n x n themselves (72 B/point); TL_PACK4 only (c1, c2, c3, w): the flow
+// direction is n = dev(sigma) w by definition (below), so a consumer that receives the stress anyway -- the host-buffer
+// form, dxmat.hip::expand_pack4_tangent -- rebuilds n and the block from 32 B/point, bit for bit.
+enum { TL_FULL = 0, TL_SYM = 1, TL_COEF = 2, TL_PACK4 = 3 };
+constexpr double SS_THIRD = 1.0 / 3.0;
 
 template <int LAW, int TL, int GRAD = 0>
-__global__ void __launch_bounds__(BLOCK, 4)  // 4 waves per SIMD; a 5-wave (96 VGPR) build measured 1 % slower
+__global__ void __launch_bounds__(BLOCK, 4)  // 4 waves per SIMD (the launcher pads the LDS of the J2 kernels so that a fifth never fits)
 small_strain_kernel(const LawParams prm, const int64_t n, const double* __restrict__ eps,
                     const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
                     double* __restrict__ sig, double* __restrict__ ct,
@@ -216,7 +218,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
 
     // ---- 3. constitutive update --------------------------------------------------------------
     double c1 = lambda, c2 = 2.0 * mu, c3 = 0.0;
-    double nn[6] = {0, 0, 0, 0, 0, 0};
+    double wn = 0.0;   // n = dev(sigma) wn: the direction the tangent is built with (0 for an elastic point)
     double p_new = p_n;
     if constexpr (LAW != LAW_ELASTIC) {
       // trial elastic strain                                   mfront:52  eel += deto
@@ -256,9 +258,17 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           }
         }
         const double iseq = 1.0 / seq;
+        double nn[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) nn[c] = 1.5 * se[c] * iseq;   // mfront:61
         const double beta = dp * iseq;
+        // The return is radial: dev(sigma) = (1 - 3 mu beta) s_e, so n = 3/2 s_e / seq = dev(sigma) wn with
+        // wn = 3/2 / (seq (1 - 3 mu beta)).  The TANGENT is built with n in that form (step 5), so that whoever holds
+        // the stress and wn holds n, to the bit.
+        {
+          const double rho = 1.0 - 3.0 * mu * beta;
+          wn = rho > 0.0 ? 1.5 * iseq * fast_rcp(rho) : 0.0;
+        }
         const double gamma = 1.0 / (hardening_dR<LAW>(prm, p_n + dp) + 3.0 * mu);
         // Dt = lambda IxI + 2mu Id - 4mu^2 [beta (M - n^n) + gamma n^n]      mfront:66-69
         c1 = lambda + 2.0 * mu * mu * beta;
@@ -303,11 +313,17 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
     stage2[lane * 3 + 0] = double2_t{s[0], s[1]};
     stage2[lane * 3 + 1] = double2_t{s[2], s[3]};
     stage2[lane * 3 + 2] = double2_t{s[4], s[5]};
-    if constexpr (LAW != LAW_ELASTIC) {
+    if constexpr (LAW != LAW_ELASTIC && TL == TL_PACK4) {
+      double2_t* c4 = reinterpret_cast<double2_t*>(coef) + lane * 2;
+      c4[0] = double2_t{c1, c2};
+      c4[1] = double2_t{c3, wn};
+    } else if constexpr (LAW != LAW_ELASTIC) {
       double* cf = coef + lane * 9;
       cf[0] = c1; cf[1] = c2; cf[2] = c3;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) cf[3 + c] = nn[c];
+      // n = dev(sigma) wn, every operation individually rounded (the host rebuilds it with the same three lines)
+      const double third = opaque((s[0] + s[1] + s[2]) * SS_THIRD);
+      cf[3] = (s[0] - third) * wn; cf[4] = (s[1] - third) * wn; cf[5] = (s[2] - third) * wn;
+      cf[6] = s[3] * wn; cf[7] = s[4] * wn; cf[8] = s[5] * wn;
     }
     wave_lds_sync();
 
@@ -323,7 +339,20 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
       }
     }
     // ---- 7. coalesced tangent store: entry pair (i, j..j+1) of point q ---------------------------
-    if constexpr (TL == TL_COEF) {
+    if constexpr (TL == TL_PACK4) {
+      static_assert(LAW != LAW_ELASTIC, "the elastic tangent is a constant: nothing to write");
+      if (npts == WAVE) {   // 64 x 4 doubles: two 1 KiB wave stores
+        double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 4);
+        const double2_t* c4 = reinterpret_cast<const double2_t*>(coef);
+        stream_store<0>(gct + lane, c4[lane]);
+        stream_store<0>(gct + WAVE + lane, c4[WAVE + lane]);
+      } else {
+        double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 4);
+        const double2_t* c4 = reinterpret_cast<const double2_t*>(coef);
+        if (lane < npts * 2) stream_store<0>(gct + lane, c4[lane]);
+        if (WAVE + lane < npts * 2) stream_store<0>(gct + WAVE + lane, c4[WAVE + lane]);
+      }
+    } else if constexpr (TL == TL_COEF) {
       // the staged coefficients as they are: 64 x 9 doubles, contiguous (4.5 KiB per tile)
       static_assert(LAW != LAW_ELASTIC, "the elastic tangent is a constant: nothing to write");
       if (npts == WAVE) {

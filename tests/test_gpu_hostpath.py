@@ -304,3 +304,41 @@ def test_host_path_beyond_one_status_record_per_workgroup_of_a_single_launch():
     seq = np.sqrt(1.5) * 2 * mu * np.linalg.norm(dev, axis=1)
     assert abs(m.last_stats["n_plastic"] - int((seq > SIG0_LIN).sum())) <= int((np.abs(seq - SIG0_LIN) < 1e-9 * SIG0_LIN).sum())
     m.close()
+
+
+@pytest.mark.parametrize("kind,n", [("linear", 40_001), ("voce", 300_001)])
+def test_every_level_of_packed_transfer_delivers_the_same_bits(kind, n):
+    """``packed_transfer`` 2 (default: (c1, c2, c3, w) cross PCIe, 32 B/point, the flow direction is rebuilt from the
+    stress), 1 (the nine coefficients, 72 B/point), 0 (the full block, 288 B/point): identical stress, tangent and state,
+    with own and with bound output arrays; level 2 falls back to level 1 when the caller does not take the stress."""
+    import ctypes as C
+
+    hist = j2_history(n, seed=9, sig0=SIG0_V if kind == "voce" else SIG0_LIN)
+    mats = []
+    for level, bind in ((2, False), (2, True), (1, False), (0, False)):
+        m = _j2(kind)
+        m.set_data_manager(n)
+        m.set_option("packed_transfer", level)
+        if bind:
+            keep = (np.zeros(n * 6), np.zeros(n * 36))
+            m.bind_outputs(flux=keep[0], tangent=keep[1])
+        mats.append(m)
+    for eps in hist:
+        out = [m.integrate(eps) for m in mats]
+        for f, i, c in out[1:]:
+            assert np.array_equal(f, out[0][0]) and np.array_equal(c, out[0][2]) and np.array_equal(np.asarray(i), np.asarray(out[0][1]))
+        assert np.array_equal(out[0][2], out[0][2].transpose(0, 2, 1))
+        for m in mats:
+            m.data_manager.update()
+    # no stress destination: the C ABI still delivers the tangent (through the nine coefficients)
+    m = mats[0]
+    ct = np.zeros((n, 6, 6))
+    st = _lib.Stats()
+    rc = m._lib.dxm_integrate(m._handle, hist[2].ctypes.data, 0.0, None, None, ct.ctypes.data, C.byref(st))
+    assert rc == 0
+    ref = mats[3].integrate(hist[2])[2]
+    assert np.array_equal(ct, ref)
+    with pytest.raises(_lib.DxmError):
+        m.set_option("packed_transfer", 3)
+    for m in mats:
+        m.close()
