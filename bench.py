@@ -980,18 +980,19 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
             except Exception as exc:
                 gather_out["p2p_schedule"] = {"error": repr(exc)}
         if "error" not in gather_out:
-            # ... and with the tangent travelling as its 9 coefficients (72 instead of 288 B/point on the links) and
-            # rebuilt on every rank by dxm_expand_tangent_device (bit-identical): kernels with tangent_layout="coef"
+            # ... and with the tangent travelling as (c1, c2, c3, w) (32 instead of 288 B/point on the links: the flow
+            # direction is rebuilt from the gathered stress) and rebuilt on every rank by dxm_expand_tangent_pack4_device
+            # (bit-identical): kernels with tangent_layout="pack4"
             cmats = []
             try:
-                ct9 = torch.empty((n, 9), dtype=torch.float64, device=dev)
+                ct9 = torch.empty((n, 4), dtype=torch.float64, device=dev)
                 for k in (2, 3, 4):
-                    m = make("coef")
+                    m = make("pack4")
                     for i in range(k - 1):
                         m.integrate_device(eps[i].data_ptr(), flux.data_ptr(), ct9.data_ptr(), stream)
                         m.data_manager.update()
                     cmats.append(m)
-                coef_all = torch.empty((n * world, 9), dtype=torch.float64, device=cdev)
+                coef_all = torch.empty((n * world, 4), dtype=torch.float64, device=cdev)
                 my_c9 = plan.local_view(coef_all, rank)
 
                 def cstep(i):
@@ -999,11 +1000,11 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
                     if inplace:
                         cmats[j].integrate_device(eps[j + 1].data_ptr(), my_flux.data_ptr(), my_c9.data_ptr(), stream)
                         c.allgather_rows(my_flux, plan, out=g_flux)
-                        c.allgather_tangent(my_c9, plan, out=g_ct, coef_all=coef_all)
+                        c.allgather_tangent(my_c9, plan, out=g_ct, coef_all=coef_all, flux_all=g_flux)
                     else:
                         cmats[j].integrate_device(eps[j + 1].data_ptr(), flux.data_ptr(), ct9.data_ptr(), stream)
                         c.allgather_rows(to_cpu(flux), plan, out=g_flux)
-                        c.allgather_tangent(to_cpu(ct9), plan, out=g_ct, coef_all=coef_all)
+                        c.allgather_tangent(to_cpu(ct9), plan, out=g_ct, coef_all=coef_all, flux_all=g_flux)
 
                 cstep(0)
                 barrier()
@@ -1016,8 +1017,9 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
                 gather_out["coefficient_gather"] = {
                     "value": round(n * world * G / float(gt.item()) / 1e6, 3), "unit": "Mpoints/s",
                     "ms_per_step": round(float(gt.item()) / G * 1e3, 4), "steps": G,
-                    "bytes_received_per_rank": int((world - 1) * n * 15 * 8),
-                    "note": "stress (N,6) + tangent coefficients (N,9) all-gathered, (N,36) tangent rebuilt locally on every rank"}
+                    "bytes_received_per_rank": int((world - 1) * n * 10 * 8),
+                    "note": "stress (N,6) + (c1, c2, c3, w) (N,4) all-gathered: 80 instead of 336 B/point on the links; the (N,36) tangent rebuilt locally "
+                            "on every rank from both (dxm_expand_tangent_pack4_device), bit-identical to gathering full blocks"}
                 del ct9, coef_all, my_c9
             except Exception as exc:
                 gather_out["coefficient_gather"] = {"error": repr(exc)}

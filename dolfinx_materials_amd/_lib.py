@@ -87,6 +87,7 @@ SYMBOLS = {
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dxm_place_state": (C.c_int, [_h, C.c_int, C.c_uint64, C.c_uint64]),
     "dxm_expand_tangent_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "dxm_expand_tangent_pack4_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "dxm_kernel_name": (C.c_char_p, [_h]),
     "dxm_launch_generation": (C.c_uint64, [_h]),
     "dxm_notify_replay": (C.c_int, [_h]),

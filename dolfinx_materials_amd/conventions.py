@@ -94,3 +94,16 @@ def tangent_from_coefficients(coef):
     n = coef[:, 3:]
     return (coef[:, 0, None, None] * np.outer(one, one)[None] + coef[:, 1, None, None] * np.eye(6)[None]
             + coef[:, 2, None, None] * n[:, :, None] * n[:, None, :])
+
+
+def tangent_from_pack4(stress, pack):
+    """(N,6) stress and (N,4) ``(c1, c2, c3, w)`` of the same update -> (N,6,6) (the ``"pack4"`` tangent layout): the flow
+    direction is ``n = dev(stress) w``, formed with the kernel's own three operations (``small_strain.hpp`` step 5), then
+    ``Ct = c1 1x1 + c2 I + c3 n x n`` entry by entry as ``fma(c3, n_i n_j, t0)`` would (numpy rounds the product and the sum
+    separately: equal to the kernel's block to 1 ulp of the ``c3`` term, not to the bit)."""
+    stress = np.asarray(stress, dtype=np.float64).reshape(-1, 6)
+    pack = np.asarray(pack, dtype=np.float64).reshape(-1, 4)
+    third = (stress[:, 0] + stress[:, 1] + stress[:, 2]) * (1.0 / 3.0)
+    n = stress * pack[:, 3:4]
+    n[:, :3] = (stress[:, :3] - third[:, None]) * pack[:, 3:4]
+    return tangent_from_coefficients(np.concatenate([pack[:, :3], n], axis=1))

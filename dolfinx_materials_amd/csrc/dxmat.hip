@@ -30,7 +30,7 @@
 #include "small_strain.hpp"
 
 using namespace dxm;
-static_assert(TL_FULL == DXM_TANGENT_FULL && TL_SYM == DXM_TANGENT_SYM && TL_COEF == DXM_TANGENT_COEF, "kernel and ABI layout ids");
+static_assert(TL_FULL == DXM_TANGENT_FULL && TL_SYM == DXM_TANGENT_SYM && TL_COEF == DXM_TANGENT_COEF && TL_PACK4 == DXM_TANGENT_PACK4, "kernel and ABI layout ids");
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -416,6 +416,7 @@ static int tangent_size(const dxm_material* m) {
   const LawDesc& d = kLaws[m->law];
   if (m->tangent_layout == DXM_TANGENT_SYM) return d.n_flux * (d.n_flux + 1) / 2;
   if (m->tangent_layout == DXM_TANGENT_COEF) return 9;
+  if (m->tangent_layout == DXM_TANGENT_PACK4) return 4;
   return d.n_flux * d.n_grad;
 }
 
@@ -641,11 +642,11 @@ int dxm_set_params(dxm_material* m, const double* params, int n_params) {
 
 int dxm_set_tangent_layout(dxm_material* m, int layout) {
   if (!m) return fail(-1, "null handle");
-  if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_SYM && layout != DXM_TANGENT_COEF)
+  if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_SYM && layout != DXM_TANGENT_COEF && layout != DXM_TANGENT_PACK4)
     return fail(-1, "unknown tangent layout %d", layout);
   if (layout != DXM_TANGENT_FULL && kLaws[m->law].n_grad == 9)
     return fail(-1, "the FeFp tangent dP/dF is not symmetric: only DXM_TANGENT_FULL is available");
-  if (layout == DXM_TANGENT_COEF && m->law == DXM_LAW_ELASTIC_ISO)
+  if ((layout == DXM_TANGENT_COEF || layout == DXM_TANGENT_PACK4) && m->law == DXM_LAW_ELASTIC_ISO)
     return fail(-1, "the elastic tangent is the constant lambda 1x1 + 2 mu I: there are no per-point coefficients");
   m->tangent_layout = layout;
   ++m->epoch;
@@ -1887,6 +1888,22 @@ int dxm_expand_tangent_device(const double* coef_dev, int64_t npoints, double* c
   int64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(expand_tangent_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, npoints, coef_dev, ct_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dxm_expand_tangent_pack4_device(const double* flux_dev, const double* pack_dev, int64_t npoints, double* ct_dev, int device,
+                                    void* hip_stream) {
+  if (npoints < 0) return fail(-1, "negative point count");
+  if (npoints == 0) return 0;
+  if (!flux_dev || !pack_dev || !ct_dev) return fail(-1, "null device pointer");
+  if (((uintptr_t)flux_dev | (uintptr_t)pack_dev | (uintptr_t)ct_dev) & 15) return fail(-1, "stress / pack / tangent device arrays must be 16-byte aligned");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(-2, "hipSetDevice(%d) failed", device);
+  const int64_t tiles = (npoints + WAVE - 1) / WAVE;
+  int64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(expand_pack4_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, npoints, flux_dev, pack_dev, ct_dev);
   HIP_TRY(hipGetLastError());
   return 0;
 }

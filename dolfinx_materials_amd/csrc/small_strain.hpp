@@ -508,4 +508,71 @@ expand_tangent_kernel(const int64_t n, const double* __restrict__ cin, double* _
   }
 }
 
+// (stress (N, 6), (c1, c2, c3, w) (N, 4)) -> full tangent (N, 36): every lane forms the nine staged numbers of its point with the
+// update kernel's own three lines (step 5), then the same store loops.  408 B/point of HBM traffic.
+__global__ void __launch_bounds__(BLOCK, 4)
+expand_pack4_kernel(const int64_t n, const double* __restrict__ sig, const double* __restrict__ cw, double* __restrict__ ct) {
+  constexpr int PER_WAVE = 64 * 6 + 64 * 4;   // staging of a tile's stress rows and packs; the 64 x 9 coefficients reuse it
+  static_assert(PER_WAVE >= SS_COEF, "the coefficient records live in the staging region");
+  __shared__ __attribute__((aligned(16))) double lds_all[WAVES_PER_BLOCK * PER_WAVE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x >> 6;
+  double* coef = lds_all + wid * PER_WAVE;
+  const int64_t ntiles = (n + WAVE - 1) / WAVE;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; tile < ntiles; tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+    const int64_t base = tile * WAVE;
+    const int npts = (n - base) < WAVE ? (int)(n - base) : WAVE;
+    // stage the tile's stress rows (3 KiB) and packs (2 KiB) with 16 B-per-lane loads, then one point per lane
+    double2_t* st2 = reinterpret_cast<double2_t*>(coef);            // [0, 192) pairs: stress, [192, 320): packs
+    {
+      const double2_t* g = reinterpret_cast<const double2_t*>(sig + base * 6);
+      const double2_t* h = reinterpret_cast<const double2_t*>(cw + base * 4);
+      double2_t v[5];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] = (k * WAVE + lane < npts * 3) ? g[k * WAVE + lane] : double2_t{0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) v[3 + k] = (k * WAVE + lane < npts * 2) ? h[k * WAVE + lane] : double2_t{0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 5; ++k) st2[k * WAVE + lane] = v[k];
+    }
+    wave_lds_sync();
+    double s[6], c1, c2, c3, wn;
+    {
+      const double2_t a = st2[lane * 3], b = st2[lane * 3 + 1], c = st2[lane * 3 + 2];
+      s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = c.x; s[5] = c.y;
+      const double2_t u = st2[192 + lane * 2], w = st2[192 + lane * 2 + 1];
+      c1 = u.x; c2 = u.y; c3 = w.x; wn = w.y;
+    }
+    wave_lds_sync();
+    {
+      double* cf = coef + lane * 9;
+      cf[0] = c1; cf[1] = c2; cf[2] = c3;
+      const double third = opaque((s[0] + s[1] + s[2]) * SS_THIRD);
+      cf[3] = (s[0] - third) * wn; cf[4] = (s[1] - third) * wn; cf[5] = (s[2] - third) * wn;
+      cf[6] = s[3] * wn; cf[7] = s[4] * wn; cf[8] = s[5] * wn;
+    }
+    wave_lds_sync();
+    double2_t* gct = reinterpret_cast<double2_t*>(ct + base * 36);
+    const int lim = npts * 18;
+#pragma unroll 1
+    for (int g = 0; g < 6; ++g) {
+      double2_t v[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = (g * 3 + u) * WAVE + lane;
+        const int q = k / 18;
+        const int r = k - q * 18;
+        const int i = r / 3;
+        v[u] = tangent_pair(coef + q * 9, i, (r - i * 3) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = (g * 3 + u) * WAVE + lane;
+        if (k < lim) stream_store<0>(gct + k, v[u]);
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
 }  // namespace dxm

@@ -168,7 +168,10 @@ class HIPMaterial:
         upper-triangle entries per point, ``(N, 21)``, instead of the full ``(N, 6, 6)`` block the
         reference's ``jacobian_flatten`` expects (``conventions.unpack_sym_tangent`` expands it);
         ``"coef"`` (J2 laws) the nine coefficients ``(c1, c2, c3, n[6])`` of ``Ct = c1 1x1 + c2 I + c3 n x n``,
-        ``(N, 9)`` (``conventions.tangent_from_coefficients``; an assembly can use the rank structure directly).
+        ``(N, 9)`` (``conventions.tangent_from_coefficients``; an assembly can use the rank structure directly);
+        ``"pack4"`` only ``(c1, c2, c3, w)``, ``(N, 4)``: the flow direction is ``n = dev(stress) w`` by construction of the
+        kernels, so a consumer that holds the stress of the same update rebuilds the block bit for bit
+        (``conventions.tangent_from_pack4``, ``dxm_expand_tangent_pack4_device``; 80 B/point of stress + tangent).
 
         ``lazy_isv=True``: the ``isv`` array ``integrate`` returns is a :class:`LazyISV`, downloaded when it
         is first looked at; ``False`` downloads it in every call like the reference.
@@ -179,8 +182,8 @@ class HIPMaterial:
         into its rows of the one host array -- G PCIe links for the PCIe-bound form, no collective, no gather
         (north_star: "reassemble ... into the dolfinx quadrature Function", i.e. into host memory of one process,
         ``quadrature_map.py:66-70``).  The device-pointer forms belong to one GPU and raise for such a material."""
-        if tangent_layout not in ("full", "sym", "coef"):
-            raise ValueError("tangent_layout must be 'full', 'sym' or 'coef'")
+        if tangent_layout not in ("full", "sym", "coef", "pack4"):
+            raise ValueError("tangent_layout must be 'full', 'sym', 'coef' or 'pack4'")
         if not isinstance(jit, (bool, type(None))):
             raise TypeError("the second argument of JAXMaterial / HIPMaterial is `jit` (jaxmat.py:144); pass the GPU index as device=")
         self.jit = bool(jit)
@@ -264,7 +267,7 @@ class HIPMaterial:
         """Doubles per point of the tangent array ``integrate`` returns (``dxm_tangent_size``): 36 / 81 for the
         full block, 21 / 9 for the ``"sym"`` / ``"coef"`` layouts."""
         nf, ng = int(self._info.n_flux), int(self._info.n_grad)
-        return {"full": nf * ng, "sym": nf * (nf + 1) // 2, "coef": 9}[self.tangent_layout]
+        return {"full": nf * ng, "sym": nf * (nf + 1) // 2, "coef": 9, "pack4": 4}[self.tangent_layout]
 
     @property
     def algorithmic_bytes_per_point(self):
@@ -322,7 +325,7 @@ class HIPMaterial:
                     raise DxmError(f"dxm_create failed: {_lib.last_error(self._lib)}")
                 self._parts.append((h, lo, hi, dev))
                 if self.tangent_layout != "full":
-                    self._chk(self._lib.dxm_set_tangent_layout(h, {"sym": 1, "coef": 2}[self.tangent_layout]))
+                    self._chk(self._lib.dxm_set_tangent_layout(h, {"sym": 1, "coef": 2, "pack4": 3}[self.tangent_layout]))
                 lo = hi
         except Exception:
             self.close()
@@ -337,7 +340,7 @@ class HIPMaterial:
         self._flux = [np.zeros((self._n, nf)), np.zeros((self._n, nf))]
         # output arrays owned by the material: page-locked so that D2H runs at full PCIe rate, allocated when the first
         # host-buffer call needs them (a bound array or a device-pointer caller never does)
-        self._ct_shape = {"full": (self._n, nf, ng), "sym": (self._n, nf * (nf + 1) // 2), "coef": (self._n, 9)}[self.tangent_layout]
+        self._ct_shape = {"full": (self._n, nf, ng), "sym": (self._n, nf * (nf + 1) // 2), "coef": (self._n, 9), "pack4": (self._n, 4)}[self.tangent_layout]
         self._pinned = {}
         self._out_isv = self._out_ct = None
         self._flux_buf = []

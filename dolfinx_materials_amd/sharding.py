@@ -121,13 +121,20 @@ def allgather_rows_p2p(local: torch.Tensor, plan: ShardPlan, out: torch.Tensor |
 
 
 def allgather_tangent(coef_local: torch.Tensor, plan: ShardPlan, out: torch.Tensor | None = None,
-                      coef_all: torch.Tensor | None = None, group=None, p2p: bool = False) -> torch.Tensor:
-    """Reassemble the full ``(N, 36)`` J2 tangent on every rank from per-rank COEFFICIENT blocks ``(n_r, 9)``
-    (materials created with ``tangent_layout="coef"``): 72 instead of 288 B/point cross the links, then every rank
-    rebuilds the blocks locally with ``dxm_expand_tangent_device`` -- the update kernel's own expression, bit-identical
-    to gathering full blocks.  xGMI is the bound of the gather-inclusive figure (27 ms of link
-    time against 2 ms of compute per shard at cfg 3), HBM is not: the rebuild costs 360 B/point of local traffic
-    (~6 ms for 1e8 points) and saves 216 B/point on the links.  CPU tensors (the gloo tests) are rebuilt with numpy."""
+                      coef_all: torch.Tensor | None = None, group=None, p2p: bool = False,
+                      flux_all: torch.Tensor | None = None) -> torch.Tensor:
+    """Reassemble the full ``(N, 36)`` J2 tangent on every rank from per-rank COEFFICIENT blocks: ``(n_r, 9)`` (materials
+    created with ``tangent_layout="coef"``: 72 instead of 288 B/point cross the links) or ``(n_r, 4)`` (``"pack4"``: 32
+    B/point; needs ``flux_all``, the already gathered ``(N, 6)`` stress of the same update, from which the flow direction is
+    rebuilt), then every rank rebuilds the blocks locally with ``dxm_expand_tangent[_pack4]_device`` -- the update kernel's own
+    expression, bit-identical to gathering full blocks.  xGMI is the bound of the gather-inclusive figure (SURVEY.md section
+    8(e): 27 ms of link time against 2 ms of compute per shard at cfg 3), HBM is not: the rebuild costs 360-410 B/point of local
+    traffic (~6 ms for 1e8 points) and saves 216 / 256 B/point on the links.  CPU tensors (the gloo tests) are rebuilt with numpy."""
+    width = coef_local.shape[1]
+    if width not in (4, 9):
+        raise ValueError("coefficient blocks are (n, 9) ('coef') or (n, 4) ('pack4')")
+    if width == 4 and flux_all is None:
+        raise ValueError("the 'pack4' form needs flux_all, the gathered stress of the same update")
     gather = allgather_rows_p2p if p2p else allgather_rows
     kw = {} if p2p else {"scratch": None}
     coef_all = gather(coef_local, plan, out=coef_all, group=group, **kw)
@@ -137,10 +144,15 @@ def allgather_tangent(coef_local: torch.Tensor, plan: ShardPlan, out: torch.Tens
         from . import _lib
 
         lib = _lib.load()
-        _lib.check(lib.dxm_expand_tangent_device(coef_all.data_ptr(), plan.n_total, out.data_ptr(), coef_all.device.index or 0,
-                                                 torch.cuda.current_stream(coef_all.device).cuda_stream or None), lib)
+        st = torch.cuda.current_stream(coef_all.device).cuda_stream or None
+        dev = coef_all.device.index or 0
+        if width == 9:
+            _lib.check(lib.dxm_expand_tangent_device(coef_all.data_ptr(), plan.n_total, out.data_ptr(), dev, st), lib)
+        else:
+            _lib.check(lib.dxm_expand_tangent_pack4_device(flux_all.data_ptr(), coef_all.data_ptr(), plan.n_total, out.data_ptr(), dev, st), lib)
     else:
-        from .conventions import tangent_from_coefficients
+        from .conventions import tangent_from_coefficients, tangent_from_pack4
 
-        out.copy_(torch.from_numpy(tangent_from_coefficients(coef_all.numpy()).reshape(-1, 36)))
+        full = tangent_from_coefficients(coef_all.numpy()) if width == 9 else tangent_from_pack4(flux_all.numpy(), coef_all.numpy())
+        out.copy_(torch.from_numpy(full.reshape(-1, 36)))
     return out

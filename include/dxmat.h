@@ -130,7 +130,11 @@ int dxm_set_params(dxm_material* m, const double* params, int n_params);
  * (tests/mfront/IsotropicLinearHardeningPlasticity.mfront:66-69 with M expanded); integrate writes the nine
  * numbers (c1, c2, c3, n[0..5]) per point and a consumer that assembles B^T Ct B can use the rank structure
  * directly (examples/hex_fem.py): 72 instead of 288 B/point leave the device. */
-enum { DXM_TANGENT_FULL = 0, DXM_TANGENT_SYM = 1, DXM_TANGENT_COEF = 2 };
+/* DXM_TANGENT_PACK4 (J2 laws): (c1, c2, c3, w) only, 32 B/point.  The kernels build the tangent with the flow direction
+ * n = dev(stress) w (three individually rounded operations on the stress they store), so a consumer that holds the stress
+ * of the same update rebuilds n and the block bit for bit: dxm_expand_tangent_pack4_device on the GPU,
+ * conventions.tangent_from_pack4 in numpy; the host-buffer form does it internally (option "packed_transfer" = 2). */
+enum { DXM_TANGENT_FULL = 0, DXM_TANGENT_SYM = 1, DXM_TANGENT_COEF = 2, DXM_TANGENT_PACK4 = 3 };
 int dxm_set_tangent_layout(dxm_material* m, int layout);
 /* doubles per point of the tangent array integrate writes (36 / 21 / 9 / 81). */
 int dxm_tangent_size(const dxm_material* m);
@@ -200,6 +204,11 @@ int dxm_place_state(dxm_material* m, int mode, uint64_t chunk_bytes, uint64_t se
  * hip_stream of `device`.  For consumers that move the 72 B/point form (e.g. across xGMI: an all-gather of
  * coefficients followed by this kernel instead of an all-gather of 288 B/point blocks) and need the full block. */
 int dxm_expand_tangent_device(const double* coef_dev, int64_t npoints, double* ct_dev, int device, void* hip_stream);
+/* The same from the 32 B/point form: flux_dev (npoints, 6) the stress and pack_dev (npoints, 4) the (c1, c2, c3, w) of the
+ * same update (DXM_TANGENT_PACK4) -> ct_dev (npoints, 36), bit for bit what DXM_TANGENT_FULL writes.  An all-gather of
+ * stress + this form moves 80 instead of 120 (coefficients) or 336 (full blocks) B/point across xGMI. */
+int dxm_expand_tangent_pack4_device(const double* flux_dev, const double* pack_dev, int64_t npoints, double* ct_dev, int device,
+                                    void* hip_stream);
 /* Name of the HIP kernel integrate launches for this handle (for profile filtering). */
 const char* dxm_kernel_name(const dxm_material* m);
 /* Identity of the launch configuration: changes whenever a launch captured into a HIP graph before would
@@ -215,11 +224,17 @@ int dxm_notify_replay(dxm_material* m);
 /* Per-handle options (no environment variables are read by the library):
  *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on two streams (default 1)
  *   "max_chunks"     1..64   upper bound on the chunks of that pipeline (default 64)
- *   "packed_transfer" 1 | 0  host-buffer form, full tangent layout, >= packed_min_points: move the 9 coefficients
+ *   "packed_transfer" 2|1|0  host-buffer form, full tangent layout, >= packed_min_points.  1: move the 9 coefficients
  *                            of Ct = c1 1x1 + c2 I + c3 n x n (72 instead of 288 B/point; nothing for the elastic
  *                            law) / for the FeFp laws the 54 building blocks of the 9x9 tangent (432 instead of
- *                            648 B/point), and rebuild the block on the host with the kernel's own expression,
- *                            bit-identical (default 1)
+ *                            648 B/point), and rebuild the block on the host with the kernel's own expression.
+ *                            2 (default): the J2 laws move (c1, c2, c3, w) only, 32 B/point -- the kernels build
+ *                            the tangent with n = dev(stress) w, so the host rebuilds n from the stress it receives
+ *                            anyway (needs a flux destination in page-locked / registered memory, else as 1); FeFp
+ *                            as 1.  0: the full block crosses PCIe.  All three deliver the same bits
+ *   "query_foreign_pointers" 1 | 0  (process-wide) host pointers that this library did not page-lock itself
+ *                            (dxm_host_alloc / dxm_host_register) are looked up with hipPointerGetAttributes (1,
+ *                            default) or treated as pageable and staged (0)
  *   "packed_min_points" >= 0 batch size from which packed_transfer applies (default 32768: below, waking the
  *                            worker threads costs what the bytes save)
  *   "pageable_dma"   0 | 1   host-buffer form: 1 hands gradient / result arrays in ordinary (pageable) memory to the

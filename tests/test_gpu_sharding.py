@@ -44,9 +44,9 @@ def _worker(rank, world, port, n, law, q):
         sig0 = SIG0_LIN if law == "linear" else SIG0_V
         hard = jm.LinearHardening(SIG0_LIN, H_LIN) if law == "linear" else jm.VoceHardening(SIG0_V, SIGU_V, B_V)
         beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard)
-        mat, cmat = JAXMaterial(beh, device=0), JAXMaterial(beh, device=0, tangent_layout="coef")
-        mat.set_data_manager(hi - lo)
-        cmat.set_data_manager(hi - lo)
+        mat, cmat, pmat = JAXMaterial(beh, device=0), JAXMaterial(beh, device=0, tangent_layout="coef"), JAXMaterial(beh, device=0, tangent_layout="pack4")
+        for m_ in (mat, cmat, pmat):
+            m_.set_data_manager(hi - lo)
         out = []
         for eps in j2_history(n, seed=77, sig0=sig0):  # same global batch on every rank; each takes its block
             sig, isv, ct = mat.integrate(eps[lo:hi])
@@ -55,18 +55,23 @@ def _worker(rank, world, port, n, law, q):
             g_ct = allgather_rows(torch.from_numpy(np.array(ct).reshape(-1, 36)), plan)
             g_isv = allgather_rows_p2p(torch.from_numpy(np.array(isv)), plan)
             assert torch.equal(g_ct, allgather_rows_p2p(torch.from_numpy(np.array(ct).reshape(-1, 36)), plan))
-            # the third schedule: the nine coefficients per point on the wire, blocks rebuilt on every rank
+            # the third schedule: the nine coefficients per point on the wire, blocks rebuilt on every rank ...
             _, _, coef = cmat.integrate(eps[lo:hi])
             for p2p in (False, True):
                 g_ct9 = allgather_tangent(torch.from_numpy(np.array(coef)), plan, p2p=p2p)
                 assert (g_ct9 - g_ct).abs().max() <= 1e-15 * g_ct.abs().max()
+            # ... and the 32 B/point form: (c1, c2, c3, w), the flow direction rebuilt from the gathered stress
+            _, _, pack = pmat.integrate(eps[lo:hi])
+            assert np.array_equal(np.array(pack)[:, :3], np.array(coef)[:, :3])
+            g_ct4 = allgather_tangent(torch.from_numpy(np.array(pack)), plan, p2p=True, flux_all=g_sig)
+            assert (g_ct4 - g_ct).abs().max() <= 1e-15 * g_ct.abs().max()
             out.append((g_sig.numpy(), g_isv.numpy(), g_ct.numpy()))
-            mat.data_manager.update()
-            cmat.data_manager.update()
+            for m_ in (mat, cmat, pmat):
+                m_.data_manager.update()
         if rank == 0:
             q.put(out)
-        mat.close()
-        cmat.close()
+        for m_ in (mat, cmat, pmat):
+            m_.close()
     finally:
         dist.destroy_process_group()
 
@@ -162,12 +167,13 @@ def test_coefficient_gather_payload_is_rebuilt_bit_for_bit_on_the_device(gpu_ava
 
     dev = torch.device("cuda:0")
     beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
-    full, coef = JAXMaterial(beh), JAXMaterial(beh, tangent_layout="coef")
-    full.set_data_manager(n)
-    coef.set_data_manager(n)
+    full, coef, pack = JAXMaterial(beh), JAXMaterial(beh, tangent_layout="coef"), JAXMaterial(beh, tangent_layout="pack4")
+    for m_ in (full, coef, pack):
+        m_.set_data_manager(n)
     st = torch.cuda.current_stream().cuda_stream
     f = torch.empty((n, 6), dtype=torch.float64, device=dev)
     c36, c9, out = (torch.empty((n, k), dtype=torch.float64, device=dev) for k in (36, 9, 36))
+    c4 = torch.empty((n, 4), dtype=torch.float64, device=dev)
     lib = _lib.load()
     for eps in j2_history(n, seed=8, sig0=SIG0_V):
         g = to_device(eps, dev)   # through a page-locked staging tensor
@@ -177,8 +183,14 @@ def test_coefficient_gather_payload_is_rebuilt_bit_for_bit_on_the_device(gpu_ava
         _lib.check(lib.dxm_expand_tangent_device(c9.data_ptr(), n, out.data_ptr(), 0, st or None), lib)
         torch.cuda.synchronize()
         assert torch.equal(out, c36)
-        full.data_manager.update()
-        coef.data_manager.update()
+        # the 32 B/point form + the stress of the same update
+        pack.integrate_device(g.data_ptr(), f.data_ptr(), c4.data_ptr(), st)
+        out.fill_(float("nan"))
+        _lib.check(lib.dxm_expand_tangent_pack4_device(f.data_ptr(), c4.data_ptr(), n, out.data_ptr(), 0, st or None), lib)
+        torch.cuda.synchronize()
+        assert torch.equal(out, c36) and torch.equal(c4[:, :3], c9[:, :3])
+        for m_ in (full, coef, pack):
+            m_.data_manager.update()
     assert full.stats()[1]["n_plastic"] == 0 and float(c9[:, 2].abs().max()) == 0.0   # last increment unloads
 
 

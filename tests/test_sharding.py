@@ -75,6 +75,14 @@ def _worker(rank, world, port, n, q):
         for p2p in (False, True):
             full = allgather_tangent(torch.from_numpy(coef), plan, p2p=p2p)
             assert (full - ct).abs().max() <= 1e-12 * ct.abs().max()
+        # 32 B/point form: (c1, c2, c3, w) with n = dev(stress) w rebuilt from the gathered stress
+        sdev = r["sig"] - r["sig"][:, :3].sum(1)[:, None] / 3 * one
+        seq_f = np.sqrt(1.5 * (sdev * sdev).sum(1))
+        w = np.where(pl, 1.5 / np.where(pl, seq_f, 1.0), 0.0)
+        pack = np.column_stack([coef[:, :3], w])
+        for p2p in (False, True):
+            full = allgather_tangent(torch.from_numpy(pack), plan, p2p=p2p, flux_all=sig)
+            assert (full - ct).abs().max() <= 1e-12 * ct.abs().max()
         if rank == 0:
             q.put((sig.numpy(), ct.numpy()))
     finally:
