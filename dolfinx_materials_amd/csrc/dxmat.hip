@@ -1212,7 +1212,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const int tl = packed && !constant ? (pack4 ? TL_PACK4 : TL_COEF) : m->tangent_layout;   // layout of this call's launches
   const int np = fefp ? FEFP_REC : (pack4 ? 4 : 9);                     // doubles per point of the packed form
   const int nfull = d.n_flux * d.n_grad;
-  const int nt = (tl == TL_COEF || tl == TL_PACK4) ? np : (tl == TL_SYM ? d.n_flux * (d.n_flux + 1) / 2 : nfull);   // doubles per point in d_ct
+  const int nt = packed && !constant ? np : tangent_size(m);   // doubles per point in d_ct: the packed form of this call, else the handle's layout
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (packed || host_grad) {
     if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * (fefp ? FEFP_REC : 9), hipHostMallocDefault));

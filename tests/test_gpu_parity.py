@@ -243,6 +243,39 @@ def test_coefficient_tangent_layout_rebuilds_the_full_block_bit_for_bit(kind, n)
         coef.data_manager.update()
 
 
+@pytest.mark.parametrize("kind,n", [("linear", 1001), ("voce", 70_003)])
+def test_pack4_tangent_layout_with_the_stress_rebuilds_the_full_block(kind, n):
+    """`tangent_layout="pack4"`: (c1, c2, c3, w) per point; with the stress of the same update the block is
+    c1 1x1 + c2 I + c3 n x n, n = dev(stress) w (`conventions.tangent_from_pack4`: numpy rounds the product and the sum of
+    an entry separately, so 1 ulp of the c3 term from the kernel's fused form), and 1e-12 from the oracle."""
+    from dolfinx_materials_amd.conventions import tangent_from_pack4
+
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    hard_d, hard, sig0 = ((jm.LinearHardening(SIG0_LIN, H_LIN), onp.LinearHardening(SIG0_LIN, H_LIN), SIG0_LIN) if kind == "linear"
+                          else (jm.VoceHardening(SIG0_V, SIGU_V, B_V), onp.VoceHardening(SIG0_V, SIGU_V, B_V), SIG0_V))
+    beh = jm.vonMisesIsotropicHardening(el, hard_d)
+    full, pack = JAXMaterial(beh), JAXMaterial(beh, tangent_layout="pack4")
+    full.set_data_manager(n)
+    pack.set_data_manager(n)
+    assert pack.tangent_size == 4
+    epsp, p = np.zeros((n, 6)), np.zeros(n)
+    for eps in j2_history(n, seed=43, sig0=sig0)[:3]:
+        sf, isvf, cf = full.integrate(eps)
+        sp, isvp, cp = pack.integrate(eps)
+        assert cp.shape == (n, 4) and np.array_equal(sf, sp) and np.array_equal(isvf, isvp)
+        rebuilt = tangent_from_pack4(sp, cp)
+        assert np.abs(rebuilt - cf).max() <= 2e-16 * np.abs(cf).max() * 4
+        ref = onp.j2_update(eps, epsp, p, E, NU, hard)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * sig0
+        assert np.abs(rebuilt[safe] - ref["Ct"][safe]).max() <= 1e-12 * np.abs(ref["Ct"]).max()
+        assert not cp[~ref["plastic"] & safe][:, 2:].any()      # elastic points: c3 = 0, w = 0
+        epsp, p = ref["epsp"], ref["p"]
+        full.data_manager.update()
+        pack.data_manager.update()
+    full.close()
+    pack.close()
+
+
 def test_coefficient_layout_rejected_where_it_has_no_meaning():
     from dolfinx_materials_amd import _lib
 

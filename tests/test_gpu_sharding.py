@@ -19,6 +19,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _collect(q, procs, timeout=600):
+    """Rank 0's result; fails as soon as any rank has died instead of waiting for the queue's timeout."""
+    import queue as _queue
+    import time as _time
+
+    t0, got = _time.time(), None
+    while got is None:
+        try:
+            got = q.get(timeout=1.0)
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f"ranks exited with {dead}" if dead else "timed out waiting for rank 0")
+    for p in procs:
+        p.join(timeout=timeout)
+        assert p.exitcode == 0
+    return got
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -92,10 +114,7 @@ def test_ranks_with_hipmaterial_per_shard_match_single_process_oracle(gpu_availa
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, law, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=900)
-    for p in procs:
-        p.join(timeout=900)
-        assert p.exitcode == 0
+    got = _collect(q, procs)
     sig0 = SIG0_LIN if law == "linear" else SIG0_V
     hard = onp.LinearHardening(SIG0_LIN, H_LIN) if law == "linear" else onp.VoceHardening(SIG0_V, SIGU_V, B_V)
     epsp, p_ = np.zeros((n, 6)), np.zeros(n)

@@ -25,6 +25,28 @@ def test_shard_plan_partitions():
         assert sum(counts) == n and max(counts) - min(counts) <= 1 and p.max_count == max(counts)
 
 
+def _collect(q, procs, timeout=600):
+    """Rank 0's result; fails as soon as any rank has died instead of waiting for the queue's timeout."""
+    import queue as _queue
+    import time as _time
+
+    t0, got = _time.time(), None
+    while got is None:
+        try:
+            got = q.get(timeout=1.0)
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f"ranks exited with {dead}" if dead else "timed out waiting for rank 0")
+    for p in procs:
+        p.join(timeout=timeout)
+        assert p.exitcode == 0
+    return got
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -99,10 +121,7 @@ def test_sharded_update_and_allgather_matches_single_process(world, n):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    sig, ct = q.get(timeout=600)
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    sig, ct = _collect(q, procs)
     eps = j2_history(n, seed=77)[2]
     ref = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
     assert np.array_equal(sig, ref["sig"]) and np.array_equal(ct, ref["Ct"].reshape(n, 36))
