@@ -79,13 +79,15 @@ class AcceleratedUpdate:
         total.add(len(self.jacobian_flatten.x.array) // self._jacobian_width())
         plan.identity = len(total) == 1 and total.pop() == plan.npoints and bool(np.array_equal(dofs, np.arange(plan.npoints)))
         plan.grad_buffers = {}
+        width = getattr(m, "tangent_size", None)
+        if width is not None and int(width) != self._jacobian_width():
+            raise ValueError(f"the material returns {width} tangent entries per point (a packed tangent_layout) but jacobian_flatten "
+                             f"holds {self._jacobian_width()} (quadrature_map.py:83-105): create the material with tangent_layout='full'")
         # results straight into the Functions: one flux, full-width tangent, and a material that can take caller arrays
         if plan.identity and plan.npoints > 0 and len(self.fluxes) == 1 and hasattr(m, "bind_outputs"):
             (flux_fun,) = self.fluxes.values()
-            ct = self.jacobian_flatten.x.array
-            if getattr(m, "tangent_size", self._jacobian_width()) == self._jacobian_width():
-                m.bind_outputs(flux=flux_fun.x.array, tangent=ct)
-                plan.bound = True
+            m.bind_outputs(flux=flux_fun.x.array, tangent=self.jacobian_flatten.x.array)
+            plan.bound = True
         self.__dict__["_accel"] = plan
         return plan
 

@@ -194,8 +194,11 @@ class installed:
             del sys.modules[k]
         sys.modules.update(_modules())
         sys.path.insert(0, self.root)
-        import dolfinx_materials.quadrature_map as qm
-
+        try:
+            import dolfinx_materials.quadrature_map as qm
+        except BaseException:
+            self.__exit__(None, None, None)
+            raise
         return qm
 
     def __exit__(self, *exc):

@@ -211,3 +211,15 @@ def test_quadrature_map_placeholder_says_what_is_missing():
             QuadratureMap(None, 2, None)
     else:
         assert issubclass(QuadratureMap, AcceleratedUpdate) and issubclass(QuadratureMap, qmod._reference)
+
+
+def test_a_packed_tangent_layout_behind_the_reference_sized_jacobian_is_refused_with_a_reason():
+    class Sym21(OracleJ2Material):
+        tangent_size = 21
+
+    q = QuadratureFieldMap(3, 4, Sym21(E, NU, _hard()))
+    q.jacobian_width = 36      # what the reference's constructor sizes jacobian_flatten for (quadrature_map.py:83-87)
+    q.jacobian_flatten = type(q.jacobian_flatten)("jacobian", 36, 12)
+    q.register_gradient("strain", lambda c: np.zeros((len(c) * 4, 6)))
+    with pytest.raises(ValueError, match="tangent_layout='full'"):
+        q.update()
