@@ -1968,6 +1968,21 @@ int dxm_isv_host(dxm_material* m, int which, double* isv_aos) {
   return download_to_host(isv_aos, m->d_isv, sizeof(double) * m->n * total, m->own_stream);
 }
 
+int dxm_host_copy(void* dst, const void* src, uint64_t bytes, int threads) {
+  if (bytes == 0) return 0;
+  if (!dst || !src) return fail(-1, "null host pointer");
+  int nt = threads > 0 ? threads : 8;
+  if (nt > 64) nt = 64;
+  if (bytes < (uint64_t)(4u << 20) || nt == 1) { memcpy(dst, src, bytes); return 0; }
+  const uint64_t per = ((bytes + nt - 1) / nt + 4095) / 4096 * 4096;
+  std::vector<std::thread> pool;
+  for (uint64_t o = per; o < bytes; o += per)
+    pool.emplace_back([=] { memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, (size_t)std::min<uint64_t>(per, bytes - o)); });
+  memcpy(dst, src, (size_t)std::min<uint64_t>(per, bytes));
+  for (auto& t : pool) t.join();
+  return 0;
+}
+
 int dxm_host_register(void* p, uint64_t bytes) {
   if (!p || bytes == 0) return fail(-1, "null / empty host range");
   hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);

@@ -488,12 +488,20 @@ class HIPMaterial:
             self._chk(self._lib.dxm_advance(h))
         # a bound gradient / flux array is overwritten by the next update: the s0 mirrors keep their own copies then
         old = (self._grad[0], self._flux[0])
-        self._grad[0] = self._grad[1].copy() if "gradient" in self._bound else self._grad[1]
-        self._flux[0] = self._flux[1].copy() if "flux" in self._bound else self._flux[1]
+        self._grad[0] = self._snapshot(self._grad[1]) if "gradient" in self._bound else self._grad[1]
+        self._flux[0] = self._snapshot(self._flux[1]) if "flux" in self._bound else self._flux[1]
         for a in old:   # the mirrors of the increment before: freed off this thread
             if a is not self._grad[0] and a is not self._flux[0] and not any(a is b for b in self._flux_buf):
                 _reaper.drop(a)
         del old, a
+
+    def _snapshot(self, a):
+        """Copy of a (large, C-contiguous) array on several threads (``dxm_host_copy``; numpy copies on one)."""
+        if not (a.flags.c_contiguous and a.nbytes >= (4 << 20)):
+            return a.copy()
+        out = np.empty_like(a)
+        self._chk(self._lib.dxm_host_copy(_ptr(out), _ptr(a), a.nbytes, 8))
+        return out
 
     def _revert(self):
         for h in self._handles():
@@ -697,6 +705,23 @@ class HIPMaterial:
         if gradient.nbytes:
             self._chk(self._lib.dxm_host_register(_ptr(gradient), gradient.nbytes))
         self._bound["gradient"] = gradient
+
+    def bind_state_outputs(self, arrays):
+        """Page-lock in place the caller-owned arrays that receive internal state variables at ``advance`` -- the
+        ``x.array`` of the ISV quadrature Functions (``read_final_state(name, out)`` into such memory is one DMA
+        transfer instead of a staged copy).  ``arrays``: name -> C-contiguous fp64 array of ``N * dim`` entries."""
+        self._handles()
+        for name, arr in arrays.items():
+            if name not in self.internal_state_variables:
+                raise ValueError(f"unknown internal state variable {name!r}")
+            size = self._n * max(1, self.internal_state_variables[name])
+            if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size == size):
+                raise ValueError(f"{name} must be a C-contiguous float64 array with {size} entries")
+            key = "isv:" + name
+            self._unbind(key)
+            if arr.nbytes:
+                self._chk(self._lib.dxm_host_register(_ptr(arr), arr.nbytes))
+            self._bound[key] = arr
 
     def pinned_array(self, shape):
         """A zero-initialised fp64 array in page-locked host memory that owns its block (``_lib.PinnedArray``)."""

@@ -88,6 +88,9 @@ class AcceleratedUpdate:
             (flux_fun,) = self.fluxes.values()
             m.bind_outputs(flux=flux_fun.x.array, tangent=self.jacobian_flatten.x.array)
             plan.bound = True
+            pin_state = getattr(m, "bind_state_outputs", None)
+            if pin_state is not None and self.internal_state_variables:   # advance() downloads straight into these
+                pin_state({name: f.x.array for name, f in self.internal_state_variables.items()})
         self.__dict__["_accel"] = plan
         return plan
 

@@ -123,3 +123,19 @@ def test_header_is_plain_c99_and_the_c_host_example_links():
     subprocess.run(["make", "-C", os.path.join(root, "examples", "c_host"), "clean"], check=True, capture_output=True)
     subprocess.run(["make", "-C", os.path.join(root, "examples", "c_host")], check=True, capture_output=True)
     assert os.path.exists(os.path.join(root, "examples", "c_host", "j2_batch"))
+
+
+def test_host_copy_moves_every_byte_without_a_gpu():
+    """`dxm_host_copy`: the multi-threaded snapshot copy the Python layer uses at `advance` (pure host code)."""
+    import numpy as np
+
+    from dolfinx_materials_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for nbytes, threads in ((0, 4), (1000, 4), (5 << 20, 1), ((9 << 20) + 13, 8), ((6 << 20) + 1, 64)):
+        src = rng.integers(0, 255, nbytes, dtype=np.uint8)
+        dst = np.zeros(nbytes + 16, dtype=np.uint8)
+        assert lib.dxm_host_copy(dst.ctypes.data + 8, src.ctypes.data, nbytes, threads) == 0
+        assert np.array_equal(dst[8:8 + nbytes], src) and not dst[:8].any() and not dst[8 + nbytes:].any()
+    assert lib.dxm_host_copy(None, None, 8, 2) < 0

@@ -90,7 +90,7 @@ def test_accelerated_quadrature_map_is_the_reference_class_with_three_methods_re
         for name in ("p", "epsp"):
             assert np.array_equal(ref[4].internal_state_variables[name].x.array, acc[4].internal_state_variables[name].x.array)
     m, q = acc[3], acc[4]
-    assert set(m._bound) == {"flux", "tangent", "gradient"}
+    assert set(m._bound) == {"flux", "tangent", "gradient", "isv:p", "isv:epsp"}
     assert m._bound["flux"].ctypes.data == q.fluxes["stress"].x.array.ctypes.data
     assert m._bound["tangent"].ctypes.data == q.jacobian_flatten.x.array.ctypes.data
     assert m._bound["gradient"].ctypes.data == q.gradients["strain"].function.x.array.ctypes.data

@@ -96,7 +96,7 @@ def test_field_map_on_a_multi_device_material_binds_and_matches():
         for q in maps:
             q.advance()
         assert np.array_equal(maps[0].internal_state_variables["epsp"].x.array, maps[1].internal_state_variables["epsp"].x.array)
-    assert maps[1]._bound and set(maps[1].material._bound) == {"flux", "tangent", "gradient"}
+    assert maps[1]._bound and set(maps[1].material._bound) == {"flux", "tangent", "gradient", "isv:p", "isv:epsp"}
     for q in maps:
         q.close()
         q.material.close()

@@ -108,7 +108,7 @@ def test_bound_map_delivers_into_the_fields_memory_and_fetches_isvs_at_advance_o
     q = QuadratureFieldMap(ncell, nqp, m)
     q.register_gradient("strain", lambda c: now["g"].reshape(ncell, nqp, 6)[c].reshape(-1, 6))
     q.update()
-    assert q._bound and set(m._bound) == {"flux", "tangent", "gradient"}
+    assert q._bound and set(m._bound) == {"flux", "tangent", "gradient", "isv:p", "isv:epsp"}
     assert m._bound["flux"].ctypes.data == q.fluxes["stress"].x.array.ctypes.data
     assert m._bound["tangent"].ctypes.data == q.jacobian_flatten.x.array.ctypes.data
     assert m._bound["gradient"].ctypes.data == q.gradients["strain"].function.x.array.ctypes.data
