@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DXM_ABI_VERSION 2
+#define DXM_ABI_VERSION 3   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2 */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
 enum {
