@@ -44,6 +44,14 @@ def rows_of(fun, dim):
     return fun.x.array.reshape(-1, max(1, int(dim)))
 
 
+def _slow_path_warning(what, exc):
+    import warnings
+
+    from . import PerformanceWarning
+
+    warnings.warn(f"could not page-lock the memory of {what} in place ({exc}): results are delivered through staging copies", PerformanceWarning)
+
+
 def _same_memory(a, b):
     return a.size == b.size and a.ctypes.data == b.ctypes.data
 
@@ -86,11 +94,21 @@ class AcceleratedUpdate:
         # results straight into the Functions: one flux, full-width tangent, and a material that can take caller arrays
         if plan.identity and plan.npoints > 0 and len(self.fluxes) == 1 and hasattr(m, "bind_outputs"):
             (flux_fun,) = self.fluxes.values()
-            m.bind_outputs(flux=flux_fun.x.array, tangent=self.jacobian_flatten.x.array)
-            plan.bound = True
+            # page-locking caller memory can be refused (RLIMIT_MEMLOCK, a range that is registered already): the map
+            # then works through the material's own arrays and row copies, slower but identical
+            try:
+                m.bind_outputs(flux=flux_fun.x.array, tangent=self.jacobian_flatten.x.array)
+                plan.bound = True
+            except Exception as exc:
+                _slow_path_warning("the flux / jacobian_flatten Functions", exc)
+                if hasattr(m, "_unbind"):
+                    m._unbind()
             pin_state = getattr(m, "bind_state_outputs", None)
-            if pin_state is not None and self.internal_state_variables:   # advance() downloads straight into these
-                pin_state({name: f.x.array for name, f in self.internal_state_variables.items()})
+            if plan.bound and pin_state is not None and self.internal_state_variables:   # advance() downloads straight into these
+                try:
+                    pin_state({name: f.x.array for name, f in self.internal_state_variables.items()})
+                except Exception as exc:
+                    _slow_path_warning("the internal-state Functions", exc)
         self.__dict__["_accel"] = plan
         return plan
 
@@ -173,7 +191,10 @@ class AcceleratedUpdate:
             if name not in plan.grad_buffers:   # page-lock the Function's memory once: uploaded by DMA, no staging copy
                 pin = getattr(self.material, "bind_inputs", None)
                 if pin is not None and rows.size:
-                    pin(gradient=grad.function.x.array)
+                    try:
+                        pin(gradient=grad.function.x.array)
+                    except Exception as exc:   # uploaded through the library's staging ring instead
+                        _slow_path_warning(f"the '{name}' gradient Function", exc)
                 plan.grad_buffers[name] = rows
             if not self._evaluate_into(grad, rows):
                 grad.eval(self.cells)           # the reference's route: scatter through the expression's dof table

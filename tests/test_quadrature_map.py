@@ -223,3 +223,27 @@ def test_a_packed_tangent_layout_behind_the_reference_sized_jacobian_is_refused_
     q.register_gradient("strain", lambda c: np.zeros((len(c) * 4, 6)))
     with pytest.raises(ValueError, match="tangent_layout='full'"):
         q.update()
+
+
+def test_refused_page_locking_falls_back_to_copies_with_a_warning():
+    from dolfinx_materials_amd import PerformanceWarning
+
+    class Refusing(EngineLikeMaterial):
+        def bind_outputs(self, flux=None, tangent=None):
+            raise RuntimeError("hipHostRegister failed")
+
+        def bind_inputs(self, gradient=None):
+            raise RuntimeError("hipHostRegister failed")
+
+    ncell, nqp = 5, 4
+    eps = j2_history(ncell * nqp, seed=4)[2]
+    q = QuadratureFieldMap(ncell, nqp, Refusing(E, NU, _hard()))
+    ref = FieldMapBase(ncell, nqp, OracleJ2Material(E, NU, _hard()))
+    for qq in (q, ref):
+        qq.register_gradient("strain", lambda c: eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    with pytest.warns(PerformanceWarning):
+        q.update()
+    as_reference_update(ref)
+    assert not q._bound
+    assert np.array_equal(q.fluxes["stress"].x.array, ref.fluxes["stress"].x.array)
+    assert np.array_equal(q.jacobian_flatten.x.array, ref.jacobian_flatten.x.array)
