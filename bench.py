@@ -687,7 +687,7 @@ def main():
     cfg3 = None
     if world > 1 and not args.no_cfg3 and args.law == "j2_linear":
         # (the debug share mode keeps all ranks on one GPU and gathers through gloo on the host: never the full size there)
-        n3 = args.cfg3_points if args.cfg3_points else (min(n, 100_000_000 // world) if share else 100_000_000 // world)
+        n3 = args.cfg3_points if args.cfg3_points else (min(n, 50_000, 100_000_000 // world) if share else 100_000_000 // world)
         try:
             cfg3 = run_workload(c, "j2_voce", n3, max(10, min(K, 50)), min(W, 5), max(10, args.gather_steps), gather=not args.no_gather)
         except Exception as exc:   # context block: never lose the headline line
