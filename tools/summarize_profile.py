@@ -31,9 +31,15 @@ def _source_hash():
     return bench.source_hash()
 
 
+def _newest(files):
+    """Only the most recent run's file: `gpurun` MERGES what a call wrote into gpurun_out/, so a pass directory can still
+    hold the files of an earlier round (this mixed round-2 counters into the first round-3 summaries)."""
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def counters(path, match):
     agg = collections.defaultdict(list)
-    files = glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+    files = _newest(glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True))
     for f in files:
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
@@ -56,7 +62,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.prefix) or ".", exist_ok=True)
 
-    stats_files = glob.glob(os.path.join(a.src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    stats_files = _newest(glob.glob(os.path.join(a.src, "trace", "**", "*kernel_stats.csv"), recursive=True))
     rows = []
     if stats_files:
         shutil.copy(stats_files[0], a.prefix + "_kernel_stats.csv")
@@ -67,7 +73,7 @@ def main():
     # before it are setup: building the load-step contexts, placement tuning (incl. rejected slow
     # candidates), warm-up.  The --stats table averages over all of them.
     timed = None
-    tfiles = glob.glob(os.path.join(a.src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    tfiles = _newest(glob.glob(os.path.join(a.src, "trace", "**", "*kernel_trace.csv"), recursive=True))
     if tfiles:
         disp = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tfiles[0]))
                        if a.kernel in r["Kernel_Name"]))
