@@ -331,6 +331,9 @@ struct dxm_material {
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
   bool opt_tune_verbose = false;
+  bool opt_register_input = true;         // host path: page-lock a pageable gradient array for the duration of the call (DMA upload)
+  int register_skip = 0;                  // calls left that stage instead (the last registrations were expensive: small pages)
+  int register_calls = 0, register_slow = 0;
   int opt_host_threads = 16;
   int opt_pageable_dma = 0;   // 1: hand pageable host arrays to the runtime (faster uploads; see upload_from_host)
   int64_t opt_packed_min_points = 32768;   // below: waking the workers costs what the bytes save (r02_hostpath_v2.jsonl)
@@ -1405,7 +1408,43 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
   DEVICE_GUARD(m);
   // a page-locked gradient array is uploaded by DMA; so is a pageable one if the caller asked for it (option pageable_dma)
   const auto t_in = std::chrono::steady_clock::now();
-  const bool locked_in = m->opt_pageable_dma || page_locked(grad_aos, sizeof(double) * n * d.n_grad);
+  bool locked_in = m->opt_pageable_dma || page_locked(grad_aos, sizeof(double) * n * d.n_grad);
+  // An array in ordinary memory is page-locked HERE, for the duration of this call, and uploaded by DMA like a page-locked
+  // one: registering a 480 MB array takes ~1 ms (profiles/r03_hostpath_register.md) where staging it through the ring
+  // costs the worker threads 5-10 ms of a 24 ms call.  This is not the runtime's implicit path for pageable memory (whose
+  // cache of on-the-fly mappings outlives the caller's array: DESIGN.md section 1): the range is unregistered before this
+  // function returns, error paths included, while the caller still owns the array.  A refusal (a range that overlaps a
+  // registered one, memory that cannot be pinned) falls back to the staging ring.
+  struct TempRegistration {
+    void* p = nullptr;
+    ~TempRegistration() { if (p) { forget_locked(p); (void)hipHostUnregister(p); (void)hipGetLastError(); } }
+  } temp;
+  if (!locked_in && m->opt_register_input && (size_t)n * d.n_grad * sizeof(double) >= ((size_t)1 << 20)) {
+    if (m->register_skip > 0) {
+      --m->register_skip;
+    } else {
+      void* p = const_cast<double*>(grad_aos);
+      const size_t bytes = sizeof(double) * n * d.n_grad;
+      const auto t0 = std::chrono::steady_clock::now();
+      if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) {
+        temp.p = p;
+        locked_in = true;
+        // 0.9 ms per 480 MB on transparent huge pages (what numpy asks for), 7-17 ms on 4 KiB pages, where the whole call
+        // then takes 43 instead of 28 ms: such arrays go through the staging ring for the next 20 calls, then one more try
+        const double ms_per_gb = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / ((double)bytes / 1e9);
+        // (the first registration of a handle also pays for one-time set-up in the runtime and is not judged; three expensive
+        // ones in a row -- above 10 ms/GB: a loaded host makes a huge-page registration take 2-4 ms now and then -- are)
+        if (m->register_calls++ > 0 && ms_per_gb > 10.0) {
+          if (++m->register_slow >= 3) { m->register_skip = 20; m->register_slow = 0; }
+        } else {
+          m->register_slow = 0;
+        }
+      } else {
+        (void)hipGetLastError();
+        m->register_skip = 20;
+      }
+    }
+  }
   const auto t_q = std::chrono::steady_clock::now();
   if (int rc = ensure_host_path_buffers(m)) return rc;
   if (int rc = sync_last(m)) return rc;
@@ -1929,6 +1968,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   }
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
   else if (k == "tune_verbose") m->opt_tune_verbose = on;
+  else if (k == "register_input") m->opt_register_input = on;
   else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;
   else if (k == "query_foreign_pointers") g_query_foreign.store(on ? 1 : 0);   // process-wide
   else if (k == "packed_min_points") {

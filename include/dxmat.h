@@ -232,6 +232,12 @@ int dxm_notify_replay(dxm_material* m);
  *                            the tangent with n = dev(stress) w, so the host rebuilds n from the stress it receives
  *                            anyway (needs a flux destination in page-locked / registered memory, else as 1); FeFp
  *                            as 1.  0: the full block crosses PCIe.  All three deliver the same bits
+ *   "register_input" 1 | 0   host-buffer form: a gradient array in ordinary (pageable) memory is page-locked for the
+ *                            duration of the call (hipHostRegister ... hipHostUnregister before the call returns) and
+ *                            uploaded by DMA: ~1 ms per 480 MB on transparent huge pages (numpy's default), instead of
+ *                            5-10 ms of staging copies by the worker threads.  Arrays on 4 KiB pages register slowly
+ *                            (7-17 ms): after three such registrations in a row the handle stages the next 20 calls.  0: always
+ *                            stage through the page-locked ring (default 1)
  *   "query_foreign_pointers" 1 | 0  (process-wide) host pointers that this library did not page-lock itself
  *                            (dxm_host_alloc / dxm_host_register) are looked up with hipPointerGetAttributes (1,
  *                            default) or treated as pageable and staged (0)

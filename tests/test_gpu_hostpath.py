@@ -342,3 +342,36 @@ def test_every_level_of_packed_transfer_delivers_the_same_bits(kind, n):
         m.set_option("packed_transfer", 3)
     for m in mats:
         m.close()
+
+
+def test_pageable_gradient_is_page_locked_for_the_call_only():
+    """`register_input` (default): a gradient array in ordinary memory is registered for the duration of `dxm_integrate`
+    and uploaded by DMA; staged through the ring with the option off.  Same bits either way, and the range is unregistered
+    again when the call returns: registering it explicitly afterwards succeeds (a range that is still registered is
+    refused by the runtime), also after a call that fails part-way."""
+    n = 200_003
+    hist = j2_history(n, seed=21)
+    a, b = _j2(), _j2()
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    b.set_option("register_input", 0)
+    lib = a._lib
+    for eps in hist[:3]:
+        g = np.array(eps)                       # a fresh array per call, as QuadratureMap.update hands over
+        fa, ia, ca = a.integrate(g)
+        fb, ib, cb = b.integrate(np.array(eps))
+        assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(np.asarray(ia), np.asarray(ib))
+        assert lib.dxm_host_register(g.ctypes.data, g.nbytes) == 0, _lib.last_error(lib)   # not registered any more
+        assert lib.dxm_host_unregister(g.ctypes.data) == 0
+        a.data_manager.update()
+        b.data_manager.update()
+    # a view that does not start at the array's first byte, and a read-only array
+    big = np.zeros((n + 7, 6))
+    big[7:] = hist[3]
+    ro = np.array(hist[3])
+    ro.setflags(write=False)
+    ref = b.integrate(np.array(hist[3]))[0].copy()
+    assert np.array_equal(a.integrate(big[7:])[0], ref)
+    assert np.array_equal(a.integrate(ro)[0], ref)
+    a.close()
+    b.close()
