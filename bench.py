@@ -309,24 +309,42 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
         return {"accelerated_update": fast, "as_reference_update": slow, "fields_bit_identical": bool(same),
                 "accelerated_over_reference": round(slow["ms_per_update"] / fast["ms_per_update"], 2)}
 
+    def page_lock_probe():
+        """What page-locking a fresh strain array costs on this host (the library does it per call, option register_input):
+        ~1 ms per 480 MB on transparent huge pages, 7-17 ms on 4 KiB pages (then the library stages through its ring)."""
+        from dolfinx_materials_amd import _lib
+
+        lib = _lib.load()
+        ts = []
+        for _ in range(3):
+            a = np.array(h[1])
+            t0 = time.perf_counter()
+            rc = lib.dxm_host_register(a.ctypes.data, a.nbytes)
+            ts.append(time.perf_counter() - t0)
+            if rc == 0:
+                lib.dxm_host_unregister(a.ctypes.data)
+            del a
+        return round(float(np.median(ts)) * 1e3 * 480e6 / (n * 48), 2)
+
     dt_own, dt, dt_fast = timed(False), timed(True), timed(True, pageable_dma=True)
     dt_fresh, dt_fresh_fast = timed(True, fresh=True), timed(True, pageable_dma=True, fresh=True)
     out = {"value": round(n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_call": round(dt * 1e3, 3), "points": n,
            "into_the_materials_own_arrays": {"value": round(n / dt_own / 1e6, 2), "ms_per_call": round(dt_own * 1e3, 3)},
            "new_strain_array_every_call": {"value": round(n / dt_fresh / 1e6, 2), "ms_per_call": round(dt_fresh * 1e3, 3),
                                            "with_option_pageable_dma": round(n / dt_fresh_fast / 1e6, 2),
-                                           "note": "what QuadratureMap.update hands over (quadrature_map.py:304-313): the runtime's pageable path "
-                                                   "has to page-lock the array again each time, the staged default does not care"},
+                                           "note": "what QuadratureMap.update hands over (quadrature_map.py:304-313): a newly allocated array per call, "
+                                                   "page-locked by the library for the call (~1 ms on huge pages) and released off the calling thread afterwards"},
            "with_option_pageable_dma": {"value": round(n / dt_fast / 1e6, 2), "ms_per_call": round(dt_fast * 1e3, 3),
                                         "note": "the pageable strain array handed to the runtime's own transfer path instead of the library's page-locked "
                                                 "staging ring: faster, but exposed to the runtime's cache of on-the-fly page-locked ranges (DESIGN.md section 1)"},
+           "page_lock_ms_per_480MB": page_lock_probe(),
            "pcie_bytes_per_point": {"h2d_strain": 48, "d2h_stress": 48, "d2h_tangent_coefficients": 32, "isv": "on demand (56)"},
            "GBs_over_pcie": round(n * 128 / dt / 1e9, 1),
            "note": "host buffers in and out through dxm_integrate: chunk-pipelined on two streams; of the tangent only (c1, c2, c3, w) cross PCIe -- the flow "
                    "direction is dev(stress) w by construction of the kernel -- and the (N,6,6) block is rebuilt by 16 host threads with the kernel's own "
                    "expression, bit-identical to the full download (what bounds the call now is those threads writing 288 B/point into host memory); "
                    "`value`: results delivered into caller-owned arrays (bind_outputs: the x.array of the quadrature Functions), the pageable strain array "
-                   "staged through a page-locked ring by the worker threads (no DMA from or into pageable memory)"}
+                   "page-locked for the duration of the call and uploaded by DMA (option register_input; the staging ring when that is slow or refused)"}
     try:
         out.update(cadence_pair())
     except Exception as exc:  # context only
