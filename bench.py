@@ -220,8 +220,11 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
             m.integrate(g)
             ts.append(time.perf_counter() - t0)
             del g
+        uploads.append(m.last_upload)
         m.close()
         return float(np.median(ts))
+
+    uploads = []
 
     def update_cadence(accelerated, reps, nqp=8):
         """One ``QuadratureMap.update()`` at n points (n / 8 hexahedra with 8 Gauss points), numpy stand-ins for the
@@ -338,6 +341,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
                                         "note": "the pageable strain array handed to the runtime's own transfer path instead of the library's page-locked "
                                                 "staging ring: faster, but exposed to the runtime's cache of on-the-fly page-locked ranges (DESIGN.md section 1)"},
            "page_lock_ms_per_480MB": page_lock_probe(),
+           "strain_upload": {"own_arrays": uploads[0], "bound_arrays": uploads[1], "pageable_dma": uploads[2], "new_array_every_call": uploads[3]},
            "pcie_bytes_per_point": {"h2d_strain": 48, "d2h_stress": 48, "d2h_tangent_coefficients": 32, "isv": "on demand (56)"},
            "GBs_over_pcie": round(n * 128 / dt / 1e9, 1),
            "note": "host buffers in and out through dxm_integrate: chunk-pipelined on two streams; of the tangent only (c1, c2, c3, w) cross PCIe -- the flow "

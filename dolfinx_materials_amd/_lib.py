@@ -42,11 +42,18 @@ class Stats(C.Structure):
         ("n_not_converged", C.c_int64),
         ("n_nan", C.c_int64),
         ("max_local_iters", C.c_int32),
-        ("reserved", C.c_int32),
+        ("upload", C.c_int32),
     ]
 
+    #: dxm_stats.upload: how the gradient array reached the GPU in a host-buffer call (include/dxmat.h DXM_UPLOAD_*)
+    UPLOAD = {0: None, 1: "dma (caller's array page-locked)", 2: "dma (page-locked for the call)", 3: "staged through the ring", 4: "runtime pageable path"}
+
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "upload"}
+
+    @property
+    def upload_mode(self):
+        return self.UPLOAD.get(int(self.upload))
 
 
 _dp = C.POINTER(C.c_double)

@@ -334,6 +334,7 @@ struct dxm_material {
   bool opt_register_input = true;         // host path: page-lock a pageable gradient array for the duration of the call (DMA upload)
   int register_skip = 0;                  // calls left that stage instead (the last registrations were expensive: small pages)
   int register_calls = 0, register_slow = 0;
+  int last_upload = DXM_UPLOAD_NONE;      // dxm_stats.upload of the last host-buffer call
   int opt_host_threads = 16;
   int opt_pageable_dma = 0;   // 1: hand pageable host arrays to the runtime (faster uploads; see upload_from_host)
   int64_t opt_packed_min_points = 32768;   // below: waking the workers costs what the bytes save (r02_hostpath_v2.jsonl)
@@ -1388,6 +1389,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   inflight.completed = true;
   const auto t_stats = std::chrono::steady_clock::now();
   const int rc_stats = dxm_get_stats(m, stats);
+  if (stats) stats->upload = host_grad ? DXM_UPLOAD_STAGED : m->last_upload;
   if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] status records summed in %.3f ms; %.2f ms since entry\n", ms_since(t_stats), ms_since(t_enter));
   return rc_stats;
 }
@@ -1445,6 +1447,7 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
       }
     }
   }
+  m->last_upload = m->opt_pageable_dma ? DXM_UPLOAD_RUNTIME : (temp.p ? DXM_UPLOAD_REGISTERED : (locked_in ? DXM_UPLOAD_PAGE_LOCKED : DXM_UPLOAD_STAGED));
   const auto t_q = std::chrono::steady_clock::now();
   if (int rc = ensure_host_path_buffers(m)) return rc;
   if (int rc = sync_last(m)) return rc;

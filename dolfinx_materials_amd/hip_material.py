@@ -208,6 +208,7 @@ class HIPMaterial:
         self._n = 0
         self.data_manager = None
         self.last_stats = None
+        self.last_upload = None
         self.dt = 0.0
         self._warm = False
 
@@ -575,6 +576,7 @@ class HIPMaterial:
         rcs = self._run(calls)
         for rc in rcs:
             self._chk(rc)
+        self.last_upload = recs[0].upload_mode   # how the gradient array reached the GPU (first block)
         tot = {"n_points": 0, "n_plastic": 0, "n_not_converged": 0, "n_nan": 0, "max_local_iters": 0}
         for st in recs:
             d = st.as_dict()

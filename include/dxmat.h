@@ -94,7 +94,7 @@ typedef struct dxm_stats {
   int64_t n_not_converged;  /* local Newton hit maxit              */
   int64_t n_nan;            /* points with a non-finite flux / isv */
   int32_t max_local_iters;
-  int32_t reserved;
+  int32_t upload;   /* host-buffer form: how the gradient reached the GPU in this call -- DXM_UPLOAD_* below; 0 otherwise */
 } dxm_stats;
 
 typedef struct dxm_material dxm_material; /* opaque handle */
@@ -134,6 +134,11 @@ int dxm_set_params(dxm_material* m, const double* params, int n_params);
  * n = dev(stress) w (three individually rounded operations on the stress they store), so a consumer that holds the stress
  * of the same update rebuilds n and the block bit for bit: dxm_expand_tangent_pack4_device on the GPU,
  * conventions.tangent_from_pack4 in numpy; the host-buffer form does it internally (option "packed_transfer" = 2). */
+/* dxm_stats.upload */
+enum { DXM_UPLOAD_NONE = 0, DXM_UPLOAD_PAGE_LOCKED = 1 /* the caller's array was page-locked already: DMA */,
+       DXM_UPLOAD_REGISTERED = 2 /* page-locked by the library for the duration of the call: DMA */,
+       DXM_UPLOAD_STAGED = 3 /* copied chunk by chunk into the library's page-locked ring by the worker threads */,
+       DXM_UPLOAD_RUNTIME = 4 /* option pageable_dma: handed to the runtime's own pageable path */ };
 enum { DXM_TANGENT_FULL = 0, DXM_TANGENT_SYM = 1, DXM_TANGENT_COEF = 2, DXM_TANGENT_PACK4 = 3 };
 int dxm_set_tangent_layout(dxm_material* m, int layout);
 /* doubles per point of the tangent array integrate writes (36 / 21 / 9 / 81). */

@@ -361,6 +361,7 @@ def test_pageable_gradient_is_page_locked_for_the_call_only():
         fa, ia, ca = a.integrate(g)
         fb, ib, cb = b.integrate(np.array(eps))
         assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(np.asarray(ia), np.asarray(ib))
+        assert a.last_upload == "dma (page-locked for the call)" and b.last_upload == "staged through the ring"
         assert lib.dxm_host_register(g.ctypes.data, g.nbytes) == 0, _lib.last_error(lib)   # not registered any more
         assert lib.dxm_host_unregister(g.ctypes.data) == 0
         a.data_manager.update()
@@ -373,5 +374,13 @@ def test_pageable_gradient_is_page_locked_for_the_call_only():
     ref = b.integrate(np.array(hist[3]))[0].copy()
     assert np.array_equal(a.integrate(big[7:])[0], ref)
     assert np.array_equal(a.integrate(ro)[0], ref)
+    pin = _lib.PinnedArray(hist[3].shape)
+    pin.array[...] = hist[3]
+    assert np.array_equal(a.integrate(pin.array)[0], ref) and a.last_upload == "dma (caller's array page-locked)"
+    small = _j2()
+    small.set_data_manager(1000)
+    small.integrate(np.array(hist[0][:1000]))
+    assert small.last_upload == "staged through the ring"     # below 1 MB the registration is not worth a system call
+    small.close()
     a.close()
     b.close()
