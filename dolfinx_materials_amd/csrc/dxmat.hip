@@ -292,6 +292,7 @@ struct HostPool {
 // handle
 // ------------------------------------------------------------------------------------------
 constexpr int DXM_MAX_CHUNKS = 64;
+constexpr int DXM_RING = 16;   // slots of the page-locked staging ring
 
 struct dxm_material {
   int law = 0;
@@ -356,7 +357,8 @@ struct dxm_material {
   // host-buffer form, strain in ordinary memory: page-locked ring the kernels read the chunks from (zero-copy)
   double* h_grad_ring = nullptr;
   int64_t ring_slot_doubles = 0;
-  hipEvent_t ring_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ring_done[DXM_RING] = {};
+  int opt_stage_ahead = 3;
 };
 
 static int sync_last(dxm_material* m);
@@ -1241,7 +1243,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (m->ring_slot_doubles < need) {
       if (m->h_grad_ring) HIP_TRY(hipHostFree(m->h_grad_ring));
       m->h_grad_ring = nullptr;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_grad_ring), sizeof(double) * need * 8, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_grad_ring), sizeof(double) * need * DXM_RING, hipHostMallocDefault));
       m->ring_slot_doubles = need;
     }
     for (hipEvent_t& e : m->ring_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1283,13 +1285,14 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   auto stage_chunk = [&](int p) -> int {
     const int64_t o = (int64_t)p * csize;
     if (!host_grad || p >= nchunks || o >= n) return 0;
-    if (p >= 8) HIP_TRY(hipEventSynchronize(m->ring_done[p % 8]));   // the copy kernel of chunk p - 8 has read this slot
-    m->pool->copy_async(host_grad + o * d.n_grad, m->h_grad_ring + (int64_t)(p % 8) * m->ring_slot_doubles,
+    if (p >= DXM_RING) HIP_TRY(hipEventSynchronize(m->ring_done[p % DXM_RING]));   // the copy kernel of chunk p - DXM_RING has read this slot
+    m->pool->copy_async(host_grad + o * d.n_grad, m->h_grad_ring + (int64_t)(p % DXM_RING) * m->ring_slot_doubles,
                         sizeof(double) * ((n - o) < csize ? (n - o) : csize) * d.n_grad, p);
     return 0;
   };
   double ms_wait_copy = 0.0, ms_first_copy = 0.0;   // tune_verbose: time the issue loop spent waiting for staging copies
-  for (int p = 0; p < 3; ++p) if (int rc = stage_chunk(p)) return rc;
+  const int ahead = m->opt_stage_ahead;
+  for (int p = 0; p < ahead; ++p) if (int rc = stage_chunk(p)) return rc;
   for (int c = 0; c < nchunks; ++c) {
     const int64_t off = (int64_t)c * csize;
     if (off >= n) break;
@@ -1298,9 +1301,9 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (int rc = upload(off, cnt, st)) return rc;
     const double* gptr = fused ? m->d_flux : m->d_grad + off * d.n_grad;
     if (host_grad) {
-      const int slot = c % 8;
+      const int slot = c % DXM_RING;
       double* dst = m->h_grad_ring + (int64_t)slot * m->ring_slot_doubles;
-      if (int rc = stage_chunk(c + 3)) return rc;   // keep three chunks ahead of the launches
+      if (int rc = stage_chunk(c + ahead)) return rc;   // keep `ahead` chunks ahead of the launches
       {
         const auto tw = std::chrono::steady_clock::now();
         m->pool->wait_copy(c);
@@ -1971,6 +1974,10 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   }
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
   else if (k == "tune_verbose") m->opt_tune_verbose = on;
+  else if (k == "stage_ahead") {
+    if (!(value >= 1 && value <= DXM_RING - 2)) return fail(-1, "stage_ahead must be in [1, %d]", DXM_RING - 2);
+    m->opt_stage_ahead = (int)value;
+  }
   else if (k == "register_input") m->opt_register_input = on;
   else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;
   else if (k == "query_foreign_pointers") g_query_foreign.store(on ? 1 : 0);   // process-wide
