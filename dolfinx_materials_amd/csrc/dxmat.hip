@@ -1436,7 +1436,8 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
         locked_in = true;
         // 0.9 ms per 480 MB on transparent huge pages (what numpy asks for), 7-17 ms on 4 KiB pages, where the whole call
         // then takes 43 instead of 28 ms: such arrays go through the staging ring for the next 20 calls, then one more try
-        const double ms_per_gb = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / ((double)bytes / 1e9);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const double ms_per_gb = ms > 0.5 ? (ms - 0.5) / ((double)bytes / 1e9) : 0.0;   // half a millisecond of fixed cost is fine for any size
         // (the first registration of a handle also pays for one-time set-up in the runtime and is not judged; three expensive
         // ones in a row -- above 10 ms/GB: a loaded host makes a huge-page registration take 2-4 ms now and then -- are)
         if (m->register_calls++ > 0 && ms_per_gb > 10.0) {
