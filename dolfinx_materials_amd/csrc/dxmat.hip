@@ -1795,6 +1795,7 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
   if (dxm_mesh_npoints(mesh) != m->n) return fail(-1, "mesh has %lld Gauss points, material %lld",
                                                    (long long)dxm_mesh_npoints(mesh), (long long)m->n);
   DEVICE_GUARD(m);
+  m->last_upload = DXM_UPLOAD_NONE;   // no gradient array crosses PCIe in this form
   const bool fuse = m->opt_fused_gradient && fusable(mesh);   // gradient evaluated inside the update kernel
   if (int rc = ensure_host_path_buffers(m, !fuse)) return rc;
   hipStream_t st = m->own_stream;
