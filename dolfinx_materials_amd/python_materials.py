@@ -6,12 +6,15 @@ from . import materials as _m
 
 
 class LinearElasticIsotropic(HIPMaterial):
-    def __init__(self, E, nu, device=0):
+    def __init__(self, E, nu, device=0, **engine_options):
+        """``LinearElasticIsotropic(E, nu)`` as in the reference; ``device`` / ``devices=[...]`` / ``lazy_isv`` ... are
+        the engine's own keyword arguments (:class:`HIPMaterial`)."""
         super().__init__(
             _m.ElasticBehavior(_m.LinearElasticIsotropic(E=E, nu=nu)),
             device=device,
             gradient_name="Strain",
             flux_name="Stress",
+            **engine_options,
         )
         self.E = E
         self.nu = nu
