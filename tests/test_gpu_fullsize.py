@@ -114,3 +114,49 @@ def test_fefp_full_size_device_path():
         assert abs(stats["n_plastic"] / N - ref["plastic"].mean()) < 0.05
         mat.data_manager.update()
         cp, p = ref["cpinv"], ref["p"]
+
+
+def test_cfg3_total_size_on_one_gpu():
+    """cfg 3's batch -- 1e8 Gauss points of J2 + Voce (sig0 = 350, sigu = 500, b = 1e3) -- on ONE MI355X (55 GB of HBM): the
+    size the 8-GPU configuration shards is exercised here end to end on the device path (two increments, advance in
+    between), a strided sample against the oracle, the whole batch through the status record and checksums; 64-bit point
+    offsets everywhere (1e8 x 36 tangent entries = 3.6e9 > 2^31)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    n = 100_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 70e9:
+        pytest.skip("needs 70 GB of free HBM")
+    hard_o = onp.VoceHardening(SIG0_V, SIGU_V, B_V)
+    g = torch.Generator(device=dev).manual_seed(77)
+    eps_hat = torch.randn((n, 6), generator=g, device=dev, dtype=torch.float64)
+    eps_hat /= eps_hat.norm(dim=1, keepdim=True)
+    eps_hat *= torch.rand((n, 1), generator=g, device=dev, dtype=torch.float64) * 4.0 * eps_yield(SIG0_V)
+    mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V)))
+    mat.set_data_manager(n)
+    sig = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+    isv = torch.empty((n, 7), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    idx = torch.cat([torch.arange(0, n, 99_991, device=dev), torch.tensor([n - 1, n - 64, n - 65, 2**31 // 36 + 1, 2**32 // 48 + 3], device=dev)])   # past 2^31 tangent entries / 2^32 stress bytes
+    assert int(idx.max()) < n
+    eps_s = to_host(eps_hat[idx])
+    epsp, p = np.zeros((len(idx), 6)), np.zeros(len(idx))
+    for fac in (0.6, 1.0):
+        eps = eps_hat * fac
+        mat.integrate_device(eps.data_ptr(), sig.data_ptr(), ct.data_ptr(), st)
+        mat.isv_device(1, isv.data_ptr(), st)
+        rc, stats = mat.stats()
+        assert rc == 0 and stats["n_nan"] == 0 and stats["n_points"] == n and stats["n_not_converged"] == 0
+        ref = onp.j2_update(eps_s * fac, epsp, p, E, NU, hard_o)
+        safe = np.abs(ref["f_trial"]) > 1e-9 * SIG0_V
+        for got, exp in ((to_host(sig[idx]), ref["sig"]), (to_host(ct[idx]).reshape(-1, 6, 6), ref["Ct"]),
+                         (to_host(isv[idx, 0]), ref["p"]), (to_host(isv[idx, 1:]), ref["epsp"])):
+            assert np.abs(got[safe] - exp[safe]).max() <= 1e-12 * max(np.abs(exp).max(), 1e-300)
+        assert abs(stats["n_plastic"] / n - ref["plastic"].mean()) < 0.05
+        c3 = ct.view(n, 6, 6)
+        assert float((c3[:, 0, 3] - c3[:, 3, 0]).abs().max()) == 0.0 and float((c3[:, 1, 2] - c3[:, 2, 1]).abs().max()) == 0.0
+        mat.data_manager.update()
+        epsp, p = ref["epsp"], ref["p"]
+        del eps
+    mat.close()
