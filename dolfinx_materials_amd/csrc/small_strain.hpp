@@ -267,7 +267,7 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
         // the stress and wn holds n, to the bit.
         {
           const double rho = 1.0 - 3.0 * mu * beta;
-          wn = rho > 0.0 ? 1.5 * iseq * fast_rcp(rho) : 0.0;
+          wn = rho > 0.0 ? 1.5 * iseq / rho : 0.0;   // (a division: with the 5-instruction reciprocal the fused tet4 Voce variant spills 2 registers)
         }
         const double gamma = 1.0 / (hardening_dR<LAW>(prm, p_n + dp) + 3.0 * mu);
         // Dt = lambda IxI + 2mu Id - 4mu^2 [beta (M - n^n) + gamma n^n]      mfront:66-69
