@@ -351,6 +351,12 @@ struct dxm_material {
   // host-path staging (device side), allocated on first dxm_integrate
   double* d_grad = nullptr;
   double* d_flux = nullptr;
+  // option keep_initial_io: gradient / flux of the initial state s0, kept by swapping with d_grad / d_flux at dxm_advance
+  double* d_grad0 = nullptr;
+  double* d_flux0 = nullptr;
+  int io1_valid = 0;          // bit 0: d_grad holds the gradient of s1, bit 1: d_flux its flux (a completed host-buffer call)
+  int io0_valid = 0;          // the same for d_grad0 / d_flux0 and s0
+  int opt_keep_initial_io = 0;
   double* d_isv = nullptr;
   double* d_ct = nullptr;
   double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
@@ -625,6 +631,8 @@ int dxm_destroy(dxm_material* m) {
   if (m->h_stats) (void)hipHostFree(m->h_stats);
   if (m->d_grad) (void)hipFree(m->d_grad);
   if (m->d_flux) (void)hipFree(m->d_flux);
+  if (m->d_grad0) (void)hipFree(m->d_grad0);
+  if (m->d_flux0) (void)hipFree(m->d_flux0);
   if (m->d_isv) (void)hipFree(m->d_isv);
   if (m->d_ct) (void)hipFree(m->d_ct);
   if (m->d_field) (void)hipFree(m->d_field);
@@ -888,13 +896,40 @@ int dxm_advance(dxm_material* m) {
     m->state[1] = t;
     m->s1_alias = true;
     m->parity ^= 1;   // launches now read / write the other buffer: dxm_launch_generation changes
+    // Gradient and flux of the accepted state stay on the device as those of s0 (option keep_initial_io): the buffers the
+    // last host-buffer call filled become d_grad0 / d_flux0 and the next call fills the other pair -- no copy.  Without a
+    // new state in between (advance twice, advance after revert) s0 keeps what it has; so it does when the state came
+    // from a form of call that has no host arrays (device pointers, a fused displacement for the gradient): like the
+    // caller's own host arrays, the copies follow the host-buffer calls only.
+    if (m->opt_keep_initial_io && m->io1_valid) {
+      if (m->io1_valid & 1) { double* g = m->d_grad0; m->d_grad0 = m->d_grad; m->d_grad = g; }
+      if (m->io1_valid & 2) { double* f = m->d_flux0; m->d_flux0 = m->d_flux; m->d_flux = f; }
+      m->io0_valid |= m->io1_valid;
+    }
+    m->io1_valid = 0;
   }
   return 0;
+}
+
+int dxm_initial_io(const dxm_material* m) { return m ? m->io0_valid : -1; }
+
+int dxm_get_initial_io(dxm_material* m, int kind, double* host_aos) {
+  if (!m) return fail(-1, "null handle");
+  if (kind != 0 && kind != 1) return fail(-1, "kind must be 0 (gradient) or 1 (flux)");
+  if (!(m->io0_valid & (1 << kind)))
+    return fail(-1, "the %s of the initial state is not held on the device (option keep_initial_io, and a host-buffer integrate before dxm_advance)", kind ? "flux" : "gradient");
+  if (m->n == 0) return 0;
+  if (!host_aos) return fail(-1, "null host pointer");
+  DEVICE_GUARD(m);
+  if (int rc = sync_last(m)) return rc;
+  const LawDesc& d = kLaws[m->law];
+  return download_to_host(host_aos, kind ? m->d_flux0 : m->d_grad0, sizeof(double) * m->n * (kind ? d.n_flux : d.n_grad), m->own_stream);
 }
 
 int dxm_revert(dxm_material* m) {
   if (!m) return fail(-1, "null handle");
   m->s1_alias = true;  // s1 <- s0 (generic.py:215-216, jaxmat.py:42-43)
+  m->io1_valid = 0;    // d_grad / d_flux belong to the state that was dropped
   return 0;
 }
 
@@ -938,6 +973,7 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
                         const MeshSource* fused, int tl) {
   if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
     return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
+  m->io1_valid = 0;   // s1 is being rewritten; a host-buffer call that completes sets it again
   const int64_t ntiles = (cnt + WAVE - 1) / WAVE;
   int64_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int64_t cap = (int64_t)m->num_cu * m->blocks_per_cu;
@@ -1390,6 +1426,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   if (m->opt_tune_verbose && host_grad) fprintf(stderr, "[dxm host path] %d chunks of %lld points; issue loop waited %.2f ms for staging copies (first chunk %.2f ms)\n", nchunks, (long long)csize, ms_wait_copy, ms_first_copy);
   if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] all landed at +%.2f ms, workers done %.2f ms later\n", std::chrono::duration<double, std::milli>(t_landed - t_issued).count(), ms_since(t_landed));
   inflight.completed = true;
+  m->io1_valid = (fused ? 0 : 1) | 2;   // d_grad (unless the strain never existed as an array) and d_flux are those of s1
   const auto t_stats = std::chrono::steady_clock::now();
   const int rc_stats = dxm_get_stats(m, stats);
   if (stats) stats->upload = host_grad ? DXM_UPLOAD_STAGED : m->last_upload;
@@ -1981,6 +2018,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
     m->opt_stage_ahead = (int)value;
   }
   else if (k == "register_input") m->opt_register_input = on;
+  else if (k == "keep_initial_io") m->opt_keep_initial_io = on;
   else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;
   else if (k == "query_foreign_pointers") g_query_foreign.store(on ? 1 : 0);   // process-wide
   else if (k == "packed_min_points") {

@@ -92,15 +92,21 @@ class LazyISV(np.lib.mixins.NDArrayOperatorsMixin):
         self.dtype = np.dtype(np.float64)
         self.ndim = 2
 
+    def _serial(self):
+        return self._m._serial
+
+    def _download(self):
+        return self._m._fetch_isv()
+
     def _get(self):
-        if self._seen != self._m._serial:
-            self._value = self._m._fetch_isv()
-            self._seen = self._m._serial
+        if self._seen != self._serial():
+            self._value = self._download()
+            self._seen = self._serial()
         return self._value
 
     @property
     def fetched(self):
-        return self._seen == self._m._serial
+        return self._seen == self._serial()
 
     def __array__(self, dtype=None, copy=None):
         a = self._get()
@@ -125,7 +131,25 @@ class LazyISV(np.lib.mixins.NDArrayOperatorsMixin):
         return getattr(self._get(), name)
 
     def __repr__(self):
-        return f"LazyISV(shape={self.shape}, fetched={self.fetched})"
+        return f"{type(self).__name__}(shape={self.shape}, fetched={self.fetched})"
+
+
+class LazyInitialRows(LazyISV):
+    """Gradient (``kind`` 0) or flux (1) of the INITIAL state s0 -- ``get_initial_state_dict()["Strain"]``,
+    ``generic.py:194-198`` -- kept on the device by ``dxm_advance`` (option ``keep_initial_io``) and downloaded when
+    first looked at.  Used when the host array that held the accepted state is a bound Function that the next update
+    overwrites: accepting an increment then costs a pointer swap instead of a 480 MB host copy per array (1e7 points).
+    A view like :class:`LazyISV`: after a later ``advance`` it shows the then-current s0."""
+
+    def __init__(self, material, shape, kind):
+        super().__init__(material, shape)
+        self._kind = kind
+
+    def _serial(self):
+        return self._m._serial0
+
+    def _download(self):
+        return self._m._fetch_initial_rows(self._kind)
 
 
 class DataManager:
@@ -189,6 +213,7 @@ class HIPMaterial:
         self.jit = bool(jit)
         self.lazy_isv = bool(lazy_isv)
         self._serial = 0
+        self._serial0 = 0     # counts the changes of s0 (advance, set_initial_state_dict)
         self._bound = {}
         self.tangent_layout = tangent_layout
         self.behavior = behavior
@@ -464,8 +489,10 @@ class HIPMaterial:
             a = _as_c(value, (self._n, max(1, dim)))
             if key == self._gname:
                 self._grad[0] = a.copy()
+                self._serial0 += 1
             elif key == self._fname:
                 self._flux[0] = a.copy()
+                self._serial0 += 1
             elif key == "be_bar" and self._info.n_grad == 9:
                 continue  # handled below together with F
             else:
@@ -485,16 +512,43 @@ class HIPMaterial:
                 self._chk(self._lib.dxm_set_state(h, S0, field, ptrs[0]))
 
     def _advance(self):
-        for h in self._handles():
+        self._handles()
+        held = 3
+        for h, lo, hi, _dev in self._parts:
             self._chk(self._lib.dxm_advance(h))
-        # a bound gradient / flux array is overwritten by the next update: the s0 mirrors keep their own copies then
+            if hi > lo:
+                held &= max(0, int(self._lib.dxm_initial_io(h)))
+        # A bound gradient / flux array is overwritten by the next update, so the s0 mirror cannot be that array.  When
+        # every handle kept its device copy (bind_* set option keep_initial_io; bit 0 gradient, bit 1 flux) the mirror is
+        # a lazy view of it, else a snapshot of the array.  Mirrors that are already such views stay (advance twice,
+        # advance after revert: s0 did not change).
         old = (self._grad[0], self._flux[0])
-        self._grad[0] = self._snapshot(self._grad[1]) if "gradient" in self._bound else self._grad[1]
-        self._flux[0] = self._snapshot(self._flux[1]) if "flux" in self._bound else self._flux[1]
+        new = []
+        for kind, (cur, key) in enumerate(((self._grad[1], "gradient"), (self._flux[1], "flux"))):
+            if isinstance(cur, LazyInitialRows):
+                new.append(cur)
+            elif key not in self._bound:
+                new.append(cur)
+            elif held & (1 << kind):
+                new.append(LazyInitialRows(self, cur.shape, kind))
+            else:
+                new.append(self._snapshot(cur))
+        self._grad[0], self._flux[0] = new
+        self._serial0 += 1
         for a in old:   # the mirrors of the increment before: freed off this thread
-            if a is not self._grad[0] and a is not self._flux[0] and not any(a is b for b in self._flux_buf):
+            if isinstance(a, np.ndarray) and a is not self._grad[0] and a is not self._flux[0] and not any(a is b for b in self._flux_buf):
                 _reaper.drop(a)
-        del old, a
+        del old, a, new
+
+    def _fetch_initial_rows(self, kind):
+        """Download the gradient (0) / flux (1) of s0 from the device copies ``dxm_advance`` kept (:class:`LazyInitialRows`)."""
+        mirror = (self._grad, self._flux)[kind][0]
+        if not isinstance(mirror, LazyInitialRows):   # a view that outlived its state: s0 is an ordinary array again
+            return mirror
+        out = np.empty(mirror.shape)
+        self._run([lambda h=h, ptr=ptrs[0]: self._chk(self._lib.dxm_get_initial_io(h, kind, ptr))
+                   for h, lo, hi, ptrs in self._blocks(out) if hi > lo])
+        return out
 
     def _snapshot(self, a):
         """Copy of a (large, C-contiguous) array on several threads (``dxm_host_copy``; numpy copies on one)."""
@@ -549,7 +603,7 @@ class HIPMaterial:
             self._serial += 1
             isv = self._out_isv if eager else LazyISV(self, (self._n, self._info.n_isv_total))
             # the gradient array of the previous call: released off this thread, after the transfers of this call
-            if old is not g and old is not self._grad[0]:
+            if isinstance(old, np.ndarray) and old is not g and old is not self._grad[0]:
                 _reaper.drop(old)
             del old
         return flux, isv, self._out_ct
@@ -689,6 +743,7 @@ class HIPMaterial:
             self._bound[key] = arr
         if "flux" in self._bound:
             self._flux_buf = [self._bound["flux"].reshape(self._n, nf)]
+            self.set_option("keep_initial_io", 1)   # the flux of an accepted state stays on the device (_advance)
         if "tangent" in self._bound:
             self._out_ct = self._bound["tangent"].reshape(self._ct_shape)
 
@@ -707,6 +762,7 @@ class HIPMaterial:
         if gradient.nbytes:
             self._chk(self._lib.dxm_host_register(_ptr(gradient), gradient.nbytes))
         self._bound["gradient"] = gradient
+        self.set_option("keep_initial_io", 1)
 
     def bind_state_outputs(self, arrays):
         """Page-lock in place the caller-owned arrays that receive internal state variables at ``advance`` -- the

@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define DXM_ABI_VERSION 3   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2 */
+#define DXM_ABI_VERSION 4   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2;
+                             * 4: option "keep_initial_io", dxm_initial_io, dxm_get_initial_io */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
 enum {
@@ -156,6 +157,16 @@ int dxm_get_state(dxm_material* m, int which, int field, double* host_aos);
 int dxm_advance(dxm_material* m);
 /* DataManager.revert(): s1 <- s0   (generic.py:215-216, jaxmat.py:42-43) */
 int dxm_revert(dxm_material* m);
+/* The reference's state dictionaries also hold the gradient and the flux of s0 (generic.py:194-201: get_initial_state_dict()
+ * ["Strain"] / ["Stress"]).  The kernels do not need them, so the library keeps no such arrays -- unless option
+ * "keep_initial_io" is set: then dxm_advance keeps the device copies of the gradient and flux of the last host-buffer
+ * dxm_integrate as those of s0 (a pointer swap, +96 B/point of HBM, no copy), for a caller whose own arrays are about to be
+ * overwritten by the next update (the Functions an accelerated QuadratureMap binds).  They follow the host-buffer calls only:
+ * a state produced through device pointers leaves them as they were.  dxm_initial_io: bit 0 set = a gradient is held,
+ * bit 1 = a flux; dxm_get_initial_io downloads one of them (kind 0 gradient, 1 flux) into
+ * host_aos (npoints, n_grad | n_flux). */
+int dxm_initial_io(const dxm_material* m);
+int dxm_get_initial_io(dxm_material* m, int kind, double* host_aos);
 
 /* ---- the hot path: Material.integrate(gradients, dt)  (jaxmat.py:208-234, generic.py:176-189;
  *      consumer quadrature_map.py:321) ------------------------------------------------------ */
@@ -243,6 +254,8 @@ int dxm_notify_replay(dxm_material* m);
  *                            5-10 ms of staging copies by the worker threads.  Arrays on 4 KiB pages register slowly
  *                            (7-17 ms): after three such registrations in a row the handle stages the next 20 calls.  0: always
  *                            stage through the page-locked ring (default 1)
+ *   "keep_initial_io" 0 | 1  dxm_advance keeps the device copies of gradient and flux of the accepted state as those of
+ *                            s0 (dxm_initial_io / dxm_get_initial_io above); default 0
  *   "query_foreign_pointers" 1 | 0  (process-wide) host pointers that this library did not page-lock itself
  *                            (dxm_host_alloc / dxm_host_register) are looked up with hipPointerGetAttributes (1,
  *                            default) or treated as pageable and staged (0)

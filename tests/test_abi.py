@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol():
     lib = _lib.load()
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert lib.dxm_abi_version() == 3
+    assert lib.dxm_abi_version() == 4
 
 
 def test_law_table():

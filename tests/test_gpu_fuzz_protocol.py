@@ -23,12 +23,12 @@ class Model:
     def __init__(self, n):
         self.n = n
         self.sig0 = SIG0_V
-        self.s0 = dict(p=np.zeros(n), epsp=np.zeros((n, 6)), stress=np.zeros((n, 6)))
+        self.s0 = dict(p=np.zeros(n), epsp=np.zeros((n, 6)), stress=np.zeros((n, 6)), strain=np.zeros((n, 6)))
         self.s1 = {k: v.copy() for k, v in self.s0.items()}
 
     def integrate(self, eps):
         r = oracle_c.j2(eps, self.s0["epsp"], self.s0["p"], E, NU, 1, self.sig0, SIGU_V, B_V)
-        self.s1 = dict(p=r["p"].copy(), epsp=r["epsp"].copy(), stress=r["sig"].copy())
+        self.s1 = dict(p=r["p"].copy(), epsp=r["epsp"].copy(), stress=r["sig"].copy(), strain=np.array(eps))
         return r
 
     def update(self):
@@ -50,7 +50,8 @@ def close(a, b, scale):
 
 
 @pytest.mark.parametrize("seed,n,bound,lazy", [(0, 777, False, True), (1, 5000, True, True), (2, 64, False, False),
-                                               (3, 40_000, True, False), (4, 1, False, True), (5, 70_001, False, True)])
+                                               (3, 40_000, True, False), (4, 1, False, True), (5, 70_001, False, True),
+                                               (6, 3000, "io", True), (7, 66_000, "io", True), (8, 130, "io", False)])
 def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     rng = np.random.default_rng(seed)
     beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
@@ -59,6 +60,9 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     if bound:
         flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
         m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+    if bound == "io":   # the gradient Function too (what the accelerated QuadratureMap binds): every update overwrites it, the
+        grad_fn = np.zeros(n * 6)   # s0 mirrors of strain and stress are views of the device copies dxm_advance keeps
+        m.bind_inputs(gradient=grad_fn)
     model = Model(n)
     mu = E / 2 / (1 + NU)
     ey = SIG0_V / (2 * mu) * np.sqrt(2.0 / 3.0)
@@ -76,7 +80,11 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
         if op == "integrate":
             d = rng.standard_normal((n, 6))
             eps = 0.6 * eps + d * (rng.uniform(0, 3.0, n) * ey / np.linalg.norm(d, axis=1))[:, None]
-            sig, isv, ct = m.integrate(eps)
+            if bound == "io":
+                grad_fn[...] = eps.ravel()
+                sig, isv, ct = m.integrate(grad_fn.reshape(n, 6))
+            else:
+                sig, isv, ct = m.integrate(eps)
             ref = model.integrate(eps)
             scale = max(np.abs(ref["sig"]).max(), SIG0_V)
             assert close(sig, ref["sig"], scale) and close(ct, ref["Ct"], np.abs(ref["Ct"]).max())
@@ -123,6 +131,7 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
                 assert close(got["epsp"], st["epsp"], max(np.abs(st["epsp"]).max(), 1e-300) + 1e-30), which
                 if known[which]:
                     assert close(got["stress"], st["stress"], max(np.abs(st["stress"]).max(), SIG0_V)), which
+                    assert np.array_equal(np.asarray(got["strain"]), st["strain"]), which
         elif op == "set":
             # a consistent plastic state: p >= 0 and a deviatoric plastic strain
             p = rng.uniform(0, 2e-3, n)

@@ -102,6 +102,59 @@ def test_isv_is_fetched_on_demand_and_equals_the_eager_download():
     assert np.array_equal(np.asarray(il_old), np.asarray(il_new)) and not np.array_equal(first, np.asarray(il_new))
 
 
+def test_bound_arrays_keep_the_initial_gradient_and_flux_on_the_device():
+    """With the gradient / flux Functions bound (what the accelerated QuadratureMap does) accepting an increment copies
+    nothing on the host: `dxm_advance` keeps the device copies of the last call's strain and stress as those of s0
+    (option keep_initial_io, a pointer swap) and `get_initial_state_dict()` shows them through lazy views."""
+    import ctypes as C
+
+    from dolfinx_materials_amd.hip_material import LazyInitialRows
+
+    n = 70_003
+    m = _j2()
+    m.set_data_manager(n)
+    lib, handle = m._lib, m._handles()[0]
+    flux_fn, jac_fn, grad_fn = np.zeros(n * 6), np.zeros(n * 36), np.zeros(n * 6)
+    h = j2_history(n, seed=21)
+    # without the option nothing is kept (and nothing is allocated for it)
+    m.integrate(h[0])
+    m.data_manager.update()
+    assert lib.dxm_initial_io(handle) == 0
+    assert lib.dxm_get_initial_io(handle, 1, flux_fn.ctypes.data_as(C.c_void_p)) < 0 and b"keep_initial_io" in lib.dxm_last_error()
+    assert isinstance(m.get_initial_state_dict()["stress"], np.ndarray)
+    m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+    m.bind_inputs(gradient=grad_fn)
+    rows = grad_fn.reshape(n, 6)
+    rows[...] = h[1]
+    f1 = np.array(m.integrate(rows)[0])
+    m.data_manager.update()
+    assert lib.dxm_initial_io(handle) == 3
+    s0 = m.get_initial_state_dict()
+    assert isinstance(s0["stress"], LazyInitialRows) and isinstance(s0["strain"], LazyInitialRows) and not s0["stress"].fetched
+    rows[...] = h[2]
+    m.integrate(rows)                                    # overwrites both bound arrays
+    assert not np.array_equal(flux_fn.reshape(n, 6), f1)
+    assert np.array_equal(np.asarray(s0["stress"]), f1) and np.array_equal(np.asarray(s0["strain"]), h[1])
+    assert s0["stress"].shape == (n, 6) and s0["strain"][5, 2] == h[1][5, 2]
+    # revert: the final state shows the same arrays; a second advance without a new state keeps them
+    m.data_manager.revert()
+    assert np.array_equal(np.asarray(m.get_final_state_dict()["stress"]), f1)
+    m.data_manager.update()
+    m.data_manager.update()
+    assert lib.dxm_initial_io(handle) == 3 and np.array_equal(np.asarray(m.get_initial_state_dict()["strain"]), h[1])
+    # a state produced by a device-pointer form has no host arrays: like an unbound mirror, the views keep what they had
+    import torch
+    d_eps, d_flux, d_ct = to_device(h[3]), torch.empty((n, 6), dtype=torch.float64, device="cuda:0"), torch.empty((n, 36), dtype=torch.float64, device="cuda:0")
+    m.integrate_device(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr())
+    torch.cuda.synchronize()
+    m.data_manager.update()
+    assert np.array_equal(np.asarray(m.get_initial_state_dict()["stress"]), f1)
+    # an explicit initial stress replaces the view
+    m.set_initial_state_dict({"stress": np.ones((n, 6))})
+    assert np.array_equal(np.asarray(s0["stress"]), np.ones((n, 6)))
+    m.close()
+
+
 def test_results_are_delivered_into_bound_caller_arrays():
     n = 70_000
     ref_m, m = _j2(), _j2()
