@@ -103,6 +103,8 @@ SYMBOLS = {
     "dxm_set_option": (C.c_int, [_h, C.c_char_p, C.c_double]),
     "dxm_isv_host": (C.c_int, [_h, C.c_int, C.c_void_p]),
     "dxm_host_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "dxm_host_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "dxm_host_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     "dxm_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dxm_host_unregister": (C.c_int, [C.c_void_p]),
     "dxm_host_alloc": (C.c_void_p, [C.c_uint64]),

@@ -781,6 +781,25 @@ class HIPMaterial:
                 self._chk(self._lib.dxm_host_register(_ptr(arr), arr.nbytes))
             self._bound[key] = arr
 
+    def scatter_rows(self, dst, rows, src):
+        """``dst[rows] = src`` for ``(*, w)`` fp64 arrays on several threads (``dxm_host_scatter_rows``): what a map over a
+        subset of the cells does with flux, tangent and state per update (``utils.py:136-143``; numpy's fancy assignment is
+        one core, 1 s per 1e7 tangent blocks).  ``rows``: C-contiguous int64, each row once."""
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        if not (dst.dtype == np.float64 and dst.flags.c_contiguous and dst.ndim == 2 and src.ndim == 2 and src.shape[1] == dst.shape[1]
+                and rows.dtype == np.int64 and rows.flags.c_contiguous and len(rows) == len(src)):
+            dst[rows] = src
+            return
+        self._chk(self._lib.dxm_host_scatter_rows(_ptr(dst), _ptr(src), rows.ctypes.data, len(rows), dst.shape[1], 16))
+
+    def gather_rows(self, src, rows):
+        """``src[rows]`` the same way (``quadrature_map.py:271``: ``_get_vals(field)[self.dofs]``)."""
+        if not (src.dtype == np.float64 and src.flags.c_contiguous and src.ndim == 2 and rows.dtype == np.int64 and rows.flags.c_contiguous):
+            return src[rows]
+        out = np.empty((len(rows), src.shape[1]))
+        self._chk(self._lib.dxm_host_gather_rows(_ptr(out), _ptr(src), rows.ctypes.data, len(rows), src.shape[1], 16))
+        return out
+
     def pinned_array(self, shape):
         """A zero-initialised fp64 array in page-locked host memory that owns its block (``_lib.PinnedArray``)."""
         a = _lib.PinnedArray(shape).array

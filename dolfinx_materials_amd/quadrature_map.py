@@ -63,6 +63,7 @@ class _Plan:
     bound = False             # flux + jacobian_flatten are the material's output arrays
     npoints = 0
     grad_buffers = None       # subset maps: persistent (page-locked where the material can) gradient rows per name
+    rows = None               # subset maps: self.dofs as a C-contiguous int64 index, made once
     device_gradient = None    # (mesh, displacement callable)
 
 
@@ -86,6 +87,8 @@ class AcceleratedUpdate:
         total = {len(rows_of(f, widths[name])) for name, f in {**self.fluxes, **self.internal_state_variables}.items()}
         total.add(len(self.jacobian_flatten.x.array) // self._jacobian_width())
         plan.identity = len(total) == 1 and total.pop() == plan.npoints and bool(np.array_equal(dofs, np.arange(plan.npoints)))
+        if not plan.identity:
+            plan.rows = np.ascontiguousarray(dofs, dtype=np.int64)
         plan.grad_buffers = {}
         width = getattr(m, "tangent_size", None)
         if width is not None and int(width) != self._jacobian_width():
@@ -145,14 +148,23 @@ class AcceleratedUpdate:
         """Rows of ``fun`` that belong to this map, in the order the material sees them (a view for a map over all
         cells, a gathered copy otherwise: ``_get_vals(field)[self.dofs]``, ``quadrature_map.py:271, :283-289``)."""
         r = rows_of(fun, dim)
-        return r if self._accel_plan().identity else r[self.dofs]
+        plan = self._accel_plan()
+        if plan.identity:
+            return r
+        gather = getattr(self.material, "gather_rows", None)   # on several threads where the material offers it
+        return gather(r, plan.rows) if gather is not None else r[self.dofs]
 
     def _put(self, fun, dim, values):
         dst = rows_of(fun, dim)
-        src = np.asarray(values, dtype=np.float64).reshape(self._accel_plan().npoints, dst.shape[1])
-        if self._accel_plan().identity:
+        plan = self._accel_plan()
+        src = np.asarray(values, dtype=np.float64).reshape(plan.npoints, dst.shape[1])
+        if plan.identity:
             if not _same_memory(src, dst):          # bound outputs are already in place
                 dst[...] = src
+            return
+        scatter = getattr(self.material, "scatter_rows", None)
+        if scatter is not None:
+            scatter(dst, plan.rows, src)
         else:
             dst[self.dofs] = src
 

@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define DXM_ABI_VERSION 4   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2;
-                             * 4: option "keep_initial_io", dxm_initial_io, dxm_get_initial_io */
+                             * 4: option "keep_initial_io", dxm_initial_io, dxm_get_initial_io, dxm_host_scatter_rows, dxm_host_gather_rows */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
 enum {
@@ -296,6 +296,12 @@ int dxm_host_free(void* p);
 /* bytes from src to dst (host memory, non-overlapping) on `threads` threads (<= 0: 8): a 480 MB numpy copy takes 50 ms on one
  * core; the Python layer snapshots bound gradient / flux arrays with this when an increment is accepted. */
 int dxm_host_copy(void* dst, const void* src, uint64_t bytes, int threads);
+/* Rows of `width` doubles through an index on `threads` threads (<= 0: 8), host memory, no overlap between dst and src:
+ * scatter: dst[rows[i]] = src[i]; gather: dst[i] = src[rows[i]] for i < n.  What a QuadratureMap over a SUBSET of the cells does
+ * with every array per update (utils.py:136-143 `array[index] = values`, quadrature_map.py:271 `_get_vals(f)[self.dofs]`);
+ * the index holds each row once (the caller's responsibility, as in the reference) and is not range-checked. */
+int dxm_host_scatter_rows(double* dst, const double* src, const int64_t* rows, int64_t n, int width, int threads);
+int dxm_host_gather_rows(double* dst, const double* src, const int64_t* rows, int64_t n, int width, int threads);
 int dxm_host_register(void* p, uint64_t bytes);
 int dxm_host_unregister(void* p);
 

@@ -139,3 +139,26 @@ def test_host_copy_moves_every_byte_without_a_gpu():
         assert lib.dxm_host_copy(dst.ctypes.data + 8, src.ctypes.data, nbytes, threads) == 0
         assert np.array_equal(dst[8:8 + nbytes], src) and not dst[:8].any() and not dst[8 + nbytes:].any()
     assert lib.dxm_host_copy(None, None, 8, 2) < 0
+
+
+def test_row_scatter_and_gather_match_numpy_indexing_without_a_gpu():
+    """`dxm_host_scatter_rows` / `dxm_host_gather_rows`: `array[index] = values` and `array[index]` of `utils.py:136-143` /
+    `quadrature_map.py:271` on several threads (what a QuadratureMap over a subset of the cells does per update)."""
+    import numpy as np
+
+    from dolfinx_materials_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    for n, total, width, threads in ((0, 10, 6, 4), (1, 3, 36, 4), (257, 1000, 1, 4), (20_000, 50_000, 36, 8), (70_001, 70_001, 6, 64), (9000, 20_000, 81, 0)):
+        rows = np.ascontiguousarray(rng.permutation(total)[:n], dtype=np.int64)
+        src = rng.standard_normal((n, width))
+        dst = rng.standard_normal((total, width))
+        want = dst.copy()
+        want[rows] = src
+        assert lib.dxm_host_scatter_rows(dst.ctypes.data, src.ctypes.data, rows.ctypes.data, n, width, threads) == 0
+        assert np.array_equal(dst, want)
+        out = np.full((n, width), np.nan)
+        assert lib.dxm_host_gather_rows(out.ctypes.data, dst.ctypes.data, rows.ctypes.data, n, width, threads) == 0
+        assert np.array_equal(out, dst[rows])
+    assert lib.dxm_host_scatter_rows(None, None, None, 5, 6, 2) < 0
