@@ -78,8 +78,9 @@ SYMBOLS = {
     "dxm_get_state": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     "dxm_advance": (C.c_int, [_h]),
     "dxm_revert": (C.c_int, [_h]),
-    "dxm_initial_io": (C.c_int, [_h]),
-    "dxm_get_initial_io": (C.c_int, [_h, C.c_int, C.c_void_p]),
+    "dxm_io_held": (C.c_int, [_h, C.c_int]),
+    "dxm_get_io": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    "dxm_integrate_rows": (C.c_int, [_h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "dxm_integrate": (
         C.c_int,
         [_h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],

@@ -148,10 +148,18 @@ static void expand_coef_tangent(const double* __restrict__ s, double* __restrict
 #if !defined(__HIP_DEVICE_COMPILE__)
 __attribute__((target("fma")))
 #endif
-static void expand_pack4_tangent(const double* __restrict__ sg, const double* __restrict__ cw, double* __restrict__ d, int64_t n) {
+// With `rows` (a map over a subset of the cells): point p belongs in row rows[p] of the caller's arrays -- its block goes to
+// dbase + rows[p] * 36 and its stress, which landed in the library's own page-locked area, to fdst + rows[p] * 6.
+static void expand_pack4_tangent(const double* __restrict__ sg, const double* __restrict__ cw, double* __restrict__ dbase, int64_t n,
+                                 const int64_t* __restrict__ rows = nullptr, double* __restrict__ fdst = nullptr) {
 #pragma clang fp contract(off)
-  const bool aligned = (reinterpret_cast<uintptr_t>(d) & 15) == 0;
-  for (int64_t p = 0; p < n; ++p, sg += 6, cw += 4, d += 36) {
+  const bool aligned = (reinterpret_cast<uintptr_t>(dbase) & 15) == 0;
+  for (int64_t p = 0; p < n; ++p, sg += 6, cw += 4) {
+    double* d = dbase + (rows ? rows[p] : p) * 36;
+    if (rows) {
+      double* f = fdst + rows[p] * 6;
+      for (int k = 0; k < 6; ++k) f[k] = sg[k];
+    }
     const double k1 = cw[0], k2 = cw[1], k3 = cw[2], w = cw[3];
     const double third = (sg[0] + sg[1] + sg[2]) * SS_THIRD;
     double nv[6];
@@ -210,7 +218,7 @@ static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, do
 struct HostPool {
   // stride 9: J2 coefficients -> 6x6, 4: (c1, c2, c3, w) + the stress rows `aux` -> 6x6, 54: FeFp building blocks -> 9x9,
   // 0: constant block, -1: plain copy of n BYTES
-  struct Job { const double* src; double* dst; int64_t n; int stride; int tag; const double* aux; };
+  struct Job { const double* src; double* dst; int64_t n; int stride; int tag; const double* aux; const int64_t* rows; double* dst2; };
   std::vector<std::thread> threads;
   std::mutex mu;
   std::condition_variable cv, cv_done, cv_copy;
@@ -237,7 +245,7 @@ struct HostPool {
         queue.pop_front();
       }
       if (j.stride == 9) expand_coef_tangent(j.src, j.dst, j.n);
-      else if (j.stride == 4) expand_pack4_tangent(j.aux, j.src, j.dst, j.n);
+      else if (j.stride == 4) expand_pack4_tangent(j.aux, j.src, j.dst, j.n, j.rows, j.dst2);
       else if (j.stride == 54) expand_fefp_tangent(j.src, j.dst, j.n);
       else if (j.stride == -1) memcpy(j.dst, j.src, (size_t)j.n);
       else fill_const_tangent(j.src, j.dst, j.n);
@@ -249,12 +257,14 @@ struct HostPool {
     }
   }
   // rows [0, n) of one chunk, cut into one piece per thread
-  void submit(const double* src, double* dst, int64_t n, int stride, const double* aux = nullptr) {
+  // (rows != nullptr, stride 4 only: dst / dst2 are the BASES of the caller's tangent / flux arrays, rows the index of this chunk)
+  void submit(const double* src, double* dst, int64_t n, int stride, const double* aux = nullptr, const int64_t* rows = nullptr, double* dst2 = nullptr) {
     const int64_t pieces = (int64_t)threads.size();
     const int64_t per = (n + pieces - 1) / pieces;
     std::lock_guard<std::mutex> lk(mu);
     for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * stride, dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0, aux ? aux + o * 6 : nullptr});
+      queue.push_back(Job{src + o * stride, rows ? dst : dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0, aux ? aux + o * 6 : nullptr,
+                          rows ? rows + o : nullptr, dst2});
       ++pending;
     }
     cv.notify_all();
@@ -276,7 +286,7 @@ struct HostPool {
       std::lock_guard<std::mutex> lk(mu);
       for (size_t o = 0; o < bytes; o += per) {
         queue.push_front(Job{reinterpret_cast<const double*>(static_cast<const char*>(src) + o),
-                             reinterpret_cast<double*>(static_cast<char*>(dst) + o), (int64_t)std::min(per, bytes - o), -1, tag, nullptr});
+                             reinterpret_cast<double*>(static_cast<char*>(dst) + o), (int64_t)std::min(per, bytes - o), -1, tag, nullptr, nullptr, nullptr});
         ++pending_copy[tag];
       }
     }
@@ -343,6 +353,7 @@ struct dxm_material {
   int opt_max_chunks = DXM_MAX_CHUNKS;
   HostPool* pool = nullptr;
   double* h_coef = nullptr;               // page-locked (n, 9) landing area of the tangent coefficients
+  double* h_flux = nullptr;               // page-locked (n, 6) landing area of the stress (dxm_integrate_rows)
   double elastic_lm[2] = {0.0, 0.0};      // lambda, mu handed to the constant-block fill
   hipEvent_t chunk_done[DXM_MAX_CHUNKS] = {};
   int num_cu = 256;
@@ -624,6 +635,7 @@ int dxm_destroy(dxm_material* m) {
   (void)sync_last(m);
   delete m->pool;
   if (m->h_coef) (void)hipHostFree(m->h_coef);
+  if (m->h_flux) (void)hipHostFree(m->h_flux);
   for (hipEvent_t e : m->chunk_done) if (e) (void)hipEventDestroy(e);
   if (m->last_event) (void)hipEventDestroy(m->last_event);
   free_state(m);
@@ -911,19 +923,28 @@ int dxm_advance(dxm_material* m) {
   return 0;
 }
 
-int dxm_initial_io(const dxm_material* m) { return m ? m->io0_valid : -1; }
+// which copies the handle holds for state `which`: s1 shows those of s0 while it is served from it (after advance / revert)
+static int io_mask(const dxm_material* m, int which) { return (which == DXM_S0 || m->s1_alias) ? m->io0_valid : m->io1_valid; }
 
-int dxm_get_initial_io(dxm_material* m, int kind, double* host_aos) {
+int dxm_io_held(const dxm_material* m, int which) {
+  if (!m || (which != DXM_S0 && which != DXM_S1)) return -1;
+  return io_mask(m, which);
+}
+
+int dxm_get_io(dxm_material* m, int which, int kind, double* host_aos) {
   if (!m) return fail(-1, "null handle");
+  if (which != DXM_S0 && which != DXM_S1) return fail(-1, "state selector must be DXM_S0 or DXM_S1");
   if (kind != 0 && kind != 1) return fail(-1, "kind must be 0 (gradient) or 1 (flux)");
-  if (!(m->io0_valid & (1 << kind)))
-    return fail(-1, "the %s of the initial state is not held on the device (option keep_initial_io, and a host-buffer integrate before dxm_advance)", kind ? "flux" : "gradient");
+  if (!(io_mask(m, which) & (1 << kind)))
+    return fail(-1, "the %s of that state is not held on the device (a host-buffer integrate; for s0 also option keep_initial_io before dxm_advance)", kind ? "flux" : "gradient");
   if (m->n == 0) return 0;
   if (!host_aos) return fail(-1, "null host pointer");
   DEVICE_GUARD(m);
   if (int rc = sync_last(m)) return rc;
   const LawDesc& d = kLaws[m->law];
-  return download_to_host(host_aos, kind ? m->d_flux0 : m->d_grad0, sizeof(double) * m->n * (kind ? d.n_flux : d.n_grad), m->own_stream);
+  const bool first = which == DXM_S0 || m->s1_alias;
+  const double* src = kind ? (first ? m->d_flux0 : m->d_flux) : (first ? m->d_grad0 : m->d_grad);
+  return download_to_host(host_aos, src, sizeof(double) * m->n * (kind ? d.n_flux : d.n_grad), m->own_stream);
 }
 
 int dxm_revert(dxm_material* m) {
@@ -1239,18 +1260,22 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 template <class Upload>
 static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, double* isv_aos,
                             double* ct_aos, dxm_stats* stats, const MeshSource* fused = nullptr,
-                            const double* host_grad = nullptr) {
+                            const double* host_grad = nullptr, const int64_t* rows = nullptr) {
   const auto t_enter = std::chrono::steady_clock::now();
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
   const int total = isv_total(d);
-  const bool packed = m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && ct_aos != nullptr && n >= m->opt_packed_min_points;
+  // rows (dxm_integrate_rows: J2 laws, full layout, flux and tangent requested): flux_aos / ct_aos are the BASES of larger
+  // arrays, point i is their row rows[i].  Always the 32 B/point form; the stress lands in the library's own page-locked
+  // area and the worker threads that rebuild the blocks put both where they belong -- the caller's arrays see CPU stores only.
+  const bool rowmode = rows != nullptr;
+  const bool packed = rowmode || (m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && ct_aos != nullptr && n >= m->opt_packed_min_points);
   const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
   const bool fefp = d.n_grad == 9;
   // small strain: (c1, c2, c3, w) only -- the direction n is rebuilt from the stress, which the caller receives in
   // page-locked memory as part of the same chunk -- else the nine coefficients
-  const bool pack4 = packed && !constant && !fefp && m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
-                     (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux));
+  const bool pack4 = rowmode || (packed && !constant && !fefp && m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
+                     (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux)));
   const int tl = packed && !constant ? (pack4 ? TL_PACK4 : TL_COEF) : m->tangent_layout;   // layout of this call's launches
   const int np = fefp ? FEFP_REC : (pack4 ? 4 : 9);                     // doubles per point of the packed form
   const int nfull = d.n_flux * d.n_grad;
@@ -1258,6 +1283,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (packed || host_grad) {
     if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * (fefp ? FEFP_REC : 9), hipHostMallocDefault));
+    if (rowmode && !m->h_flux) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_flux), sizeof(double) * n * d.n_flux, hipHostMallocDefault));
     if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
       delete m->pool;
       m->pool = new HostPool(m->opt_host_threads);
@@ -1285,9 +1311,9 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     for (hipEvent_t& e : m->ring_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const bool any = m->opt_pageable_dma;
-  const bool flux_locked = any || page_locked(flux_aos, sizeof(double) * n * d.n_flux);
+  const bool flux_locked = rowmode || any || page_locked(flux_aos, sizeof(double) * n * d.n_flux);   // rowmode: into h_flux
   const bool isv_locked = any || page_locked(isv_aos, sizeof(double) * n * total);
-  const bool ct_locked = any || page_locked(ct_aos, sizeof(double) * n * tangent_size(m));
+  const bool ct_locked = rowmode || any || page_locked(ct_aos, sizeof(double) * n * tangent_size(m));
   int stats_off = 0, issued = 0, submitted = 0;
   hipStream_t streams[2] = {m->own_stream, m->pipe_stream};
   // An early return (a failing HIP call part-way through the chunk loop) leaves kernels, ring copies and downloads of
@@ -1366,7 +1392,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       return rc;
     stats_off += grid;
     if (flux_aos && flux_locked)
-      HIP_TRY(hipMemcpyAsync(flux_aos + off * d.n_flux, m->d_flux + off * d.n_flux,
+      HIP_TRY(hipMemcpyAsync((rowmode ? m->h_flux : flux_aos) + off * d.n_flux, m->d_flux + off * d.n_flux,
                              sizeof(double) * cnt * d.n_flux, hipMemcpyDeviceToHost, st));
     if (isv_aos && total > 0) {
       // the kernel wrote state[1]; s1_alias is cleared below, address it directly
@@ -1390,7 +1416,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && !constant)
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
-        m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, np, pack4 ? flux_aos + o * d.n_flux : nullptr);
+        if (rowmode) m->pool->submit(m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
+        else m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, np, pack4 ? flux_aos + o * d.n_flux : nullptr);
         ++submitted;
       }
   }
@@ -1407,7 +1434,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && !constant && c >= submitted) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-      m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, np, pack4 ? flux_aos + off * d.n_flux : nullptr);
+      if (rowmode) m->pool->submit(m->h_coef + off * np, ct_aos, cnt, np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
+      else m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, np, pack4 ? flux_aos + off * d.n_flux : nullptr);
       submitted = c + 1;
     }
   }
@@ -1436,9 +1464,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
 
 extern "C" {
 
-int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
-                  double* isv_aos, double* ct_aos, dxm_stats* stats) {
-  (void)dt;
+static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_aos, double* isv_aos, double* ct_aos,
+                          dxm_stats* stats, const int64_t* rows) {
   if (!m) return fail(-1, "null handle");
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
@@ -1503,7 +1530,23 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
                              hipMemcpyHostToDevice, st));
     return 0;
   };
-  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats, nullptr, locked_in ? nullptr : grad_aos);
+  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats, nullptr, locked_in ? nullptr : grad_aos, rows);
+}
+
+int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
+                  double* isv_aos, double* ct_aos, dxm_stats* stats) {
+  (void)dt;
+  return integrate_host(m, grad_aos, flux_aos, isv_aos, ct_aos, stats, nullptr);
+}
+
+int dxm_integrate_rows(dxm_material* m, const double* grad_aos, double dt, double* flux_rows, double* ct_rows,
+                       const int64_t* rows, dxm_stats* stats) {
+  (void)dt;
+  if (!m) return fail(-1, "null handle");
+  if (m->n > 0 && (!flux_rows || !ct_rows || !rows)) return fail(-1, "dxm_integrate_rows needs the flux array, the tangent array and the row index");
+  if (!(m->law == DXM_LAW_J2_LINEAR || m->law == DXM_LAW_J2_VOCE) || m->tangent_layout != DXM_TANGENT_FULL)
+    return fail(-1, "dxm_integrate_rows: small-strain J2 laws with the full tangent layout only (others: dxm_integrate + dxm_host_scatter_rows)");
+  return integrate_host(m, grad_aos, flux_rows, nullptr, ct_rows, stats, rows);
 }
 
 void* dxm_host_alloc(uint64_t bytes) {

@@ -141,6 +141,8 @@ class LazyInitialRows(LazyISV):
     overwrites: accepting an increment then costs a pointer swap instead of a 480 MB host copy per array (1e7 points).
     A view like :class:`LazyISV`: after a later ``advance`` it shows the then-current s0."""
 
+    _which = 0
+
     def __init__(self, material, shape, kind):
         super().__init__(material, shape)
         self._kind = kind
@@ -149,7 +151,18 @@ class LazyInitialRows(LazyISV):
         return self._m._serial0
 
     def _download(self):
-        return self._m._fetch_initial_rows(self._kind)
+        return self._m._fetch_io_rows(self._which, self._kind)
+
+
+class LazyFinalRows(LazyInitialRows):
+    """The flux of the FINAL state s1 after :meth:`HIPMaterial.integrate_rows`, whose results went to scattered rows of the
+    caller's arrays: the contiguous ``(N, nf)`` array exists on the device only and is downloaded when somebody asks
+    (``get_final_state_dict()["Stress"]``)."""
+
+    _which = 1
+
+    def _serial(self):
+        return self._m._serial
 
 
 class DataManager:
@@ -409,6 +422,7 @@ class HIPMaterial:
         self._pinned = {}
         self._out_isv = self._out_ct = None
         self._flux_buf = []
+        self._rows_checked = None
 
     # ---- protocol: external state variables (quadrature_map.py:195, :225) --------------------------
     def initialize_external_state_variable(self, name, values):
@@ -517,7 +531,7 @@ class HIPMaterial:
         for h, lo, hi, _dev in self._parts:
             self._chk(self._lib.dxm_advance(h))
             if hi > lo:
-                held &= max(0, int(self._lib.dxm_initial_io(h)))
+                held &= max(0, int(self._lib.dxm_io_held(h, S0)))
         # A bound gradient / flux array is overwritten by the next update, so the s0 mirror cannot be that array.  When
         # every handle kept its device copy (bind_* set option keep_initial_io; bit 0 gradient, bit 1 flux) the mirror is
         # a lazy view of it, else a snapshot of the array.  Mirrors that are already such views stay (advance twice,
@@ -525,7 +539,9 @@ class HIPMaterial:
         old = (self._grad[0], self._flux[0])
         new = []
         for kind, (cur, key) in enumerate(((self._grad[1], "gradient"), (self._flux[1], "flux"))):
-            if isinstance(cur, LazyInitialRows):
+            if isinstance(cur, LazyFinalRows):     # results of integrate_rows: the device copy became that of s0
+                new.append(LazyInitialRows(self, cur.shape, kind))
+            elif isinstance(cur, LazyInitialRows):
                 new.append(cur)
             elif key not in self._bound:
                 new.append(cur)
@@ -540,13 +556,14 @@ class HIPMaterial:
                 _reaper.drop(a)
         del old, a, new
 
-    def _fetch_initial_rows(self, kind):
-        """Download the gradient (0) / flux (1) of s0 from the device copies ``dxm_advance`` kept (:class:`LazyInitialRows`)."""
-        mirror = (self._grad, self._flux)[kind][0]
-        if not isinstance(mirror, LazyInitialRows):   # a view that outlived its state: s0 is an ordinary array again
+    def _fetch_io_rows(self, which, kind):
+        """Download the gradient (0) / flux (1) of s0 / s1 from the device copies of the last host-buffer call
+        (:class:`LazyInitialRows`, :class:`LazyFinalRows`)."""
+        mirror = (self._grad, self._flux)[kind][which]
+        if not isinstance(mirror, LazyInitialRows):   # a view that outlived its state: the mirror is an ordinary array again
             return mirror
         out = np.empty(mirror.shape)
-        self._run([lambda h=h, ptr=ptrs[0]: self._chk(self._lib.dxm_get_initial_io(h, kind, ptr))
+        self._run([lambda h=h, ptr=ptrs[0]: self._chk(self._lib.dxm_get_io(h, which, kind, ptr))
                    for h, lo, hi, ptrs in self._blocks(out) if hi > lo])
         return out
 
@@ -627,7 +644,9 @@ class HIPMaterial:
                 calls.append(lambda h=h, p=p, st=st: entry(h, p[0], dt, p[1], p[2], p[3], C.byref(st)))
             else:
                 calls.append(lambda h=h, p=p, st=st: entry(h, mesh_handle, _ptr(src), dt, p[1], p[2], p[3], C.byref(st)))
-        rcs = self._run(calls)
+        return self._finish_blocks(self._run(calls), recs)
+
+    def _finish_blocks(self, rcs, recs):
         for rc in rcs:
             self._chk(rc)
         self.last_upload = recs[0].upload_mode   # how the gradient array reached the GPU (first block)
@@ -651,6 +670,55 @@ class HIPMaterial:
             cand = self._flux_buf[self._flux_next]
         self._flux_next ^= 1
         return cand
+
+    @property
+    def supports_row_outputs(self):
+        """Whether :meth:`integrate_rows` exists for this law and layout (small-strain J2, full tangent blocks)."""
+        return self.behavior.law in (_lib.LAW_J2_LINEAR, _lib.LAW_J2_VOCE) and self.tangent_layout == "full"
+
+    def integrate_rows(self, gradients, rows, flux, tangent, dt=0):
+        """``integrate`` for a map over a SUBSET of the cells (``dxm_integrate_rows``): ``gradients`` are this material's
+        ``(N, 6)`` points as usual, but ``flux`` / ``tangent`` are the arrays of the quadrature Functions over ALL cells
+        -- ``(M, 6)`` / ``(M, 36)`` (or flat), ``M >= N`` -- and point ``i`` is delivered into their row ``rows[i]``: what
+        ``_update_vals(field, values, cells)`` does with one fancy assignment per array per update
+        (``utils.py:136-143``), done by the threads that rebuild the tangent blocks.  ``rows``: C-contiguous int64, each row
+        once (``QuadratureMap.dofs``).  Returns the internal state variables (lazily, like ``integrate``); the flux of the
+        final state in ``get_final_state_dict()`` is a :class:`LazyFinalRows`."""
+        self._handles()
+        if not self.supports_row_outputs:
+            raise DxmError("integrate_rows: small-strain J2 laws with tangent_layout='full' only (integrate + scatter_rows otherwise)")
+        ng, nf = self._info.n_grad, self._info.n_flux
+        g = _as_c(gradients)
+        if g.shape != (self._n, ng):
+            raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
+        if not (isinstance(rows, np.ndarray) and rows.dtype == np.int64 and rows.flags.c_contiguous and rows.shape == (self._n,)):
+            raise ValueError(f"rows must be a C-contiguous int64 array of {self._n} entries")
+        for name, arr, w in (("flux", flux, nf), ("tangent", tangent, nf * ng)):
+            if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size % w == 0):
+                raise ValueError(f"{name} must be a C-contiguous float64 array of whole rows of {w}")
+        total = min(flux.size // nf, tangent.size // (nf * ng))
+        key = (rows.ctypes.data, self._n, total)
+        if self.__dict__.get("_rows_checked") != key:   # once per index: the library does not range-check it
+            if self._n and (int(rows.min()) < 0 or int(rows.max()) >= total):
+                raise ValueError(f"rows must lie in [0, {total})")
+            self._rows_checked = key
+            self.set_option("keep_initial_io", 1)   # the contiguous flux exists on the device only: advance keeps it for s0
+        old = self._grad[1]
+        self._grad[1] = g
+        recs = [Stats() for _ in self._parts]
+        calls = [lambda h=h, lo=lo, st=st: self._lib.dxm_integrate_rows(h, g.ctypes.data + lo * g.strides[0], float(dt), _ptr(flux), _ptr(tangent),
+                                                                        rows.ctypes.data + lo * 8, C.byref(st))
+                 for (h, lo, hi, _dev), st in zip(self._parts, recs)]
+        self._warm = True
+        rc = self._finish_blocks(self._run(calls), recs)
+        if rc > 0:
+            warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
+        self._flux[1] = LazyFinalRows(self, (self._n, nf), 1)
+        self._serial += 1
+        if isinstance(old, np.ndarray) and old is not g and old is not self._grad[0]:
+            _reaper.drop(old)
+        del old
+        return LazyISV(self, (self._n, self._info.n_isv_total))
 
     def integrate_displacement(self, mesh, u, dt=0):
         """Same as :meth:`integrate`, with the gradient evaluated on the device from the nodal

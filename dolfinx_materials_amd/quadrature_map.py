@@ -17,8 +17,10 @@ same job with what the engine offers:
   page-locks them in place): ``integrate`` delivers into them and nothing is scattered.  The gradient expression is
   evaluated straight into its own Function's memory (``Expression.eval(mesh, cells, values=...)``), which is page-locked
   too, so it is uploaded by DMA without a staging copy -- no gather, no concatenate;
-* a map over a subset of cells keeps a persistent page-locked gradient buffer and scatters rows through ``self.dofs``,
-  the point index the constructor already built (``quadrature_map.py:231-233, :259-260``) -- nothing is rebuilt per call;
+* a map over a subset of cells keeps a persistent page-locked gradient buffer and delivers through ``self.dofs``, the
+  point index the constructor already built (``quadrature_map.py:231-233, :259-260``) -- nothing is rebuilt per call: for
+  the J2 laws the engine stores every point's stress and tangent block straight into its row of the Functions
+  (``HIPMaterial.integrate_rows``), otherwise rows are moved on several threads (``scatter_rows``);
 * NaNs are taken from the kernel's status record (``material.last_stats["n_nan"]``) instead of three host passes;
 * internal state variables cross PCIe when the increment is accepted (``advance``), not in every Newton iteration
   (``refresh_internal_state_variables()`` / ``isv_every_update = True`` for callers that want them earlier);
@@ -64,6 +66,8 @@ class _Plan:
     npoints = 0
     grad_buffers = None       # subset maps: persistent (page-locked where the material can) gradient rows per name
     rows = None               # subset maps: self.dofs as a C-contiguous int64 index, made once
+    row_outputs = False       # subset maps: the material delivers flux and tangent into the Functions' rows itself
+    state_buffers = None      # subset maps: persistent (page-locked) landing rows of the final state per field (advance)
     device_gradient = None    # (mesh, displacement callable)
 
 
@@ -89,7 +93,8 @@ class AcceleratedUpdate:
         plan.identity = len(total) == 1 and total.pop() == plan.npoints and bool(np.array_equal(dofs, np.arange(plan.npoints)))
         if not plan.identity:
             plan.rows = np.ascontiguousarray(dofs, dtype=np.int64)
-        plan.grad_buffers = {}
+            plan.row_outputs = bool(len(self.fluxes) == 1 and plan.npoints > 0 and getattr(m, "supports_row_outputs", False))
+        plan.grad_buffers, plan.state_buffers = {}, {}
         width = getattr(m, "tangent_size", None)
         if width is not None and int(width) != self._jacobian_width():
             raise ValueError(f"the material returns {width} tangent entries per point (a packed tangent_layout) but jacobian_flatten "
@@ -250,6 +255,18 @@ class AcceleratedUpdate:
         if getattr(self, "external_state_variables", None):
             self.update_external_state_variables()
         rotate = getattr(m, "rotation_matrix", None) is not None
+        if plan.row_outputs and not rotate:
+            # a map over a subset of the cells: the engine stores each point's stress and tangent block in its row of the
+            # Functions (the index the constructor built, quadrature_map.py:231-233) -- no scatter afterwards
+            (flux_fun,), (flux_dim,) = self.fluxes.values(), m.fluxes.values()
+            self._last_isv = m.integrate_rows(self._gradient_block(), plan.rows, rows_of(flux_fun, flux_dim),
+                                              rows_of(self.jacobian_flatten, self._jacobian_width()))
+            assert m.last_stats["n_nan"] == 0, "non-finite constitutive update"
+            self.__dict__["_accel_rows_current"] = True     # the flux Function holds the final flux already (advance)
+            if self.isv_every_update:
+                self.refresh_internal_state_variables()
+            return
+        self.__dict__["_accel_rows_current"] = False
         if plan.device_gradient is not None:
             mesh, displacement = plan.device_gradient
             flux, isv, tangent = m.integrate_displacement(mesh, displacement())
@@ -293,6 +310,14 @@ class AcceleratedUpdate:
             for name, dim in sizes.items():
                 if plan.identity and reader is not None:
                     reader(name, rows_of(funs[name], dim))     # device -> the Function's memory, no intermediate array
+                    continue
+                if funs is self.fluxes and self.__dict__.get("_accel_rows_current"):
+                    continue                                   # delivered into its rows by the last update
+                if reader is not None and hasattr(m, "pinned_array"):
+                    buf = plan.state_buffers.get(name)         # device -> page-locked rows (one DMA transfer) -> the map's rows
+                    if buf is None:
+                        buf = plan.state_buffers[name] = m.pinned_array((plan.npoints, max(1, int(dim))))
+                    self._put(funs[name], dim, reader(name, buf))
                     continue
                 if final is None:
                     final = m.get_final_state_dict()

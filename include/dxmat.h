@@ -45,7 +45,8 @@ extern "C" {
 #endif
 
 #define DXM_ABI_VERSION 4   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2;
-                             * 4: option "keep_initial_io", dxm_initial_io, dxm_get_initial_io, dxm_host_scatter_rows, dxm_host_gather_rows */
+                             * 4: option "keep_initial_io", dxm_io_held, dxm_get_io, dxm_integrate_rows, dxm_host_scatter_rows,
+                             *    dxm_host_gather_rows */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
 enum {
@@ -157,16 +158,17 @@ int dxm_get_state(dxm_material* m, int which, int field, double* host_aos);
 int dxm_advance(dxm_material* m);
 /* DataManager.revert(): s1 <- s0   (generic.py:215-216, jaxmat.py:42-43) */
 int dxm_revert(dxm_material* m);
-/* The reference's state dictionaries also hold the gradient and the flux of s0 (generic.py:194-201: get_initial_state_dict()
- * ["Strain"] / ["Stress"]).  The kernels do not need them, so the library keeps no such arrays -- unless option
- * "keep_initial_io" is set: then dxm_advance keeps the device copies of the gradient and flux of the last host-buffer
- * dxm_integrate as those of s0 (a pointer swap, +96 B/point of HBM, no copy), for a caller whose own arrays are about to be
- * overwritten by the next update (the Functions an accelerated QuadratureMap binds).  They follow the host-buffer calls only:
- * a state produced through device pointers leaves them as they were.  dxm_initial_io: bit 0 set = a gradient is held,
- * bit 1 = a flux; dxm_get_initial_io downloads one of them (kind 0 gradient, 1 flux) into
- * host_aos (npoints, n_grad | n_flux). */
-int dxm_initial_io(const dxm_material* m);
-int dxm_get_initial_io(dxm_material* m, int kind, double* host_aos);
+/* The reference's state dictionaries also hold the gradient and the flux of each state (generic.py:194-201:
+ * get_initial_state_dict()["Strain"] / ["Stress"]).  The kernels do not need them and the caller normally has them (they
+ * are what it passed to and received from dxm_integrate) -- unless its own arrays are overwritten by the next update (the
+ * Functions an accelerated QuadratureMap binds) or the results went to scattered rows (dxm_integrate_rows).  The device
+ * copies of the last host-buffer call serve then: dxm_get_io(m, DXM_S1, kind, host_aos) downloads the gradient (kind 0) or
+ * flux (kind 1) of the final state, (npoints, n_grad | n_flux); with option "keep_initial_io" dxm_advance keeps them as those
+ * of s0 (a pointer swap, +96 B/point of HBM, no copy) for dxm_get_io(m, DXM_S0, ...).  They follow the host-buffer calls
+ * only: a state produced through device pointers leaves them as they were.  dxm_io_held(m, which): bit 0 = a gradient is
+ * held for that state, bit 1 = a flux (negative: bad arguments). */
+int dxm_io_held(const dxm_material* m, int which);
+int dxm_get_io(dxm_material* m, int which, int kind, double* host_aos);
 
 /* ---- the hot path: Material.integrate(gradients, dt)  (jaxmat.py:208-234, generic.py:176-189;
  *      consumer quadrature_map.py:321) ------------------------------------------------------ */
@@ -177,6 +179,16 @@ int dxm_get_initial_io(dxm_material* m, int kind, double* host_aos);
  * Reads state s0, writes state s1.  Synchronous.  `stats` may be NULL. */
 int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
                   double* isv_aos, double* ct_aos, dxm_stats* stats);
+/* The same for a QuadratureMap over a SUBSET of the cells (quadrature_map.py:66-73 with `cells`; one map per material in a
+ * multi-material problem): grad_aos (npoints, 6) are the map's own points as above, but flux_rows / ct_rows are the BASES of
+ * the quadrature Functions over ALL cells and point i belongs in their row rows[i] (the `dofs` index the map built once,
+ * quadrature_map.py:231-233) -- what `_update_vals(field, values, cells)` does with a fancy assignment per array per update
+ * (utils.py:136-143).  Of each point 80 B cross PCIe into the library's page-locked landing areas and the worker threads that
+ * rebuild the (6, 6) blocks store them, and the stress, straight into their rows; the caller's arrays need not be page-locked.
+ * Small-strain J2 laws with DXM_TANGENT_FULL (others: dxm_integrate + dxm_host_scatter_rows); the index holds each row once
+ * and is not range-checked; internal state variables: dxm_isv_host / dxm_get_state when needed. */
+int dxm_integrate_rows(dxm_material* m, const double* grad_aos, double dt, double* flux_rows, double* ct_rows,
+                       const int64_t* rows, dxm_stats* stats);
 /* Device-pointer form: all three arrays are device memory on the handle's device (e.g. torch
  * tensors' data_ptr()); the kernel is enqueued on `hip_stream` (a hipStream_t, NULL = default
  * stream) and the call returns without synchronising.  Returns 0 or < 0. */
@@ -255,7 +267,7 @@ int dxm_notify_replay(dxm_material* m);
  *                            (7-17 ms): after three such registrations in a row the handle stages the next 20 calls.  0: always
  *                            stage through the page-locked ring (default 1)
  *   "keep_initial_io" 0 | 1  dxm_advance keeps the device copies of gradient and flux of the accepted state as those of
- *                            s0 (dxm_initial_io / dxm_get_initial_io above); default 0
+ *                            s0 (dxm_get_io above); default 0
  *   "query_foreign_pointers" 1 | 0  (process-wide) host pointers that this library did not page-lock itself
  *                            (dxm_host_alloc / dxm_host_register) are looked up with hipPointerGetAttributes (1,
  *                            default) or treated as pageable and staged (0)

@@ -119,8 +119,8 @@ def test_bound_arrays_keep_the_initial_gradient_and_flux_on_the_device():
     # without the option nothing is kept (and nothing is allocated for it)
     m.integrate(h[0])
     m.data_manager.update()
-    assert lib.dxm_initial_io(handle) == 0
-    assert lib.dxm_get_initial_io(handle, 1, flux_fn.ctypes.data_as(C.c_void_p)) < 0 and b"keep_initial_io" in lib.dxm_last_error()
+    assert lib.dxm_io_held(handle, 0) == 0
+    assert lib.dxm_get_io(handle, 0, 1, flux_fn.ctypes.data_as(C.c_void_p)) < 0 and b"keep_initial_io" in lib.dxm_last_error()
     assert isinstance(m.get_initial_state_dict()["stress"], np.ndarray)
     m.bind_outputs(flux=flux_fn, tangent=jac_fn)
     m.bind_inputs(gradient=grad_fn)
@@ -128,7 +128,7 @@ def test_bound_arrays_keep_the_initial_gradient_and_flux_on_the_device():
     rows[...] = h[1]
     f1 = np.array(m.integrate(rows)[0])
     m.data_manager.update()
-    assert lib.dxm_initial_io(handle) == 3
+    assert lib.dxm_io_held(handle, 0) == 3
     s0 = m.get_initial_state_dict()
     assert isinstance(s0["stress"], LazyInitialRows) and isinstance(s0["strain"], LazyInitialRows) and not s0["stress"].fetched
     rows[...] = h[2]
@@ -141,7 +141,7 @@ def test_bound_arrays_keep_the_initial_gradient_and_flux_on_the_device():
     assert np.array_equal(np.asarray(m.get_final_state_dict()["stress"]), f1)
     m.data_manager.update()
     m.data_manager.update()
-    assert lib.dxm_initial_io(handle) == 3 and np.array_equal(np.asarray(m.get_initial_state_dict()["strain"]), h[1])
+    assert lib.dxm_io_held(handle, 0) == 3 and np.array_equal(np.asarray(m.get_initial_state_dict()["strain"]), h[1])
     # a state produced by a device-pointer form has no host arrays: like an unbound mirror, the views keep what they had
     import torch
     d_eps, d_flux, d_ct = to_device(h[3]), torch.empty((n, 6), dtype=torch.float64, device="cuda:0"), torch.empty((n, 36), dtype=torch.float64, device="cuda:0")
@@ -153,6 +153,74 @@ def test_bound_arrays_keep_the_initial_gradient_and_flux_on_the_device():
     m.set_initial_state_dict({"stress": np.ones((n, 6))})
     assert np.array_equal(np.asarray(s0["stress"]), np.ones((n, 6)))
     m.close()
+
+
+@pytest.mark.parametrize("kind,n,total,devices", [("linear", 300_007, 700_000, None), ("voce", 70_001, 70_001, None), ("linear", 1, 5, None),
+                                                  ("linear", 150_003, 200_000, [0, 0, 0])])
+def test_integrate_rows_delivers_every_point_into_its_row(kind, n, total, devices):
+    """`dxm_integrate_rows` (a QuadratureMap over a subset of the cells): stress and tangent block of point i in row rows[i] of
+    arrays over all cells, bit-identical to `integrate` followed by the fancy assignment of `utils.py:136-143`; rows of other
+    maps untouched; the contiguous flux of the state dictionaries served from the device."""
+    from dolfinx_materials_amd.hip_material import LazyFinalRows, LazyInitialRows
+
+    rng = np.random.default_rng(n)
+    rows = np.ascontiguousarray(rng.permutation(total)[:n], dtype=np.int64)
+    ref_m, m = _j2(kind), _j2(kind, devices=devices)
+    ref_m.set_data_manager(n)
+    m.set_data_manager(n)
+    assert m.supports_row_outputs
+    flux_fn, jac_fn = np.full(total * 6, -7.0), np.full((total, 36), -7.0)     # flat and 2-D both accepted
+    want_f, want_c = flux_fn.reshape(total, 6).copy(), jac_fn.copy()
+    h = j2_history(n, seed=4, sig0=SIG0_V if kind == "voce" else SIG0_LIN)
+    for k, eps in enumerate(h[:3]):
+        f0, i0, c0 = ref_m.integrate(eps)
+        isv = m.integrate_rows(eps, rows, flux_fn, jac_fn)
+        want_f[rows], want_c[rows] = f0, c0.reshape(n, 36)
+        assert np.array_equal(flux_fn.reshape(total, 6), want_f) and np.array_equal(jac_fn, want_c), k
+        assert np.array_equal(np.asarray(isv), np.asarray(i0)) and m.last_stats == ref_m.last_stats
+        s1 = m.get_final_state_dict()
+        assert isinstance(s1["stress"], LazyFinalRows) and np.array_equal(np.asarray(s1["stress"]), f0) and np.array_equal(s1["strain"], eps)
+        ref_m.data_manager.update()
+        m.data_manager.update()
+        s0 = m.get_initial_state_dict()
+        assert isinstance(s0["stress"], LazyInitialRows) and np.array_equal(np.asarray(s0["stress"]), f0)
+        assert np.array_equal(np.asarray(m.get_final_state_dict()["stress"]), f0)      # s1 is served from s0 after advance
+        assert np.array_equal(s0["p"], ref_m.get_initial_state_dict()["p"])
+    # several updates from one s0, then revert: the state dictionaries follow
+    f3 = np.array(ref_m.integrate(h[3])[0])
+    m.integrate_rows(h[3], rows, flux_fn, jac_fn)
+    assert np.array_equal(np.asarray(m.get_final_state_dict()["stress"]), f3) and np.array_equal(np.asarray(m.get_initial_state_dict()["stress"]), f0)
+    m.data_manager.revert()
+    assert np.array_equal(np.asarray(m.get_final_state_dict()["stress"]), f0)
+    # the ordinary form keeps working on the same handle
+    f1, _, c1 = m.integrate(h[3])
+    assert np.array_equal(f1, f3) and isinstance(m.get_final_state_dict()["stress"], np.ndarray)
+    with pytest.raises(ValueError):
+        m.integrate_rows(h[3], rows.astype(np.int32), flux_fn, jac_fn)  # the index is int64
+    with pytest.raises(ValueError):
+        m.integrate_rows(h[3], rows + total, flux_fn, jac_fn)          # out of range
+    m.close()
+    ref_m.close()
+
+
+def test_integrate_rows_is_refused_where_it_does_not_exist():
+    from dolfinx_materials_amd._lib import DxmError
+
+    n = 1000
+    rows = np.arange(n, dtype=np.int64)
+    el = JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU)))
+    el.set_data_manager(n)
+    assert not el.supports_row_outputs
+    with pytest.raises(DxmError):
+        el.integrate_rows(np.zeros((n, 6)), rows, np.zeros(n * 6), np.zeros(n * 36))
+    import ctypes as C
+    assert el._lib.dxm_integrate_rows(el._handles()[0], np.zeros((n, 6)).ctypes.data_as(C.c_void_p), 0.0, np.zeros(n * 6).ctypes.data_as(C.c_void_p),
+                                      np.zeros(n * 36).ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), None) < 0
+    el.close()
+    packed = _j2(tangent_layout="coef")
+    packed.set_data_manager(n)
+    assert not packed.supports_row_outputs
+    packed.close()
 
 
 def test_results_are_delivered_into_bound_caller_arrays():
