@@ -317,7 +317,8 @@ class AcceleratedUpdate:
                     buf = plan.state_buffers.get(name)         # device -> page-locked rows (one DMA transfer) -> the map's rows
                     if buf is None:
                         buf = plan.state_buffers[name] = m.pinned_array((plan.npoints, max(1, int(dim))))
-                    self._put(funs[name], dim, reader(name, buf))
+                    reader(name, buf)
+                    self._put(funs[name], dim, buf)
                     continue
                 if final is None:
                     final = m.get_final_state_dict()

@@ -55,6 +55,31 @@ class EngineLikeMaterial(OracleJ2Material):
             out[...] = src.reshape(out.shape)
 
 
+class RowDeliveringMaterial(EngineLikeMaterial):
+    """... and the members a subset map looks for: results delivered into rows of the Functions (`integrate_rows`), a page-locked
+    landing for the final state at advance (`pinned_array`), threaded row moves."""
+
+    supports_row_outputs = True
+
+    def integrate_rows(self, g, rows, flux, tangent, dt=0):
+        self.calls.append("integrate_rows")
+        assert rows.dtype == np.int64 and rows.flags.c_contiguous and flux.shape[1] == 6 and tangent.shape[1] == 36
+        f, isv, ct = OracleJ2Material.integrate(self, g, dt)
+        flux[rows], tangent[rows] = f, ct.reshape(len(rows), 36)
+        return isv
+
+    def pinned_array(self, shape):
+        self.calls.append("pinned_array")
+        return np.zeros(shape)
+
+    def scatter_rows(self, dst, rows, src):
+        self.calls.append("scatter_rows")
+        dst[rows] = src
+
+    def gather_rows(self, src, rows):
+        return src[rows]
+
+
 def _hard():
     return onp.LinearHardening(SIG0_LIN, H_LIN)
 
@@ -64,7 +89,7 @@ def _fields(qmap):
             "jacobian": qmap.jacobian_flatten.x.array}
 
 
-@pytest.mark.parametrize("material", [OracleJ2Material, EngineLikeMaterial])
+@pytest.mark.parametrize("material", [OracleJ2Material, EngineLikeMaterial, RowDeliveringMaterial])
 @pytest.mark.parametrize("subset", [False, True])
 def test_accelerated_update_equals_the_reference_cadence(material, subset):
     ncell, nqp = 13, 4
@@ -95,6 +120,11 @@ def test_accelerated_update_equals_the_reference_cadence(material, subset):
         other = np.setdiff1d(np.arange(ncell), cells)
         assert not fast.fluxes["stress"].values.reshape(ncell, -1)[other].any()
         assert not fast.jacobian_flatten.values.reshape(ncell, -1)[other].any()
+    if material is RowDeliveringMaterial:   # the subset map hands the Functions and its index to the engine: no scatter of results
+        calls = fast.material.calls
+        assert ("integrate_rows" in calls) == subset and ("bind_outputs" in calls) == (not subset)
+        if subset:   # per update nothing but the ISVs (isv_every_update) is moved by the map itself; flux never
+            assert calls.count("pinned_array") == 1 + 2   # the gradient rows + the two ISV landing buffers
 
 
 def test_internal_state_variables_are_written_at_advance_only_by_default():
