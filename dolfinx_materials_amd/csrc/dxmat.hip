@@ -342,7 +342,7 @@ struct dxm_material {
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
   bool opt_tune_verbose = false;
-  bool opt_register_input = true;         // host path: page-lock a pageable gradient array for the duration of the call (DMA upload)
+  int opt_register_input = 1;             // host path, pageable gradient array: 2 page-lock it for the call (DMA upload), 0 stage it, 1 measure and keep the faster
   int register_skip = 0;                  // calls left that stage instead (the last registrations were expensive: small pages)
   int register_calls = 0, register_slow = 0;
   int last_upload = DXM_UPLOAD_NONE;      // dxm_stats.upload of the last host-buffer call
@@ -376,6 +376,11 @@ struct dxm_material {
   int64_t ring_slot_doubles = 0;
   hipEvent_t ring_done[DXM_RING] = {};
   int opt_stage_ahead = 3;
+  double unregister_ms = 0.0;   // what releasing the call-scoped page-lock of the gradient array took in the last call
+  // option register_input = 1: the handle measures which way a pageable gradient array goes up faster (integrate_host)
+  int up_calls = 0, up_pref = 1, up_since_probe = 0;
+  bool up_probing = false;
+  double up_ms[3] = {0.0, 0.0, 0.0};   // [1] page-locked for the call, [2] staged: best of the calibration calls, then a running mean
 };
 
 static int sync_last(dxm_material* m);
@@ -1464,16 +1469,12 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
 
 extern "C" {
 
-static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_aos, double* isv_aos, double* ct_aos,
-                          dxm_stats* stats, const int64_t* rows) {
-  if (!m) return fail(-1, "null handle");
+// upload_choice: 0 = this call had no choice to make (page-locked input, small batch, option off), else the way the pageable
+// gradient array went up (1 page-locked for the call + DMA, 2 staged by the worker threads); see integrate_host below
+static int integrate_host_impl(dxm_material* m, const double* grad_aos, double* flux_aos, double* isv_aos, double* ct_aos,
+                               dxm_stats* stats, const int64_t* rows, int* upload_choice) {
   const LawDesc& d = kLaws[m->law];
   const int64_t n = m->n;
-  if (n == 0) {
-    if (stats) memset(stats, 0, sizeof(*stats));
-    return 0;
-  }
-  if (!grad_aos) return fail(-1, "null gradient pointer");
   DEVICE_GUARD(m);
   // a page-locked gradient array is uploaded by DMA; so is a pageable one if the caller asked for it (option pageable_dma)
   const auto t_in = std::chrono::steady_clock::now();
@@ -1486,11 +1487,40 @@ static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_
   // registered one, memory that cannot be pinned) falls back to the staging ring.
   struct TempRegistration {
     void* p = nullptr;
-    ~TempRegistration() { if (p) { forget_locked(p); (void)hipHostUnregister(p); (void)hipGetLastError(); } }
+    dxm_material* m = nullptr;
+    ~TempRegistration() {
+      if (!p) return;
+      const auto t0 = std::chrono::steady_clock::now();
+      forget_locked(p);
+      (void)hipHostUnregister(p);
+      (void)hipGetLastError();
+      m->unregister_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] releasing the page-lock of the gradient array took %.3f ms\n", m->unregister_ms);
+    }
   } temp;
+  temp.m = m;
   if (!locked_in && m->opt_register_input && (size_t)n * d.n_grad * sizeof(double) >= ((size_t)1 << 20)) {
-    if (m->register_skip > 0) {
+    // Which of the two is faster depends on the host (where the caller's pages sit relative to the GPU, what else runs on the
+    // machine): DMA out of a freshly page-locked range is 2-3 ms ahead of the staging ring on most boxes of the pool and 5-9 ms
+    // behind on some (profiles/r03_hostpath_adaptive_upload.md).  With option register_input = 1 the handle finds out: its
+    // first call is not judged (one-time set-up), calls 2-5 alternate between the two ways, the faster one (by the call's
+    // whole duration; page-locking wins a tie within 5 %) is kept, and the other gets one call in 32 to prove itself.
+    // 2 = always page-lock, 0 = always stage.
+    int way = 1;
+    if (m->opt_register_input == 1) {
+      const int k = m->up_calls;
+      if (k >= 1 && k <= 4) way = (k % 2 == 1) ? 1 : 2;
+      else if (k > 4) {
+        way = m->up_pref;
+        if (++m->up_since_probe >= 32) { way = 3 - m->up_pref; m->up_probing = true; m->up_since_probe = 0; }
+      }
+    }
+    *upload_choice = way;
+    if (way == 2) {
+      // staged through the ring
+    } else if (m->register_skip > 0) {
       --m->register_skip;
+      *upload_choice = 2;
     } else {
       void* p = const_cast<double*>(grad_aos);
       const size_t bytes = sizeof(double) * n * d.n_grad;
@@ -1500,7 +1530,9 @@ static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_
         locked_in = true;
         // 0.9 ms per 480 MB on transparent huge pages (what numpy asks for), 7-17 ms on 4 KiB pages, where the whole call
         // then takes 43 instead of 28 ms: such arrays go through the staging ring for the next 20 calls, then one more try
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const double ms_lock = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] page-locking the gradient array took %.3f ms (releasing it after the previous call: %.3f ms)\n", ms_lock, m->unregister_ms);
+        const double ms = ms_lock + m->unregister_ms;   // what the previous call paid to release its range counts too
         const double ms_per_gb = ms > 0.5 ? (ms - 0.5) / ((double)bytes / 1e9) : 0.0;   // half a millisecond of fixed cost is fine for any size
         // (the first registration of a handle also pays for one-time set-up in the runtime and is not judged; three expensive
         // ones in a row -- above 10 ms/GB: a loaded host makes a huge-page registration take 2-4 ms now and then -- are)
@@ -1512,6 +1544,7 @@ static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_
       } else {
         (void)hipGetLastError();
         m->register_skip = 20;
+        *upload_choice = 2;
       }
     }
   }
@@ -1531,6 +1564,43 @@ static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_
     return 0;
   };
   return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats, nullptr, locked_in ? nullptr : grad_aos, rows);
+}
+
+static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_aos, double* isv_aos, double* ct_aos,
+                          dxm_stats* stats, const int64_t* rows) {
+  if (!m) return fail(-1, "null handle");
+  if (m->n == 0) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    return 0;
+  }
+  if (!grad_aos) return fail(-1, "null gradient pointer");
+  int way = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = integrate_host_impl(m, grad_aos, flux_aos, isv_aos, ct_aos, stats, rows, &way);
+  if (rc < 0 || way == 0 || m->opt_register_input != 1) return rc;
+  // the adaptive choice between page-locking the caller's gradient array for the call and staging it (see above)
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const int k = m->up_calls++;
+  if (k == 0) return rc;
+  if (k <= 4) {
+    m->up_ms[way] = m->up_ms[way] == 0.0 ? ms : std::min(m->up_ms[way], ms);
+    if (k == 4) {
+      m->up_pref = (m->up_ms[2] > 0.0 && m->up_ms[1] > 0.0 && m->up_ms[2] < 0.95 * m->up_ms[1]) ? 2 : 1;
+      if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] gradient upload: page-locked for the call %.2f ms, staged %.2f ms per call -> %s\n",
+                                       m->up_ms[1], m->up_ms[2], m->up_pref == 1 ? "page-locking" : "staging");
+    }
+  } else if (m->up_probing) {
+    m->up_probing = false;
+    const bool better = way == 2 ? ms < 0.95 * m->up_ms[m->up_pref] : ms < 1.05 * m->up_ms[m->up_pref];
+    if (way != m->up_pref && better) {
+      if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] gradient upload: switching to %s (%.2f against %.2f ms)\n", way == 1 ? "page-locking" : "staging", ms, m->up_ms[m->up_pref]);
+      m->up_pref = way;
+    }
+    m->up_ms[way] = ms;
+  } else {
+    m->up_ms[way] = 0.75 * m->up_ms[way] + 0.25 * ms;
+  }
+  return rc;
 }
 
 int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
@@ -2060,7 +2130,11 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
     if (!(value >= 1 && value <= DXM_RING - 2)) return fail(-1, "stage_ahead must be in [1, %d]", DXM_RING - 2);
     m->opt_stage_ahead = (int)value;
   }
-  else if (k == "register_input") m->opt_register_input = on;
+  else if (k == "register_input") {
+    if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(-1, "register_input must be 0, 1 or 2");
+    m->opt_register_input = (int)value;
+    m->up_calls = 0; m->up_pref = 1; m->up_since_probe = 0; m->up_probing = false; m->up_ms[1] = m->up_ms[2] = 0.0;
+  }
   else if (k == "keep_initial_io") m->opt_keep_initial_io = on;
   else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;
   else if (k == "query_foreign_pointers") g_query_foreign.store(on ? 1 : 0);   // process-wide

@@ -260,12 +260,15 @@ int dxm_notify_replay(dxm_material* m);
  *                            the tangent with n = dev(stress) w, so the host rebuilds n from the stress it receives
  *                            anyway (needs a flux destination in page-locked / registered memory, else as 1); FeFp
  *                            as 1.  0: the full block crosses PCIe.  All three deliver the same bits
- *   "register_input" 1 | 0   host-buffer form: a gradient array in ordinary (pageable) memory is page-locked for the
+ *   "register_input" 2 | 1 | 0  host-buffer form, gradient array in ordinary (pageable) memory.  2: page-locked for the
  *                            duration of the call (hipHostRegister ... hipHostUnregister before the call returns) and
- *                            uploaded by DMA: ~1 ms per 480 MB on transparent huge pages (numpy's default), instead of
- *                            5-10 ms of staging copies by the worker threads.  Arrays on 4 KiB pages register slowly
- *                            (7-17 ms): after three such registrations in a row the handle stages the next 20 calls.  0: always
- *                            stage through the page-locked ring (default 1)
+ *                            uploaded by DMA: ~1 ms per 480 MB on transparent huge pages (numpy's default).  Arrays on
+ *                            4 KiB pages register slowly (7-17 ms): after three such registrations in a row the handle
+ *                            stages the next 20 calls.  0: always staged through the page-locked ring by the worker
+ *                            threads.  1 (default): the handle measures -- calls 2-5 alternate between the two, the
+ *                            faster (by the whole call; page-locking wins within 5 %) is kept and the other one is
+ *                            tried again once in 32 calls; which one wins depends on the host (2-3 ms either way on
+ *                            most, 5-9 ms for staging on some).  dxm_stats.upload reports what each call did
  *   "keep_initial_io" 0 | 1  dxm_advance keeps the device copies of gradient and flux of the accepted state as those of
  *                            s0 (dxm_get_io above); default 0
  *   "query_foreign_pointers" 1 | 0  (process-wide) host pointers that this library did not page-lock itself

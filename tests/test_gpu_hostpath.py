@@ -465,8 +465,42 @@ def test_every_level_of_packed_transfer_delivers_the_same_bits(kind, n):
         m.close()
 
 
+def test_the_handle_measures_how_a_pageable_gradient_array_goes_up_fastest():
+    """Default (`register_input` = 1): the first call page-locks, calls 2-5 alternate between page-locking for the call and the
+    staging ring, then the faster way is kept (which one depends on the host) with one trial of the other in 32 calls; every call
+    delivers the same bits, and `last_upload` says what it did."""
+    n = 400_003
+    hist = j2_history(n, seed=8)
+    a, b = _j2(), _j2()
+    a.set_data_manager(n)
+    b.set_data_manager(n)
+    b.set_option("register_input", 0)
+    ways = []
+    for k in range(45):
+        eps = hist[1 + k % 3]
+        fa, _, ca = a.integrate(np.array(eps))
+        ways.append(a.last_upload)
+        if k < 8 or k % 9 == 0:
+            fb, _, cb = b.integrate(np.array(eps))
+            assert np.array_equal(fa, fb) and np.array_equal(ca, cb), k
+    locked, staged = "dma (page-locked for the call)", "staged through the ring"
+    assert ways[:5] == [locked, locked, staged, locked, staged]
+    kept = ways[5]
+    assert kept in (locked, staged)
+    other = staged if kept == locked else locked
+    assert ways[5:36] == [kept] * 31 and ways[36] == other            # the 32nd call after the calibration tries the other way
+    assert all(w in (locked, staged) for w in ways[37:])
+    a.set_option("register_input", 1)                                  # setting the option starts the measurement again
+    a.integrate(np.array(hist[1]))
+    a.integrate(np.array(hist[1]))
+    a.integrate(np.array(hist[1]))
+    assert a.last_upload == staged
+    a.close()
+    b.close()
+
+
 def test_pageable_gradient_is_page_locked_for_the_call_only():
-    """`register_input` (default): a gradient array in ordinary memory is registered for the duration of `dxm_integrate`
+    """`register_input` = 2: a gradient array in ordinary memory is registered for the duration of `dxm_integrate`
     and uploaded by DMA; staged through the ring with the option off.  Same bits either way, and the range is unregistered
     again when the call returns: registering it explicitly afterwards succeeds (a range that is still registered is
     refused by the runtime), also after a call that fails part-way."""
@@ -475,6 +509,7 @@ def test_pageable_gradient_is_page_locked_for_the_call_only():
     a, b = _j2(), _j2()
     a.set_data_manager(n)
     b.set_data_manager(n)
+    a.set_option("register_input", 2)
     b.set_option("register_input", 0)
     lib = a._lib
     for eps in hist[:3]:
