@@ -187,9 +187,16 @@ static void expand_pack4_tangent(const double* __restrict__ sg, const double* __
 #if !defined(__HIP_DEVICE_COMPILE__)
 __attribute__((target("fma")))
 #endif
-static void expand_fefp_tangent(const double* __restrict__ s, double* __restrict__ d, int64_t n) {
+// (rows / fdst / pk as in expand_pack4_tangent: block to dbase + rows[p] * 81, the stress pk[p] to fdst + rows[p] * 9)
+static void expand_fefp_tangent(const double* __restrict__ s, double* __restrict__ dbase, int64_t n, const int64_t* __restrict__ rows = nullptr,
+                                double* __restrict__ fdst = nullptr, const double* __restrict__ pk = nullptr) {
   static const int TI[9] = {0, 1, 2, 0, 1, 0, 2, 1, 2}, TJ[9] = {0, 1, 2, 1, 0, 2, 0, 2, 1};
-  for (int64_t p = 0; p < n; ++p, s += 54, d += 81) {
+  for (int64_t p = 0; p < n; ++p, s += 54) {
+    double* d = dbase + (rows ? rows[p] : p) * 81;
+    if (rows) {
+      double* f = fdst + rows[p] * 9;
+      for (int k = 0; k < 9; ++k) f[k] = pk[p * 9 + k];
+    }
     const double* fi = s;
     for (int r = 0; r < 9; ++r) {
       const int i = TI[r], J = TJ[r];
@@ -206,12 +213,17 @@ static void expand_fefp_tangent(const double* __restrict__ s, double* __restrict
 }
 
 // elastic law: the same constant block for every point
-static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, double* __restrict__ d, int64_t n) {
+static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, double* __restrict__ dbase, int64_t n, const int64_t* __restrict__ rows = nullptr,
+                               double* __restrict__ fdst = nullptr, const double* __restrict__ sg = nullptr) {
   double o[36];
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < 6; ++j) o[i * 6 + j] = ((i < 3 && j < 3) ? s[0] : 0.0) + ((i == j) ? 2.0 * s[1] : 0.0);
-  for (int64_t p = 0; p < n; ++p, d += 36)
+  for (int64_t p = 0; p < n; ++p) {
+    double* d = dbase + (rows ? rows[p] : p) * 36;
     for (int k = 0; k < 36; ++k) d[k] = o[k];
+    if (rows)
+      for (int k = 0; k < 6; ++k) fdst[rows[p] * 6 + k] = sg[p * 6 + k];
+  }
 }
 
 // A few persistent worker threads per handle (created on the first host-path call that needs them).
@@ -246,9 +258,9 @@ struct HostPool {
       }
       if (j.stride == 9) expand_coef_tangent(j.src, j.dst, j.n);
       else if (j.stride == 4) expand_pack4_tangent(j.aux, j.src, j.dst, j.n, j.rows, j.dst2);
-      else if (j.stride == 54) expand_fefp_tangent(j.src, j.dst, j.n);
+      else if (j.stride == 54) expand_fefp_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
       else if (j.stride == -1) memcpy(j.dst, j.src, (size_t)j.n);
-      else fill_const_tangent(j.src, j.dst, j.n);
+      else fill_const_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
       {
         std::lock_guard<std::mutex> lk(mu);
         if (j.stride == -1) { if (--pending_copy[j.tag] == 0) cv_copy.notify_all(); }
@@ -257,13 +269,15 @@ struct HostPool {
     }
   }
   // rows [0, n) of one chunk, cut into one piece per thread
-  // (rows != nullptr, stride 4 only: dst / dst2 are the BASES of the caller's tangent / flux arrays, rows the index of this chunk)
+  // (rows != nullptr: dst / dst2 are the BASES of the caller's tangent / flux arrays, rows the index of this chunk, aux the
+  // stress of the chunk where it landed)
   void submit(const double* src, double* dst, int64_t n, int stride, const double* aux = nullptr, const int64_t* rows = nullptr, double* dst2 = nullptr) {
     const int64_t pieces = (int64_t)threads.size();
     const int64_t per = (n + pieces - 1) / pieces;
+    const int nf = stride == 54 ? 9 : 6;
     std::lock_guard<std::mutex> lk(mu);
     for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * stride, rows ? dst : dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0, aux ? aux + o * 6 : nullptr,
+      queue.push_back(Job{src + o * stride, rows ? dst : dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0, aux ? aux + o * nf : nullptr,
                           rows ? rows + o : nullptr, dst2});
       ++pending;
     }
@@ -1279,8 +1293,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const bool fefp = d.n_grad == 9;
   // small strain: (c1, c2, c3, w) only -- the direction n is rebuilt from the stress, which the caller receives in
   // page-locked memory as part of the same chunk -- else the nine coefficients
-  const bool pack4 = rowmode || (packed && !constant && !fefp && m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
-                     (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux)));
+  const bool pack4 = packed && !constant && !fefp && (rowmode || (m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
+                     (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux))));
   const int tl = packed && !constant ? (pack4 ? TL_PACK4 : TL_COEF) : m->tangent_layout;   // layout of this call's launches
   const int np = fefp ? FEFP_REC : (pack4 ? 4 : 9);                     // doubles per point of the packed form
   const int nfull = d.n_flux * d.n_grad;
@@ -1347,7 +1361,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       p->wait();
     }
   } drain{(packed || host_grad) ? m->pool : nullptr};
-  if (constant) m->pool->submit(m->elastic_lm, ct_aos, n, 0);   // nothing to wait for
+  if (constant && !rowmode) m->pool->submit(m->elastic_lm, ct_aos, n, 0);   // nothing to wait for
   // chunk p of the caller's pageable gradient array -> its ring slot, by the worker threads, asynchronously
   auto stage_chunk = [&](int p) -> int {
     const int64_t o = (int64_t)p * csize;
@@ -1418,10 +1432,10 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     issued = c + 1;
     // a pageable upload blocks this thread for its whole duration, so earlier chunks land while the later ones are
     // still being issued: hand them to the workers now, not after the loop
-    if (packed && !constant)
+    if (packed && (!constant || rowmode))
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
-        if (rowmode) m->pool->submit(m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
+        if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, constant ? 0 : np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
         else m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, np, pack4 ? flux_aos + o * d.n_flux : nullptr);
         ++submitted;
       }
@@ -1436,10 +1450,10 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   for (int c = 0; c < issued; ++c) {
     HIP_TRY(hipEventSynchronize(m->chunk_done[c]));
     if (m->opt_tune_verbose && (c % 8 == 7 || c == 0)) fprintf(stderr, "[dxm host path] chunk %d landed at +%.2f ms after issue (issue loop took %.2f ms)\n", c, ms_since(t_issued), std::chrono::duration<double, std::milli>(t_issued - t_enter).count());
-    if (packed && !constant && c >= submitted) {
+    if (packed && (!constant || rowmode) && c >= submitted) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-      if (rowmode) m->pool->submit(m->h_coef + off * np, ct_aos, cnt, np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
+      if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + off * np, ct_aos, cnt, constant ? 0 : np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
       else m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, np, pack4 ? flux_aos + off * d.n_flux : nullptr);
       submitted = c + 1;
     }
@@ -1614,8 +1628,8 @@ int dxm_integrate_rows(dxm_material* m, const double* grad_aos, double dt, doubl
   (void)dt;
   if (!m) return fail(-1, "null handle");
   if (m->n > 0 && (!flux_rows || !ct_rows || !rows)) return fail(-1, "dxm_integrate_rows needs the flux array, the tangent array and the row index");
-  if (!(m->law == DXM_LAW_J2_LINEAR || m->law == DXM_LAW_J2_VOCE) || m->tangent_layout != DXM_TANGENT_FULL)
-    return fail(-1, "dxm_integrate_rows: small-strain J2 laws with the full tangent layout only (others: dxm_integrate + dxm_host_scatter_rows)");
+  if (m->tangent_layout != DXM_TANGENT_FULL)
+    return fail(-1, "dxm_integrate_rows: the full tangent layout only (packed layouts: dxm_integrate + dxm_host_scatter_rows)");
   return integrate_host(m, grad_aos, flux_rows, nullptr, ct_rows, stats, rows);
 }
 

@@ -673,20 +673,20 @@ class HIPMaterial:
 
     @property
     def supports_row_outputs(self):
-        """Whether :meth:`integrate_rows` exists for this law and layout (small-strain J2, full tangent blocks)."""
-        return self.behavior.law in (_lib.LAW_J2_LINEAR, _lib.LAW_J2_VOCE) and self.tangent_layout == "full"
+        """Whether :meth:`integrate_rows` exists for this material (full tangent blocks; every law)."""
+        return self.tangent_layout == "full"
 
     def integrate_rows(self, gradients, rows, flux, tangent, dt=0):
         """``integrate`` for a map over a SUBSET of the cells (``dxm_integrate_rows``): ``gradients`` are this material's
-        ``(N, 6)`` points as usual, but ``flux`` / ``tangent`` are the arrays of the quadrature Functions over ALL cells
-        -- ``(M, 6)`` / ``(M, 36)`` (or flat), ``M >= N`` -- and point ``i`` is delivered into their row ``rows[i]``: what
+        ``(N, ng)`` points as usual, but ``flux`` / ``tangent`` are the arrays of the quadrature Functions over ALL cells
+        -- ``(M, nf)`` / ``(M, nf * ng)`` (or flat), ``M >= N`` -- and point ``i`` is delivered into their row ``rows[i]``: what
         ``_update_vals(field, values, cells)`` does with one fancy assignment per array per update
         (``utils.py:136-143``), done by the threads that rebuild the tangent blocks.  ``rows``: C-contiguous int64, each row
         once (``QuadratureMap.dofs``).  Returns the internal state variables (lazily, like ``integrate``); the flux of the
         final state in ``get_final_state_dict()`` is a :class:`LazyFinalRows`."""
         self._handles()
         if not self.supports_row_outputs:
-            raise DxmError("integrate_rows: small-strain J2 laws with tangent_layout='full' only (integrate + scatter_rows otherwise)")
+            raise DxmError("integrate_rows: tangent_layout='full' only (integrate + scatter_rows otherwise)")
         ng, nf = self._info.n_grad, self._info.n_flux
         g = _as_c(gradients)
         if g.shape != (self._n, ng):

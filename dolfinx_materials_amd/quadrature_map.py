@@ -18,9 +18,9 @@ same job with what the engine offers:
   evaluated straight into its own Function's memory (``Expression.eval(mesh, cells, values=...)``), which is page-locked
   too, so it is uploaded by DMA without a staging copy -- no gather, no concatenate;
 * a map over a subset of cells keeps a persistent page-locked gradient buffer and delivers through ``self.dofs``, the
-  point index the constructor already built (``quadrature_map.py:231-233, :259-260``) -- nothing is rebuilt per call: for
-  the J2 laws the engine stores every point's stress and tangent block straight into its row of the Functions
-  (``HIPMaterial.integrate_rows``), otherwise rows are moved on several threads (``scatter_rows``);
+  point index the constructor already built (``quadrature_map.py:231-233, :259-260``) -- nothing is rebuilt per call: the
+  engine stores every point's stress and tangent block straight into its row of the Functions
+  (``HIPMaterial.integrate_rows``); rows of other arrays are moved on several threads (``scatter_rows``);
 * NaNs are taken from the kernel's status record (``material.last_stats["n_nan"]``) instead of three host passes;
 * internal state variables cross PCIe when the increment is accepted (``advance``), not in every Newton iteration
   (``refresh_internal_state_variables()`` / ``isv_every_update = True`` for callers that want them earlier);

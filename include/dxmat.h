@@ -180,13 +180,14 @@ int dxm_get_io(dxm_material* m, int which, int kind, double* host_aos);
 int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* flux_aos,
                   double* isv_aos, double* ct_aos, dxm_stats* stats);
 /* The same for a QuadratureMap over a SUBSET of the cells (quadrature_map.py:66-73 with `cells`; one map per material in a
- * multi-material problem): grad_aos (npoints, 6) are the map's own points as above, but flux_rows / ct_rows are the BASES of
+ * multi-material problem): grad_aos (npoints, n_grad) are the map's own points as above, but flux_rows / ct_rows are the BASES of
  * the quadrature Functions over ALL cells and point i belongs in their row rows[i] (the `dofs` index the map built once,
  * quadrature_map.py:231-233) -- what `_update_vals(field, values, cells)` does with a fancy assignment per array per update
  * (utils.py:136-143).  Of each point 80 B cross PCIe into the library's page-locked landing areas and the worker threads that
  * rebuild the (6, 6) blocks store them, and the stress, straight into their rows; the caller's arrays need not be page-locked.
- * Small-strain J2 laws with DXM_TANGENT_FULL (others: dxm_integrate + dxm_host_scatter_rows); the index holds each row once
- * and is not range-checked; internal state variables: dxm_isv_host / dxm_get_state when needed. */
+ * (The elastic law's constant block is filled in by the same threads, the FeFp laws move their 54 building blocks + 9 stress
+ * components per point.)  DXM_TANGENT_FULL only (packed layouts: dxm_integrate + dxm_host_scatter_rows); the index holds each
+ * row once and is not range-checked; internal state variables: dxm_isv_host / dxm_get_state when needed. */
 int dxm_integrate_rows(dxm_material* m, const double* grad_aos, double dt, double* flux_rows, double* ct_rows,
                        const int64_t* rows, dxm_stats* stats);
 /* Device-pointer form: all three arrays are device memory on the handle's device (e.g. torch

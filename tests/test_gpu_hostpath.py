@@ -203,23 +203,52 @@ def test_integrate_rows_delivers_every_point_into_its_row(kind, n, total, device
     ref_m.close()
 
 
-def test_integrate_rows_is_refused_where_it_does_not_exist():
+@pytest.mark.parametrize("law,n,total", [("elastic", 70_001, 90_000), ("elastic", 300, 300), ("fefp", 40_003, 50_000), ("fefp", 129, 700)])
+def test_integrate_rows_for_the_elastic_and_the_finite_strain_law(law, n, total):
+    """The same for the laws whose tangent does not come from (c1, c2, c3, w): the elastic law's constant block is filled in at
+    the rows, the FeFp law's 9x9 block is rebuilt from its 54 building blocks there; both sides of the packed-transfer threshold."""
+    from helpers import SIG0_F, SIGU_F, B_F, fefp_path
+
+    def make():
+        el = jm.LinearElasticIsotropic(E=E, nu=NU)
+        return JAXMaterial(jm.ElasticBehavior(el) if law == "elastic" else jm.FeFpJ2Plasticity(el, jm.VoceHardening(SIG0_F, SIGU_F, B_F)))
+
+    rng = np.random.default_rng(n)
+    rows = np.ascontiguousarray(rng.permutation(total)[:n], dtype=np.int64)
+    ref_m, m = make(), make()
+    ref_m.set_data_manager(n)
+    m.set_data_manager(n)
+    nf = 6 if law == "elastic" else 9
+    hist = j2_history(n, seed=2)[:3] if law == "elastic" else fefp_path(n, nsteps=4, eps=3e-2)
+    flux_fn, jac_fn = np.full((total, nf), 3.0), np.full((total, nf * nf), 3.0)
+    want_f, want_c = flux_fn.copy(), jac_fn.copy()
+    for k, g in enumerate(hist):
+        f0, i0, c0 = ref_m.integrate(g)
+        isv = m.integrate_rows(g, rows, flux_fn, jac_fn)
+        want_f[rows], want_c[rows] = f0, np.asarray(c0).reshape(n, nf * nf)
+        assert np.array_equal(flux_fn, want_f) and np.array_equal(jac_fn, want_c), k
+        assert np.array_equal(np.asarray(isv), np.asarray(i0)) and m.last_stats == ref_m.last_stats
+        assert np.array_equal(np.asarray(m.get_final_state_dict()[m._fname]), f0)
+        ref_m.data_manager.update()
+        m.data_manager.update()
+        assert np.array_equal(np.asarray(m.get_initial_state_dict()[m._fname]), f0)
+    m.close()
+    ref_m.close()
+
+
+def test_integrate_rows_is_refused_for_packed_tangent_layouts():
     from dolfinx_materials_amd._lib import DxmError
 
     n = 1000
     rows = np.arange(n, dtype=np.int64)
-    el = JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU)))
-    el.set_data_manager(n)
-    assert not el.supports_row_outputs
-    with pytest.raises(DxmError):
-        el.integrate_rows(np.zeros((n, 6)), rows, np.zeros(n * 6), np.zeros(n * 36))
-    import ctypes as C
-    assert el._lib.dxm_integrate_rows(el._handles()[0], np.zeros((n, 6)).ctypes.data_as(C.c_void_p), 0.0, np.zeros(n * 6).ctypes.data_as(C.c_void_p),
-                                      np.zeros(n * 36).ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), None) < 0
-    el.close()
     packed = _j2(tangent_layout="coef")
     packed.set_data_manager(n)
     assert not packed.supports_row_outputs
+    with pytest.raises(DxmError):
+        packed.integrate_rows(np.zeros((n, 6)), rows, np.zeros(n * 6), np.zeros(n * 36))
+    import ctypes as C
+    assert packed._lib.dxm_integrate_rows(packed._handles()[0], np.zeros((n, 6)).ctypes.data_as(C.c_void_p), 0.0, np.zeros(n * 6).ctypes.data_as(C.c_void_p),
+                                          np.zeros(n * 36).ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), None) < 0
     packed.close()
 
 
