@@ -786,8 +786,9 @@ class HIPMaterial:
 
     def set_option(self, name, value):
         """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"packed_transfer"``, ``"packed_min_points"``,
-        ``"pageable_dma"``, ``"host_threads"``, ``"max_chunks"``, ``"fused_gradient"``, ``"blocks_per_cu"``,
-        ``"tune_max_skip_bytes"``, ``"tune_verbose"``)."""
+        ``"register_input"``, ``"stage_ahead"``, ``"keep_initial_io"``, ``"pageable_dma"``, ``"host_threads"``, ``"max_chunks"``,
+        ``"fused_gradient"``, ``"blocks_per_cu"``, ``"tune_max_skip_bytes"``, ``"tune_verbose"``; process-wide:
+        ``"query_foreign_pointers"``)."""
         for h in self._handles():
             self._chk(self._lib.dxm_set_option(h, name.encode(), float(value)))
 
