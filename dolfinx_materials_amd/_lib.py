@@ -128,6 +128,10 @@ SYMBOLS = {
         C.c_int,
         [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],
     ),
+    "dxm_integrate_displacement_rows": (
+        C.c_int,
+        [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],
+    ),
 }
 
 _lib = None

@@ -1951,9 +1951,8 @@ static MeshSource mesh_source(const dxm_mesh* mesh, const double* u_dev) {
 }
 static bool fusable(const dxm_mesh* mesh) { return fused_kind(mesh) != 0; }
 
-int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
-                               double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats) {
-  (void)dt;
+static int integrate_displacement_host(dxm_material* m, dxm_mesh* mesh, const double* u_host, double* flux_aos, double* isv_aos,
+                                       double* ct_aos, dxm_stats* stats, const int64_t* rows) {
   if (!m || !mesh || !u_host) return fail(-1, "null argument");
   if (mesh->device != m->device) return fail(-1, "mesh and material live on different devices");
   if (dxm_mesh_npoints(mesh) != m->n) return fail(-1, "mesh has %lld Gauss points, material %lld",
@@ -1979,8 +1978,22 @@ int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_
     if (s != st) HIP_TRY(hipStreamWaitEvent(s, mesh->grad_done, 0));
     return 0;
   };
-  if (fuse) return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats, &src);
-  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats);
+  return run_and_download(m, upload, flux_aos, isv_aos, ct_aos, stats, fuse ? &src : nullptr, nullptr, rows);
+}
+
+int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
+                               double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats) {
+  (void)dt;
+  return integrate_displacement_host(m, mesh, u_host, flux_aos, isv_aos, ct_aos, stats, nullptr);
+}
+
+int dxm_integrate_displacement_rows(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt, double* flux_rows,
+                                    double* ct_rows, const int64_t* rows, dxm_stats* stats) {
+  (void)dt;
+  if (!m) return fail(-1, "null argument");
+  if (m->n > 0 && (!flux_rows || !ct_rows || !rows)) return fail(-1, "dxm_integrate_displacement_rows needs the flux array, the tangent array and the row index");
+  if (m->tangent_layout != DXM_TANGENT_FULL) return fail(-1, "dxm_integrate_displacement_rows: the full tangent layout only");
+  return integrate_displacement_host(m, mesh, u_host, flux_rows, nullptr, ct_rows, stats, rows);
 }
 
 int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const double* u_dev, double dt,

@@ -676,21 +676,10 @@ class HIPMaterial:
         """Whether :meth:`integrate_rows` exists for this material (full tangent blocks; every law)."""
         return self.tangent_layout == "full"
 
-    def integrate_rows(self, gradients, rows, flux, tangent, dt=0):
-        """``integrate`` for a map over a SUBSET of the cells (``dxm_integrate_rows``): ``gradients`` are this material's
-        ``(N, ng)`` points as usual, but ``flux`` / ``tangent`` are the arrays of the quadrature Functions over ALL cells
-        -- ``(M, nf)`` / ``(M, nf * ng)`` (or flat), ``M >= N`` -- and point ``i`` is delivered into their row ``rows[i]``: what
-        ``_update_vals(field, values, cells)`` does with one fancy assignment per array per update
-        (``utils.py:136-143``), done by the threads that rebuild the tangent blocks.  ``rows``: C-contiguous int64, each row
-        once (``QuadratureMap.dofs``).  Returns the internal state variables (lazily, like ``integrate``); the flux of the
-        final state in ``get_final_state_dict()`` is a :class:`LazyFinalRows`."""
-        self._handles()
+    def _check_rows(self, rows, flux, tangent):
+        ng, nf = self._info.n_grad, self._info.n_flux
         if not self.supports_row_outputs:
             raise DxmError("integrate_rows: tangent_layout='full' only (integrate + scatter_rows otherwise)")
-        ng, nf = self._info.n_grad, self._info.n_flux
-        g = _as_c(gradients)
-        if g.shape != (self._n, ng):
-            raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
         if not (isinstance(rows, np.ndarray) and rows.dtype == np.int64 and rows.flags.c_contiguous and rows.shape == (self._n,)):
             raise ValueError(f"rows must be a C-contiguous int64 array of {self._n} entries")
         for name, arr, w in (("flux", flux, nf), ("tangent", tangent, nf * ng)):
@@ -703,6 +692,27 @@ class HIPMaterial:
                 raise ValueError(f"rows must lie in [0, {total})")
             self._rows_checked = key
             self.set_option("keep_initial_io", 1)   # the contiguous flux exists on the device only: advance keeps it for s0
+
+    def _after_rows(self, rc):
+        if rc > 0:
+            warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
+        self._flux[1] = LazyFinalRows(self, (self._n, self._info.n_flux), 1)
+        self._serial += 1
+        return LazyISV(self, (self._n, self._info.n_isv_total))
+
+    def integrate_rows(self, gradients, rows, flux, tangent, dt=0):
+        """``integrate`` for a map over a SUBSET of the cells (``dxm_integrate_rows``): ``gradients`` are this material's
+        ``(N, ng)`` points as usual, but ``flux`` / ``tangent`` are the arrays of the quadrature Functions over ALL cells
+        -- ``(M, nf)`` / ``(M, nf * ng)`` (or flat), ``M >= N`` -- and point ``i`` is delivered into their row ``rows[i]``: what
+        ``_update_vals(field, values, cells)`` does with one fancy assignment per array per update
+        (``utils.py:136-143``), done by the threads that rebuild the tangent blocks.  ``rows``: C-contiguous int64, each row
+        once (``QuadratureMap.dofs``).  Returns the internal state variables (lazily, like ``integrate``); the flux of the
+        final state in ``get_final_state_dict()`` is a :class:`LazyFinalRows`."""
+        self._handles()
+        g = _as_c(gradients)
+        if g.shape != (self._n, self._info.n_grad):
+            raise ValueError(f"gradients must have shape {(self._n, self._info.n_grad)}, got {g.shape}")
+        self._check_rows(rows, flux, tangent)
         old = self._grad[1]
         self._grad[1] = g
         recs = [Stats() for _ in self._parts]
@@ -710,15 +720,24 @@ class HIPMaterial:
                                                                         rows.ctypes.data + lo * 8, C.byref(st))
                  for (h, lo, hi, _dev), st in zip(self._parts, recs)]
         self._warm = True
-        rc = self._finish_blocks(self._run(calls), recs)
-        if rc > 0:
-            warnings.warn(f"local Newton did not converge at {rc} quadrature points", RuntimeWarning)
-        self._flux[1] = LazyFinalRows(self, (self._n, nf), 1)
-        self._serial += 1
+        isv = self._after_rows(self._finish_blocks(self._run(calls), recs))
         if isinstance(old, np.ndarray) and old is not g and old is not self._grad[0]:
             _reaper.drop(old)
         del old
-        return LazyISV(self, (self._n, self._info.n_isv_total))
+        return isv
+
+    def integrate_displacement_rows(self, mesh, u, rows, flux, tangent, dt=0):
+        """:meth:`integrate_rows` with the gradient evaluated on the device from the nodal vector ``u``
+        (:meth:`integrate_displacement`): ``mesh`` holds the cells of this material's map only (its connectivity restricted to
+        them; coordinates and displacement vector of the whole mesh)."""
+        h = self._require()
+        u = _as_c(u).reshape(-1)
+        if u.size != mesh.displacement_size:
+            raise ValueError(f"u must have {mesh.displacement_size} entries, got {u.size}")
+        self._check_rows(rows, flux, tangent)
+        st = Stats()
+        rc = self._lib.dxm_integrate_displacement_rows(h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(tangent), rows.ctypes.data, C.byref(st))
+        return self._after_rows(self._finish_blocks([rc], [st]))
 
     def integrate_displacement(self, mesh, u, dt=0):
         """Same as :meth:`integrate`, with the gradient evaluated on the device from the nodal

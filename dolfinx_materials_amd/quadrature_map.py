@@ -127,10 +127,12 @@ class AcceleratedUpdate:
         """Evaluate the gradient on the GPU from the nodal vector ``displacement()`` returns (``gradient.Hex8Mesh`` /
         ``Tet4Mesh`` / ``SimplexMesh``; ``*.from_dolfinx(V, degree)`` builds them from a function space, and
         ``lambda: u.x.array`` is the callable): only that vector is uploaded per update, the step before the path
-        (``quadrature_function.py:45-51``) runs inside the update kernel.  Needs a map over all cells in mesh order."""
+        (``quadrature_function.py:45-51``) runs inside the update kernel.  ``mesh`` holds the cells of this map in its
+        order: all cells of the mesh for a map over everything, the connectivity restricted to ``self.cells`` for a map
+        over a subset (``Hex8Mesh(coords, conn[cells])``)."""
         plan = self._accel_plan()
-        if not plan.identity or mesh.npoints != plan.npoints:
-            raise ValueError("device gradient evaluation needs a map over all cells of the mesh")
+        if mesh.npoints != plan.npoints or not (plan.identity or plan.row_outputs):
+            raise ValueError("device gradient evaluation needs a mesh object with exactly the cells of this map, in its order")
         if not hasattr(self.material, "integrate_displacement"):
             raise ValueError("this material cannot evaluate gradients on the device")
         plan.device_gradient = (mesh, displacement)
@@ -259,8 +261,12 @@ class AcceleratedUpdate:
             # a map over a subset of the cells: the engine stores each point's stress and tangent block in its row of the
             # Functions (the index the constructor built, quadrature_map.py:231-233) -- no scatter afterwards
             (flux_fun,), (flux_dim,) = self.fluxes.values(), m.fluxes.values()
-            self._last_isv = m.integrate_rows(self._gradient_block(), plan.rows, rows_of(flux_fun, flux_dim),
-                                              rows_of(self.jacobian_flatten, self._jacobian_width()))
+            out = (plan.rows, rows_of(flux_fun, flux_dim), rows_of(self.jacobian_flatten, self._jacobian_width()))
+            if plan.device_gradient is not None:
+                mesh, displacement = plan.device_gradient
+                self._last_isv = m.integrate_displacement_rows(mesh, displacement(), *out)
+            else:
+                self._last_isv = m.integrate_rows(self._gradient_block(), *out)
             assert m.last_stats["n_nan"] == 0, "non-finite constitutive update"
             self.__dict__["_accel_rows_current"] = True     # the flux Function holds the final flux already (advance)
             if self.isv_every_update:

@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define DXM_ABI_VERSION 4   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2;
-                             * 4: option "keep_initial_io", dxm_io_held, dxm_get_io, dxm_integrate_rows, dxm_host_scatter_rows,
+                             * 4: option "keep_initial_io", dxm_io_held, dxm_get_io, dxm_integrate_rows, dxm_integrate_displacement_rows, dxm_host_scatter_rows,
                              *    dxm_host_gather_rows */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
@@ -360,6 +360,11 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
  * downloads flux / isv / tangent (any may be NULL).  mesh npoints must equal the handle's. */
 int dxm_integrate_displacement(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt,
                                double* flux_aos, double* isv_aos, double* ct_aos, dxm_stats* stats);
+/* The same with the results delivered into rows of larger arrays, as dxm_integrate_rows does: `mesh` holds the cells of ONE
+ * material's map (connectivity restricted to its cells, coordinates / displacement vector of the whole mesh), flux_rows /
+ * ct_rows are the quadrature Functions over all cells, point i goes to their row rows[i]. */
+int dxm_integrate_displacement_rows(dxm_material* m, dxm_mesh* mesh, const double* u_host, double dt, double* flux_rows,
+                                    double* ct_rows, const int64_t* rows, dxm_stats* stats);
 
 /* Device-resident form of dxm_integrate_displacement: u_dev (dxm_mesh_displacement_size doubles), flux_dev, ct_dev are device
  * arrays, the call is asynchronous on hip_stream and capturable like dxm_integrate_device.  For

@@ -163,6 +163,57 @@ def test_device_gradient_through_the_map_equals_the_host_gradient_route():
         q.material.close()
 
 
+def test_two_materials_on_disjoint_cells_with_device_gradients_fill_the_same_functions():
+    """A multi-material problem (demos/multimaterials/multimaterials.py:253-257: one QuadratureMap per material, each over its
+    cells): both maps evaluate their strain on the GPU from the one displacement vector (a mesh object per map, connectivity
+    restricted to its cells) and the engine stores stress and tangent blocks in the rows of that map -- against the same two
+    maps with host-evaluated strains, and against their restated reference cadence."""
+    from dolfinx_materials_amd.gradient import Hex8Mesh
+
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from hex_fem import HexMesh
+
+    mesh = HexMesh(7)
+    rng = np.random.default_rng(6)
+    u = {"now": 2e-3 * rng.standard_normal(mesh.ndof)}
+    cells_a = np.sort(rng.choice(mesh.num_cells, size=mesh.num_cells // 3, replace=False)).astype(np.int32)
+    cells_b = np.setdiff1d(np.arange(mesh.num_cells, dtype=np.int32), cells_a)
+    laws = {"a": ("j2_voce", cells_a), "b": ("j2_linear", cells_b)}
+    fields = {}
+    for route in ("host", "device", "cadence"):
+        maps = []
+        for law, cells in laws.values():
+            cls = FieldMapBase if route == "cadence" else QuadratureFieldMap
+            q = cls(mesh.num_cells, mesh.nqp, JAXMaterial(_behavior(law)), cells=cells)
+            q.register_gradient("strain", lambda c: mesh.strain(u["now"], c))
+            if route == "device":
+                q.register_device_gradient(Hex8Mesh(mesh.coords, mesh.conn[cells]), lambda: u["now"])
+                assert q._accel_plan().row_outputs and not q._accel_plan().identity
+            maps.append(q)
+        total = {}
+        for scale in (1.0, 1.7):
+            u_now = u["now"]
+            u["now"] = scale * u_now
+            for q in maps:
+                (as_reference_update(q) if route == "cadence" else q.update())
+                (as_reference_advance(q) if route == "cadence" else q.advance())
+            u["now"] = u_now
+        for name in _fields(maps[0]):   # the two maps own disjoint rows: the sum of their fields is the mesh-wide field
+            total[name] = _fields(maps[0])[name] + _fields(maps[1])[name]
+        fields[route] = total
+        for q in maps:
+            if hasattr(q, "close"):
+                q.close()
+            q.material.close()
+    for name in fields["host"]:
+        assert np.array_equal(fields["host"][name], fields["cadence"][name]), name
+        scale = max(np.abs(fields["host"][name]).max(), 1e-300)
+        assert np.abs(fields["device"][name] - fields["host"][name]).max() <= 1e-11 * scale, name
+    assert np.abs(fields["host"]["p"]).max() > 0 and (fields["host"]["stress"].reshape(mesh.num_cells, -1) != 0).any(axis=1).all()
+
+
 @pytest.mark.parametrize("case", ["full", "subset"])
 def test_engine_behind_the_map_reproduces_the_reference_classs_fields(case):
     """``tests/golden/quadrature_map_ref.npz``: what the REFERENCE's own ``QuadratureMap.update() / advance()`` left in
