@@ -83,17 +83,18 @@ class Tet4Mesh(_DeviceMesh):
         self._handle = h
 
     @classmethod
-    def from_dolfinx(cls, V, quadrature_degree, device=0):
+    def from_dolfinx(cls, V, quadrature_degree, device=0, cells=None):
         """From a dolfinx P1 vector function space on tetrahedra: ``u.x.array`` is the displacement vector to hand to
         ``integrate_displacement``; ``quadrature_degree`` as given to ``QuadratureMap`` (the gradient of a P1 field is
-        constant per cell and is repeated at the cell's points, point = cell * nqp + q: ``quadrature_map.py:255-260``)."""
+        constant per cell and is repeated at the cell's points, point = cell * nqp + q: ``quadrature_map.py:255-260``).
+        ``cells``: the cells of ONE ``QuadratureMap`` (``qmap.cells``, a multi-material problem) instead of all."""
         import basix
 
         coords, conn = _dolfinx_p1_layout(V)
         if conn.shape[1] != 4:
             raise ValueError("Tet4Mesh.from_dolfinx needs a tetrahedral mesh")
         pts, _ = basix.make_quadrature(basix.CellType.tetrahedron, int(quadrature_degree))
-        return cls(coords, conn, nqp=len(pts), device=device)
+        return cls(coords, conn if cells is None else conn[np.asarray(cells)], nqp=len(pts), device=device)
 
 
 class Hex8Mesh(_DeviceMesh):
@@ -136,8 +137,8 @@ class Hex8Mesh(_DeviceMesh):
         _lib.check(self._lib.dxm_mesh_tangent_diagonal_device(self._handle, int(coef_ptr), int(d_ptr), int(stream) or None))
 
     @classmethod
-    def from_dolfinx(cls, V, quadrature_degree, device=0):
-        """From a dolfinx P1 vector function space on hexahedra.  The Gauss points are basix's for
+    def from_dolfinx(cls, V, quadrature_degree, device=0, cells=None):
+        """From a dolfinx P1 vector function space on hexahedra (``cells``: those of one ``QuadratureMap`` instead of all).  The Gauss points are basix's for
         ``quadrature_degree`` (what ``QuadratureMap`` uses: ``quadrature_map.py:239-243``, ``utils.py:89-94``), mapped
         from the reference cell [0,1]^3 to [-1,1]^3 in basix's own order, so Gauss point ``q`` of cell ``c`` is row
         ``c * nqp + q`` of the quadrature Functions; the cell's dofs come in the tensor-product vertex order of basix
@@ -148,6 +149,7 @@ class Hex8Mesh(_DeviceMesh):
         if conn.shape[1] != 8:
             raise ValueError("Hex8Mesh.from_dolfinx needs a hexahedral mesh")
         pts, _ = basix.make_quadrature(basix.CellType.hexahedron, int(quadrature_degree))
+        conn = conn if cells is None else conn[np.asarray(cells)]
         return cls(coords, conn[:, DOLFINX_HEX_TO_VTK], qpoints=2.0 * np.asarray(pts) - 1.0, device=device)
 
 
@@ -244,8 +246,9 @@ class SimplexMesh(_DeviceMesh):
         return cls(coords, cells, dofmap, n_dofs, dphi, device=device), dof_coords
 
     @classmethod
-    def from_dolfinx(cls, V, quadrature_degree, device=0):
-        """From a dolfinx vector Lagrange space (any order, block size = topological dimension) on a first-order
+    def from_dolfinx(cls, V, quadrature_degree, device=0, cells=None):
+        """From a dolfinx vector Lagrange space (any order, block size = topological dimension; ``cells``: those of one
+        ``QuadratureMap`` instead of all) on a first-order
         (straight-sided) triangle or tetrahedron mesh: geometry from ``mesh.geometry``, the dofmap of ``V`` as it is,
         Gauss points and tabulated derivatives from basix -- so point ``c * nqp + q`` is row ``c * nqp + q`` of the
         quadrature Functions (``quadrature_map.py:239-260``) and ``u.x.array`` is the vector to hand to
@@ -273,4 +276,6 @@ class SimplexMesh(_DeviceMesh):
         if tab.shape[2] != dofmap.shape[1]:   # blocked element tabulated with its block: scalar basis is every bs-th
             tab = tab[:, :, ::tdim]
         dphi = np.ascontiguousarray(tab[1:1 + tdim].transpose(1, 2, 0))
+        if cells is not None:
+            geom_conn, dofmap = geom_conn[np.asarray(cells)], dofmap[np.asarray(cells)]
         return cls(np.asarray(mesh.geometry.x), geom_conn, dofmap, n_dofs, dphi, device=device)
