@@ -760,10 +760,18 @@ class HIPMaterial:
         self._serial += 1
         return flux, (self._out_isv if eager else LazyISV(self, (self._n, self._info.n_isv_total))), self._out_ct
 
+    def _host_mirrors_left_behind(self):
+        """The device-pointer forms produce a final state whose flux the host never sees: the mirrors of the state
+        dictionaries do not follow them (an array stays what the last host-buffer call left).  A lazy view of the device copy
+        of that call would fail instead -- the copy is invalidated by the launch -- so it becomes an all-NaN placeholder."""
+        if isinstance(self._flux[1], LazyFinalRows):
+            self._flux[1] = np.broadcast_to(np.nan, self._flux[1].shape)
+
     def integrate_device(self, grad_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
         """Device-pointer form: asynchronous launch on ``stream`` (a ``hipStream_t`` value, e.g.
         ``torch.cuda.current_stream().cuda_stream``); the three arguments are device addresses
         of ``(N,ng)``, ``(N,nf)`` and ``(N,nf*ng)`` fp64 arrays on this material's device."""
+        self._host_mirrors_left_behind()
         self._chk(
             self._lib.dxm_integrate_device(
                 self._require(), int(grad_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None
@@ -775,6 +783,7 @@ class HIPMaterial:
         the displacement vector (``mesh.displacement_size`` doubles), ``flux_ptr`` / ``ct_ptr`` device arrays as for
         :meth:`integrate_device`; asynchronous on ``stream``.  For hex8 meshes with 8 Gauss points per
         cell, tet4 meshes and Lagrange simplex meshes the gradient is evaluated inside the update kernel."""
+        self._host_mirrors_left_behind()
         self._chk(self._lib.dxm_integrate_displacement_device(
             self._require(), mesh._handle, int(u_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None))
 
@@ -786,6 +795,7 @@ class HIPMaterial:
         Acts like ``integrate_device(grad_ptr, flux_ptr, ct_ptr)``: the initial state is preserved,
         the final state / flux / tangent are those of that update.  Returns the kernel times."""
         before, after, tried = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        self._host_mirrors_left_behind()
         self._chk(self._lib.dxm_tune_placement(self._require(), int(grad_ptr), int(flux_ptr), int(ct_ptr),
                                                int(max_candidates), C.byref(before), C.byref(after), C.byref(tried)))
         return {"ms_before": before.value, "ms_after": after.value, "candidates_tried": tried.value}
@@ -801,6 +811,7 @@ class HIPMaterial:
     def notify_replay(self):
         """Call after replaying a HIP graph that contains a launch of this material (the replay rewrote s1,
         flux, tangent and the stats without the library seeing it): ``dxm_notify_replay``."""
+        self._host_mirrors_left_behind()
         self._chk(self._lib.dxm_notify_replay(self._require()))
 
     def set_option(self, name, value):

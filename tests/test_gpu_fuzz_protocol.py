@@ -51,13 +51,19 @@ def close(a, b, scale):
 
 @pytest.mark.parametrize("seed,n,bound,lazy", [(0, 777, False, True), (1, 5000, True, True), (2, 64, False, False),
                                                (3, 40_000, True, False), (4, 1, False, True), (5, 70_001, False, True),
-                                               (6, 3000, "io", True), (7, 66_000, "io", True), (8, 130, "io", False)])
+                                               (6, 3000, "io", True), (7, 66_000, "io", True), (8, 130, "io", False),
+                                               (9, 2500, "rows", True), (10, 70_003, "rows", True), (11, 1, "rows", True)])
 def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     rng = np.random.default_rng(seed)
     beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
     m = JAXMaterial(beh, lazy_isv=lazy)
     m.set_data_manager(n)
-    if bound:
+    if bound == "rows":   # a map over a subset of the cells: results into rows `rows` of arrays over all cells (integrate_rows)
+        total = n + 37
+        rows = np.ascontiguousarray(np.random.default_rng(seed + 100).permutation(total)[:n], dtype=np.int64)
+        flux_all, jac_all = np.full((total, 6), 9.0), np.full((total, 36), 9.0)
+        others = np.setdiff1d(np.arange(total), rows)
+    elif bound:
         flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
         m.bind_outputs(flux=flux_fn, tangent=jac_fn)
     if bound == "io":   # the gradient Function too (what the accelerated QuadratureMap binds): every update overwrites it, the
@@ -83,12 +89,16 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
             if bound == "io":
                 grad_fn[...] = eps.ravel()
                 sig, isv, ct = m.integrate(grad_fn.reshape(n, 6))
+            elif bound == "rows":
+                isv = m.integrate_rows(eps, rows, flux_all, jac_all)
+                sig, ct = flux_all[rows], jac_all[rows]
+                assert (flux_all[others] == 9.0).all() and (jac_all[others] == 9.0).all()
             else:
                 sig, isv, ct = m.integrate(eps)
             ref = model.integrate(eps)
             scale = max(np.abs(ref["sig"]).max(), SIG0_V)
             assert close(sig, ref["sig"], scale) and close(ct, ref["Ct"], np.abs(ref["Ct"]).max())
-            if bound:
+            if bound and bound != "rows":
                 assert close(flux_fn, ref["sig"].ravel(), scale) and close(jac_fn, ref["Ct"].ravel(), np.abs(ref["Ct"]).max())
             assert m.last_stats["n_plastic"] == ref["n_plastic"] and m.last_stats["n_nan"] == 0
             held = isv
@@ -129,6 +139,7 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
                 got = m.get_initial_state_dict() if which == "initial" else m.get_final_state_dict()
                 assert close(got["p"], st["p"][:, None], max(st["p"].max(), 1e-300) + 1e-30), which
                 assert close(got["epsp"], st["epsp"], max(np.abs(st["epsp"]).max(), 1e-300) + 1e-30), which
+                assert np.asarray(got["stress"]).shape == (n, 6) and np.asarray(got["strain"]).shape == (n, 6)   # whatever they hold, they can be looked at
                 if known[which]:
                     assert close(got["stress"], st["stress"], max(np.abs(st["stress"]).max(), SIG0_V)), which
                     assert np.array_equal(np.asarray(got["strain"]), st["strain"]), which
