@@ -21,7 +21,9 @@ slow mode in where the resident state sits relative to them (DESIGN.md section 3
 ``config.placement_tuning`` reports what that did, ``roofline.untuned`` carries the figure of the same
 launches before it, ``--no-tune`` skips it, ``--tune-candidates 24 --tune-skip-gib 16`` is round 1's deep search; a handle
 that is still in the slow mode after the small search (below ``--tune-extend-below`` = 0.72 of the HBM peak: on some boxes
-every nearby allocation is slow) gets that deep search once, and the record says so.
+every nearby allocation is slow) gets that deep search once, and the record says so.  Then the caller's own side of it: the
+bench allocates its tangent array up to ``--tangent-candidates`` (6) times -- the kernel has two levels 3 % apart in where
+THAT array sits -- keeps the fastest and reports the first allocation's figure as ``roofline.first_tangent_allocation``.
 
 The JSON line also carries
   roofline      achieved algorithmic HBM GB/s of the constitutive kernel (496 B/point x points
@@ -732,6 +734,9 @@ def main():
                     help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
     ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle")
     ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
+    ap.add_argument("--tangent-candidates", type=int, default=6,
+                    help="allocations of the caller's tangent array the bench may try (the kernel has two levels ~3 %% apart in where that array "
+                         "sits); stops as soon as both levels have been seen; 1 = keep the first")
     ap.add_argument("--tune-extend-below", type=float, default=0.72,
                     help="a handle whose kernel is still below this fraction of the HBM peak after the small search gets one "
                          "deep search (24 candidates, skip blocks up to 16 GiB); 0 disables")
@@ -816,6 +821,15 @@ def main():
 
     if rank == 0:
         elapsed, kern_ms, untuned_ms, copy_gbs = head["elapsed"], head["kernel_ms"], head["untuned_ms"], head["copy_gbs"]
+        ta = head.get("tangent_array")
+        first_tangent = None
+        if ta and "first_ms" in ta:
+            first_tangent = {"kernel_ms": round(ta["first_ms"], 4), "frac": round(ALG_BYTES * n / (ta["first_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "allocations_ms": ta["allocations_ms"], "kept": ta["kept"],
+                             "note": "state placed by dxm_tune_placement, tangent array where the caller's first allocation put it; the caller then "
+                                     "tried further allocations of that array (two levels ~3 % apart) and kept the fastest"}
+        elif ta:
+            first_tangent = ta
         sig0 = SIG0 if args.law == "j2_linear" else 350.0
         value = n * world * K / elapsed / 1e6
         achieved = ALG_BYTES * n / (kern_ms * 1e-3) / 1e9
@@ -867,6 +881,7 @@ def main():
                 "kernel_ms": round(kern_ms, 4),
                 "untuned": {"kernel_ms": round(untuned_ms, 4), "frac": round(ALG_BYTES * n / (untuned_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "note": "same launches before dxm_tune_placement (state where hipMalloc first put it)"},
+                "first_tangent_allocation": first_tangent,
                 "algorithmic_bytes_per_point": ALG_BYTES,
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                 "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
@@ -979,6 +994,35 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
                 tuning.append(rec)
             except Exception as exc:  # an optimisation of the setup: never lose the run over it
                 tuning.append({"error": repr(exc)})
+
+    # The caller's side of the same effect: with the state placed, WHERE THE TANGENT ARRAY SITS (58 % of the kernel's bytes) still
+    # decides between two levels 3 % apart (0.814 / 0.792 ms per 1e7 points over six allocations in one process,
+    # profiles/r03_tangent_array_allocations.jsonl).  The caller owns that array, so the caller tries: up to
+    # --tangent-candidates allocations, the fastest kept, then the state search once more against it.  Setup, outside the
+    # timed region; `roofline.first_tangent_allocation` carries the figure without it.
+    tangent_array = None
+    if not args.no_tune and args.tangent_candidates > 1:
+        try:
+            events_ms(3)
+            first_ms = events_ms(12)
+            cands, times = [ct], [first_ms]
+            for _ in range(args.tangent_candidates - 1):
+                if min(times) <= 0.985 * max(times):   # both levels seen: the fast one is in hand
+                    break
+                ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+                cands.append(ct)
+                events_ms(3)
+                times.append(events_ms(12))
+            kept = int(np.argmin(times))
+            ct = cands[kept]
+            del cands
+            torch.cuda.empty_cache()
+            if kept != 0:
+                for j, m in enumerate(mats):
+                    m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
+            tangent_array = {"allocations_ms": [round(t, 4) for t in times], "kept": kept, "first_ms": first_ms}
+        except Exception as exc:  # an optimisation of the setup: never lose the run over it
+            tangent_array = {"error": repr(exc)}
 
     def step(i):
         j = i % 3
@@ -1148,7 +1192,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         m.close()
     del eps, flux, ct
     torch.cuda.empty_cache()
-    return {"elapsed": elapsed, "kernel_ms": kern_ms, "untuned_ms": untuned_ms, "tuning": tuning, "plastic_fraction": [round(x, 4) for x in plastic_frac],
+    return {"elapsed": elapsed, "kernel_ms": kern_ms, "untuned_ms": untuned_ms, "tuning": tuning, "tangent_array": tangent_array, "plastic_fraction": [round(x, 4) for x in plastic_frac],
             "copy_gbs": copy_gbs, "gather": gather_out, "group_info": group_info, "kernel": kernel, "steps": K, "points": n}
 
 
