@@ -95,6 +95,7 @@ SYMBOLS = {
     "dxm_integrate_displacement_device": (C.c_int, [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dxm_tune_placement": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "dxm_time_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "dxm_place_state": (C.c_int, [_h, C.c_int, C.c_uint64, C.c_uint64]),
     "dxm_expand_tangent_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "dxm_expand_tangent_pack4_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),

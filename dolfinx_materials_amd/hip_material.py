@@ -800,6 +800,30 @@ class HIPMaterial:
                                                int(max_candidates), C.byref(before), C.byref(after), C.byref(tried)))
         return {"ms_before": before.value, "ms_after": after.value, "candidates_tried": tried.value}
 
+    def time_device(self, grad_ptr, flux_ptr, ct_ptr, launches=12):
+        """Best launch time (ms) of ``launches`` updates with these device arrays (``dxm_time_device``; synchronous, acts like
+        :meth:`integrate_device`)."""
+        self._host_mirrors_left_behind()
+        ms = C.c_double(0.0)
+        self._chk(self._lib.dxm_time_device(self._require(), int(grad_ptr), int(flux_ptr), int(ct_ptr), int(launches), C.byref(ms)))
+        return ms.value
+
+    def fastest_tangent_array(self, alloc, grad_ptr, flux_ptr, candidates=6, launches=12, contrast=0.985):
+        """The caller's side of :meth:`tune_placement`: where the caller's tangent array sits decides between two levels of the
+        J2 kernels 3 % apart (17 % for the elastic law).  ``alloc()`` returns a newly allocated device
+        array with a ``data_ptr()`` (``lambda: torch.empty((n, 36), dtype=torch.float64, device=dev)``); up to ``candidates``
+        are measured -- all kept alive meanwhile, so that the allocator hands out new ranges -- until both levels have
+        been seen (best <= ``contrast`` x worst), the fastest is returned with the times: ``(array, [ms, ...], index)``.
+        Call after :meth:`tune_placement`, and run that once more against the array returned if it is not the first."""
+        arrays, times = [], []
+        for _ in range(max(1, int(candidates))):
+            arrays.append(alloc())
+            times.append(self.time_device(grad_ptr, flux_ptr, arrays[-1].data_ptr(), launches))
+            if len(times) > 1 and min(times) <= contrast * max(times):
+                break
+        k = int(np.argmin(times))
+        return arrays[k], times, k
+
     @property
     def launch_generation(self):
         """``dxm_launch_generation``: a HIP graph that captured ``integrate_device`` /

@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define DXM_ABI_VERSION 4   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2;
-                             * 4: option "keep_initial_io", dxm_io_held, dxm_get_io, dxm_integrate_rows, dxm_integrate_displacement_rows, dxm_host_scatter_rows,
+                             * 4: option "keep_initial_io", dxm_io_held, dxm_get_io, dxm_integrate_rows, dxm_integrate_displacement_rows, dxm_time_device, dxm_host_scatter_rows,
                              *    dxm_host_gather_rows */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
@@ -222,6 +222,13 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
  * candidates measured (any may be NULL).  No counterpart in the reference (its state lives in jax arrays). */
 int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
                        int max_candidates, double* ms_before, double* ms_after, int* n_tried);
+/* The caller's side of the same effect: with the state placed, where the caller's TANGENT array sits still decides between two
+ * levels of the J2 kernels 3 % apart (17 % for the elastic law, which has no state; flux and gradient arrays <= 1 %).  A
+ * device-resident caller that allocates its own arrays can try a few allocations of that array and keep the fastest;
+ * dxm_time_device is the measurement: `launches` updates with these arrays on the handle's own stream (synchronous, two
+ * warm-up launches first), best launch time in ms.  Acts like dxm_integrate_device otherwise (s0 preserved).
+ * HIPMaterial.fastest_tangent_array(alloc, grad_ptr, flux_ptr) is the loop; bench.py uses it (--tangent-candidates). */
+int dxm_time_device(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev, int launches, double* best_ms);
 /* Experimental placement control: rebuild the resident state (contents preserved) in mode 0 a fresh hipMalloc
  * block, 1 separately created physical chunks of chunk_bytes (rounded up to the allocation granularity) mapped in
  * creation order, 2 the same chunks mapped in a pseudo-random order (seed) -- HIP virtual memory management

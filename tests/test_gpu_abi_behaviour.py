@@ -282,3 +282,40 @@ def test_pageable_output_arrays_are_filled_through_the_staging_path(law, n):
     assert lib.dxm_isv_host(b._handle, 1, isv2.ctypes.data) == 0 and np.array_equal(isv2, isv)
     p = np.full((n, 1), np.nan)
     assert lib.dxm_get_state(b._handle, 1, 0, p.ctypes.data) == 0 and np.array_equal(p[:, 0], isv[:, 0])
+
+
+def test_time_device_and_the_tangent_array_search_act_like_an_update():
+    """`dxm_time_device` / `HIPMaterial.fastest_tangent_array`: the caller's side of the placement search.  They run the update
+    with the candidate arrays (s0 preserved, results those of the update) and hand back one of the arrays they were given."""
+    torch = pytest.importorskip("torch")
+    from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
+
+    dev = torch.device("cuda:0")
+    n = 300_001
+    h = j2_history(n)
+    mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)))
+    mat.set_data_manager(n)
+    st = torch.cuda.current_stream().cuda_stream
+    g = [to_device(x) for x in h[:2]]
+    flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+    mat.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+    mat.data_manager.update()
+    mat.integrate_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+    torch.cuda.synchronize()
+    ref_flux, ref_ct, s0 = flux.clone(), ct.clone(), mat.get_initial_state_dict()
+    ms = mat.time_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), launches=5)
+    assert 0.0 < ms < 50.0
+    made = []
+
+    def alloc():
+        made.append(torch.zeros((n, 36), dtype=torch.float64, device=dev))
+        return made[-1]
+
+    best, times, k = mat.fastest_tangent_array(alloc, g[1].data_ptr(), flux.data_ptr(), candidates=4, launches=4)
+    assert 1 <= len(times) <= 4 and len(made) == len(times) and best is made[k] and times[k] == min(times)
+    assert torch.equal(best, ref_ct) and torch.equal(flux, ref_flux)          # every candidate received the update's tangent
+    for name, a in mat.get_initial_state_dict().items():
+        assert np.array_equal(np.asarray(a), np.asarray(s0[name])), name
+    assert mat._lib.dxm_time_device(mat._handles()[0], None, None, None, 3, None) < 0
+    mat.close()
