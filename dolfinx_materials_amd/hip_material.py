@@ -812,14 +812,14 @@ class HIPMaterial:
         """The caller's side of :meth:`tune_placement`: where the caller's tangent array sits decides between two levels of the
         J2 kernels 3 % apart (17 % for the elastic law).  ``alloc()`` returns a newly allocated device
         array with a ``data_ptr()`` (``lambda: torch.empty((n, 36), dtype=torch.float64, device=dev)``); up to ``candidates``
-        are measured -- all kept alive meanwhile, so that the allocator hands out new ranges -- until both levels have
-        been seen (best <= ``contrast`` x worst), the fastest is returned with the times: ``(array, [ms, ...], index)``.
+        are measured -- all kept alive meanwhile, so that the allocator hands out new ranges -- until, after at least three,
+        both levels have been seen (best <= ``contrast`` x worst); the fastest is returned with the times: ``(array, [ms, ...], index)``.
         Call after :meth:`tune_placement`, and run that once more against the array returned if it is not the first."""
         arrays, times = [], []
         for _ in range(max(1, int(candidates))):
             arrays.append(alloc())
             times.append(self.time_device(grad_ptr, flux_ptr, arrays[-1].data_ptr(), launches))
-            if len(times) > 1 and min(times) <= contrast * max(times):
+            if len(times) >= 3 and min(times) <= contrast * max(times):
                 break
         k = int(np.argmin(times))
         return arrays[k], times, k
