@@ -22,7 +22,7 @@ slow mode in where the resident state sits relative to them (DESIGN.md section 3
 launches before it, ``--no-tune`` skips it, ``--tune-candidates 24 --tune-skip-gib 16`` is round 1's deep search; a handle
 that is still in the slow mode after the small search (below ``--tune-extend-below`` = 0.72 of the HBM peak: on some boxes
 every nearby allocation is slow) gets that deep search once, and the record says so.  Then the caller's own side of it: the
-bench allocates its tangent array up to ``--tangent-candidates`` (6) times -- the kernel has two levels 3 % apart in where
+bench allocates its tangent array up to ``--tangent-candidates`` (8) times -- the kernel has two levels 3 % apart in where
 THAT array sits -- keeps the fastest and reports the first allocation's figure as ``roofline.first_tangent_allocation``.
 
 The JSON line also carries
@@ -549,13 +549,11 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True):
         if deep:
             out[name]["deep_placement_search"] = deep
         # ... and what a caller gets who allocates its tangent array a few times and keeps the fastest
-        # (HIPMaterial.fastest_tangent_array: up to six allocations, stops when both levels have been seen)
+        # (HIPMaterial.fastest_tangent_array: up to eight allocations, stops when a contrast has been seen and two in a row did not improve)
         if tune:
             try:
                 ct_best, t_search, k_best = m.fastest_tangent_array(lambda: torch.empty((n, nf * ng), dtype=torch.float64, device=dev),
-                                                                    g1.data_ptr(), flux.data_ptr(), candidates=6, launches=reps)
-                if m._info.n_isv_total > 0:
-                    m.tune_placement(g1.data_ptr(), flux.data_ptr(), ct_best.data_ptr())
+                                                                    g1.data_ptr(), flux.data_ptr(), candidates=8, launches=reps)
                 t_best = median_ms(flux, ct_best)
                 out[name]["tangent_array_search"] = {"best_launch_per_allocation_ms": [round(t, 4) for t in t_search], "kept": k_best,
                                                      "kernel_ms": round(t_best, 4), "frac": frac(t_best),
@@ -753,9 +751,9 @@ def main():
                     help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
     ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle")
     ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
-    ap.add_argument("--tangent-candidates", type=int, default=6,
+    ap.add_argument("--tangent-candidates", type=int, default=8,
                     help="allocations of the caller's tangent array the bench may try (the kernel has two levels ~3 %% apart in where that array "
-                         "sits); stops as soon as both levels have been seen; 1 = keep the first")
+                         "sits); stops once a contrast has been seen and two in a row did not improve; 1 = keep the first")
     ap.add_argument("--tune-extend-below", type=float, default=0.72,
                     help="a handle whose kernel is still below this fraction of the HBM peak after the small search gets one "
                          "deep search (24 candidates, skip blocks up to 16 GiB); 0 disables")
@@ -1024,19 +1022,23 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         try:
             events_ms(3)
             first_ms = events_ms(12)
-            cands, times = [ct], [first_ms]
+            cands, times, stale = [ct], [first_ms], 0
             for _ in range(args.tangent_candidates - 1):
-                if len(times) >= 3 and min(times) <= 0.985 * max(times):   # both levels seen: the fast one is in hand
+                # (the rule of HIPMaterial.fastest_tangent_array) a contrast has been seen and two candidates in a row
+                # have not improved the best by 0.5 %: the fast level is in hand
+                if stale >= 2 and min(times) <= 0.985 * max(times):
                     break
                 ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
                 cands.append(ct)
                 events_ms(3)
-                times.append(events_ms(12))
+                t_ = events_ms(12)
+                stale = 0 if t_ < 0.995 * min(times) else stale + 1
+                times.append(t_)
             kept = int(np.argmin(times))
             ct = cands[kept]
             del cands
             torch.cuda.empty_cache()
-            if kept != 0:
+            if kept != 0:   # the three states were placed against the first allocation: once more against the one kept
                 for j, m in enumerate(mats):
                     m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
             tangent_array = {"allocations_ms": [round(t, 4) for t in times], "kept": kept, "first_ms": first_ms}

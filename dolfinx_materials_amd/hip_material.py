@@ -808,20 +808,30 @@ class HIPMaterial:
         self._chk(self._lib.dxm_time_device(self._require(), int(grad_ptr), int(flux_ptr), int(ct_ptr), int(launches), C.byref(ms)))
         return ms.value
 
-    def fastest_tangent_array(self, alloc, grad_ptr, flux_ptr, candidates=6, launches=12, contrast=0.985):
-        """The caller's side of :meth:`tune_placement`: where the caller's tangent array sits decides between two levels of the
-        J2 kernels 3 % apart (17 % for the elastic law).  ``alloc()`` returns a newly allocated device
-        array with a ``data_ptr()`` (``lambda: torch.empty((n, 36), dtype=torch.float64, device=dev)``); up to ``candidates``
-        are measured -- all kept alive meanwhile, so that the allocator hands out new ranges -- until, after at least three,
-        both levels have been seen (best <= ``contrast`` x worst); the fastest is returned with the times: ``(array, [ms, ...], index)``.
-        Call after :meth:`tune_placement`, and run that once more against the array returned if it is not the first."""
-        arrays, times = [], []
+    def fastest_tangent_array(self, alloc, grad_ptr, flux_ptr, candidates=8, launches=12, contrast=0.985, patience=2, tune_state=True):
+        """The caller's side of :meth:`tune_placement`: where the caller's tangent array sits decides between levels of the
+        kernels 3 % (J2), 12 % (FeFp) or 17 % (elastic) apart.  ``alloc()`` returns a newly allocated
+        device array with a ``data_ptr()`` (``lambda: torch.empty((n, 36), dtype=torch.float64, device=dev)``); up to
+        ``candidates`` are measured -- all kept alive meanwhile, so that the allocator hands out new ranges.  The level is a
+        property of the PAIRING of the resident state with the caller's arrays, so with ``tune_state`` (default) every
+        candidate is measured with the state placed for it (``tune_placement`` with its recommended budget), and the state
+        ends up placed for the array returned.  The search stops early once a contrast has been seen (best <= ``contrast`` x
+        worst) and ``patience`` candidates in a row have not improved the best by 0.5 %.  Returns ``(array, [ms, ...], index)``."""
+        stateful = tune_state and self._info.n_isv_total > 0
+        arrays, times, stale = [], [], 0
         for _ in range(max(1, int(candidates))):
             arrays.append(alloc())
-            times.append(self.time_device(grad_ptr, flux_ptr, arrays[-1].data_ptr(), launches))
-            if len(times) >= 3 and min(times) <= contrast * max(times):
+            ptr = arrays[-1].data_ptr()
+            if stateful:
+                self.tune_placement(grad_ptr, flux_ptr, ptr)
+            t = self.time_device(grad_ptr, flux_ptr, ptr, launches)
+            stale = 0 if (not times or t < 0.995 * min(times)) else stale + 1
+            times.append(t)
+            if stale >= patience and min(times) <= contrast * max(times):
                 break
         k = int(np.argmin(times))
+        if stateful and k != len(arrays) - 1:
+            self.tune_placement(grad_ptr, flux_ptr, arrays[k].data_ptr())
         return arrays[k], times, k
 
     @property

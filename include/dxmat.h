@@ -223,7 +223,8 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
 int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
                        int max_candidates, double* ms_before, double* ms_after, int* n_tried);
 /* The caller's side of the same effect: with the state placed, where the caller's TANGENT array sits still decides between two
- * levels of the J2 kernels 3 % apart (17 % for the elastic law, which has no state; flux and gradient arrays <= 1 %).  A
+ * levels of the J2 kernels 3 % apart (up to 12 % for the FeFp laws, 17 % for the elastic law, which has no state; flux and
+ * gradient arrays <= 1 %).  A
  * device-resident caller that allocates its own arrays can try a few allocations of that array and keep the fastest;
  * dxm_time_device is the measurement: `launches` updates with these arrays on the handle's own stream (synchronous, two
  * warm-up launches first), best launch time in ms.  Acts like dxm_integrate_device otherwise (s0 preserved).
