@@ -77,3 +77,25 @@ def test_device_resident_loop_reaches_the_closed_form(preconditioner, n):
         assert step["iters"] <= 4 and step["norms"][-1] < 1e-7      # linear predictor: at most a few corrections
     if preconditioner == "mg":
         assert out["levels"] == 2 and out["cg_iterations"] / max(out["newton_iterations"] - 4, 1) < 40
+
+
+@pytest.mark.parametrize("device_gradient", [False, True])
+def test_two_materials_on_disjoint_cells_in_the_newton_loop(device_gradient):
+    """examples/two_materials_3d.py (the set-up of demos/multimaterials/multimaterials.py:253-257): two maps over disjoint
+    cell subsets deliver into rows of the same stress / tangent fields.  With the same law on both sets the loop must
+    reproduce the homogeneous closed form of the single-map run; with a stiff elastic inclusion it must converge
+    quadratically and leave the inclusion elastic and more loaded than the matrix."""
+    import two_materials_3d as tm
+
+    same = tm.run(n=6, steps=4, exx_max=2e-2, same=True, device_gradient=device_gradient, verbose=False)
+    assert same["delivered_into_rows"] == [True, True]
+    h = same["history"][-1]
+    expect = (same["sig0"] + same["H"] * h["exx"]) / (1 + same["H"] / same["E"])
+    assert abs(h["sxx_matrix"] - expect) < 1e-9 * expect and abs(h["sxx_inclusion"] - expect) < 1e-9 * expect
+    two = tm.run(n=6, steps=4, exx_max=1e-2, same=False, device_gradient=device_gradient, verbose=False)
+    for step in two["history"]:
+        n_ = step["norms"]
+        assert n_[-1] < 1e-7 and len(n_) <= 8
+        if len(n_) >= 3 and n_[-2] < 1e-2 * n_[0]:
+            assert n_[-1] < 1e-3 * n_[-2]          # the consistent tangent from both maps: quadratic tail
+    assert two["history"][-1]["sxx_inclusion"] > 1.5 * two["history"][-1]["sxx_matrix"] and two["history"][-1]["p_max"] > 0
