@@ -198,7 +198,7 @@ def as_reference_advance(qmap):
         f.x.array[np.add.outer(qmap.cells * width, np.arange(width)).ravel()] = flat
 
 
-def host_path(jm, JAXMaterial, dev_index, n, seed, reps=5):
+def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
     """PCIe-inclusive rate of the drop-in form: numpy arrays in, numpy arrays out (`integrate(gradients)` as
     QuadratureMap.update calls it, quadrature_map.py:321).  Context only, never `value`: the transfer, not the
     kernel, is the whole cost when the consumer lives on the host."""
