@@ -644,7 +644,20 @@ class HIPMaterial:
                 calls.append(lambda h=h, p=p, st=st: entry(h, p[0], dt, p[1], p[2], p[3], C.byref(st)))
             else:
                 calls.append(lambda h=h, p=p, st=st: entry(h, mesh_handle, _ptr(src), dt, p[1], p[2], p[3], C.byref(st)))
-        return self._finish_blocks(self._run(calls), recs)
+        return self._finish_blocks(self._run_over_one_array(calls, src if mesh_handle is None else None), recs)
+
+    def _run_over_one_array(self, calls, src):
+        """Several GPUs read their rows of ONE pageable gradient array: page-locked once for the call here -- the blocks'
+        sub-ranges share pages at their boundaries, so the per-handle registration of ``dxm_integrate`` would be refused for
+        every second block (and staged instead).  A refusal here leaves that per-handle behaviour."""
+        locked = False
+        if len(calls) > 1 and src is not None and src.nbytes >= (1 << 20):
+            locked = self._lib.dxm_host_register(_ptr(src), src.nbytes) == 0
+        try:
+            return self._run(calls)
+        finally:
+            if locked:
+                self._lib.dxm_host_unregister(_ptr(src))
 
     def _finish_blocks(self, rcs, recs):
         for rc in rcs:
@@ -720,7 +733,7 @@ class HIPMaterial:
                                                                         rows.ctypes.data + lo * 8, C.byref(st))
                  for (h, lo, hi, _dev), st in zip(self._parts, recs)]
         self._warm = True
-        isv = self._after_rows(self._finish_blocks(self._run(calls), recs))
+        isv = self._after_rows(self._finish_blocks(self._run_over_one_array(calls, g), recs))
         if isinstance(old, np.ndarray) and old is not g and old is not self._grad[0]:
             _reaper.drop(old)
         del old

@@ -38,6 +38,9 @@ def test_blocks_on_several_handles_equal_one_handle_bit_for_bit(law, n, devices)
         fb, ib, cb = many.integrate(g)
         assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(np.asarray(ia), np.asarray(ib)), k
         assert one.last_stats == many.last_stats
+        if g.nbytes >= (1 << 20):   # the one gradient array is page-locked once for all blocks, not staged for every second one
+            assert many.last_upload == "dma (caller's array page-locked)"
+            assert many._lib.dxm_host_register(g.ctypes.data, g.nbytes) == 0 and many._lib.dxm_host_unregister(g.ctypes.data) == 0   # and released
         if k == 1:   # a second Newton iteration from the same initial state, then back to it and forward again
             for m in (one, many):
                 m.data_manager.revert()
