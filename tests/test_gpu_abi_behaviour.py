@@ -251,7 +251,7 @@ def test_plain_c_host_runs():
     subprocess.run(["make", "-C", os.path.join(root, "examples", "c_host")], check=True, capture_output=True)
     r = subprocess.run([os.path.join(root, "examples", "c_host", "j2_batch"), "300001"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "plastic points = 300001" in r.stdout
+    assert "plastic points = 300001" in r.stdout and "0 entries differ" in r.stdout      # ... and dxm_integrate_rows == dxm_integrate
 
 
 @pytest.mark.parametrize("law,n", [("j2", 100), ("j2", 50_001), ("j2", 2_300_000), ("fefp", 40_001)])
