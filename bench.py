@@ -502,7 +502,7 @@ def devices_child(G, n, seed, reps=7):
                     "GPU's DMA delivering into its rows of the one bound host array; no collective (new strain array every call)"}
 
 
-def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True):
+def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True, blocks_per_cu=0):
     """Kernel rates of the other laws of the path at the same batch size (device-resident,
     HIP events), for context next to the headline: elastic, J2 Voce (cfg 3 parameters), FeFp J2
     (cfg 4 parameters, F = I + t (eps diag(1,-1/2,-1/2) + 0.2 eps G) as in SURVEY.md 8(d))."""
@@ -534,6 +534,8 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True):
     for name, beh, make_inputs in cases:
         m = JAXMaterial(beh, device=dev.index or 0)
         m.set_data_manager(n)
+        if blocks_per_cu:
+            m.set_option("blocks_per_cu", blocks_per_cu)
         ng, nf = m._info.n_grad, m._info.n_flux
         g0, g1 = make_inputs()
         ab = m.algorithmic_bytes_per_point
@@ -788,6 +790,7 @@ def main():
                     help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
     ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle")
     ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="option blocks_per_cu for every handle of the run (0: the library's default per law)")
     ap.add_argument("--tangent-candidates", type=int, default=8,
                     help="allocations of the caller's tangent array the bench may try (the kernel has two levels ~3 %% apart in where that array "
                          "sits); stops once a contrast has been seen and two in a row did not improve; 1 = keep the first")
@@ -966,7 +969,7 @@ def main():
         if world == 1 and not args.no_other_laws:
             try:
                 torch.cuda.empty_cache()
-                out["other_laws"] = other_laws(torch, jm, JAXMaterial, dev, n, tune=not args.no_tune)
+                out["other_laws"] = other_laws(torch, jm, JAXMaterial, dev, n, tune=not args.no_tune, blocks_per_cu=args.blocks_per_cu)
             except Exception as exc:  # context only: never lose the headline line
                 out["other_laws"] = {"error": repr(exc)}
         if world == 1 and not args.no_host_path and args.law == "j2_linear":
@@ -1004,6 +1007,8 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         hard = jm.LinearHardening(SIG0, H) if law == "j2_linear" else jm.VoceHardening(350.0, 500.0, 1e3)
         m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), hard), device=c.dev_index, tangent_layout=layout)
         m.set_data_manager(n)
+        if args.blocks_per_cu:
+            m.set_option("blocks_per_cu", args.blocks_per_cu)
         return m
 
     # one load-step context per timed increment k = 2, 3, 4: s0 = converged state after k-1

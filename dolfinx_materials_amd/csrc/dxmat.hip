@@ -633,7 +633,12 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
       if (occ < 1) occ = 1;
       m->blocks_per_cu = occ;
     }
-    if (law == DXM_LAW_ELASTIC_ISO || law == DXM_LAW_J2_LINEAR || law == DXM_LAW_J2_VOCE) m->blocks_per_cu = 32;
+    if (law == DXM_LAW_ELASTIC_ISO || law == DXM_LAW_J2_LINEAR) m->blocks_per_cu = 32;
+    // The laws with a local Newton iteration (Voce or traced hardening, FeFp) do a point-dependent amount of work per tile: a
+    // grid of one workgroup per 256 points (up to 256 per CU, the cap; a grid-stride loop beyond) lets the dispatcher balance
+    // it -- Voce +3 %, FeFp +2.5 % over the persistent grids above at 1e7 points (profiles/r03_grid_size_by_law.txt); the
+    // linear-hardening kernel, whose tiles all cost the same, loses 2.5 % with it and keeps 32.
+    if (law == DXM_LAW_J2_VOCE || law == DXM_LAW_FEFP_J2_VOCE || law == DXM_LAW_FEFP_J2_LINEAR) m->blocks_per_cu = 256;
   }
   // one record per workgroup and launch.  A single launch has at most num_cu * 256 workgroups (the largest grid
   // dxm_set_option("blocks_per_cu") allows); the chunked host path appends the records of up to DXM_MAX_CHUNKS

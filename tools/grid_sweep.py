@@ -47,6 +47,15 @@ def main():
     flux = torch.empty((n, ng), dtype=torch.float64, device=dev)
     ct = torch.empty((n, ng * ng), dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    if os.environ.get("TANGENT_SEARCH") == "1":   # first a tangent array where the kernel likes it (HIPMaterial.fastest_tangent_array)
+        scout = JAXMaterial(mk())
+        scout.set_data_manager(n)
+        scout.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+        scout.data_manager.update()
+        ct, t_search, k_best = scout.fastest_tangent_array(lambda: torch.empty((n, ng * ng), dtype=torch.float64, device=dev), g[1].data_ptr(), flux.data_ptr())
+        print(json.dumps({"tangent_array_search_ms": [round(t, 4) for t in t_search], "kept": k_best}), flush=True)
+        scout.close()
+        torch.cuda.empty_cache()
     mats = []
     for v in variants:
         m = JAXMaterial(mk())
