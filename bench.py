@@ -502,7 +502,7 @@ def devices_child(G, n, seed, reps=7):
                     "GPU's DMA delivering into its rows of the one bound host array; no collective (new strain array every call)"}
 
 
-def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True, blocks_per_cu=0):
+def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, tune=True, blocks_per_cu=0):
     """Kernel rates of the other laws of the path at the same batch size (device-resident,
     HIP events), for context next to the headline: elastic, J2 Voce (cfg 3 parameters), FeFp J2
     (cfg 4 parameters, F = I + t (eps diag(1,-1/2,-1/2) + 0.2 eps G) as in SURVEY.md 8(d))."""
@@ -563,7 +563,9 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True, blocks_per_cu=
                 except Exception:
                     pass
             def median_ms(flux_, ct_):
-                for _ in range(2):
+                # a newly allocated array needs 10-20 launches to reach its steady time (the FeFp kernel: 1.70 -> 1.63 ms over
+                # the first fifteen, profiles/r03_fefp_v2_kernel_stats.csv): ten untimed launches, then the median of `reps`
+                for _ in range(10):
                     m.integrate_device(g1.data_ptr(), flux_.data_ptr(), ct_.data_ptr(), st)
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
                 for a, b in ev:
@@ -592,7 +594,7 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=8, tune=True, blocks_per_cu=
         if tune:
             try:
                 ct_best, t_search, k_best = m.fastest_tangent_array(lambda: torch.empty((n, nf * ng), dtype=torch.float64, device=dev),
-                                                                    g1.data_ptr(), flux.data_ptr(), candidates=8, launches=reps)
+                                                                    g1.data_ptr(), flux.data_ptr(), candidates=8, launches=12)
                 t_best = median_ms(flux, ct_best)
                 out[name]["tangent_array_search"] = {"best_launch_per_allocation_ms": [round(t, 4) for t in t_search], "kept": k_best,
                                                      "kernel_ms": round(t_best, 4), "frac": frac(t_best),

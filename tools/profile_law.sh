@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$LAW
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--laws $LAW --points $PTS --reps 8"
+ARGS="--laws $LAW --points $PTS --reps 8 ${DXM_PROFILE_EXTRA:-}"   # DXM_PROFILE_EXTRA=--tangent-search: with the placement searches of the bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/bench_laws.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/bench_laws.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/tools/bench_laws.py $ARGS > $OUT/pmc_write.log 2>&1
