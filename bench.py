@@ -1078,7 +1078,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
                     break
                 ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
                 cands.append(ct)
-                events_ms(3)
+                events_ms(15)   # a newly allocated array needs 10-20 launches to reach its steady time
                 t_ = events_ms(12)
                 stale = 0 if t_ < 0.995 * min(times) else stale + 1
                 times.append(t_)
