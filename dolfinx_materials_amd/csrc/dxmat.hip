@@ -28,6 +28,7 @@
 #include "fefp.hpp"
 #include "gradient.hpp"
 #include "small_strain.hpp"
+#include "host_side.hpp"
 
 using namespace dxm;
 static_assert(TL_FULL == DXM_TANGENT_FULL && TL_SYM == DXM_TANGENT_SYM && TL_COEF == DXM_TANGENT_COEF && TL_PACK4 == DXM_TANGENT_PACK4, "kernel and ABI layout ids");
@@ -110,213 +111,21 @@ static int isv_total(const LawDesc& d) {
 }
 
 // ------------------------------------------------------------------------------------------
-// host side of the host-buffer form: symmetric-packed tangent -> full 6x6 block
+// host side that needs no GPU (worker pool, tangent rebuilds, chunk planner, locked-range table, row moves, upload-route
+// state machine): host_side.hpp, shared with the sanitizer harness of the CPU test suite
 // ------------------------------------------------------------------------------------------
-// The small-strain tangent is Ct = c1 1x1 + c2 I + c3 n x n: nine numbers per point.  The host-buffer form
-// moves those (72 instead of 288 B/point of the 392 B/point that used to come back over PCIe) and
-// rebuilds the (N, 6, 6) block the reference's jacobian_flatten expects (quadrature_map.py:83-105, :334)
-// on the host, chunk by chunk on a few worker threads while the next chunks are still in flight.  The
-// expression is the kernel's own (small_strain.hpp, step 7: t0 + k3 (ni nj) as one fused multiply-add), so
-// the block is bit-identical to the one the full-tangent kernel writes.  For the elastic law the block
-// is a constant and nothing is moved at all.
-#if !defined(__HIP_DEVICE_COMPILE__)
-__attribute__((target("fma")))
-#endif
-static void expand_coef_tangent(const double* __restrict__ s, double* __restrict__ d, int64_t n) {
-  const bool aligned = (reinterpret_cast<uintptr_t>(d) & 15) == 0;
-  for (int64_t p = 0; p < n; ++p, s += 9, d += 36) {
-    const double k1 = s[0], k2 = s[1], k3 = s[2];
-    const double* nv = s + 3;
-    double o[36];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
-        o[i * 6 + j] = __builtin_fma(k3, nv[i] * nv[j], t0);
-      }
-    if (aligned) {   // streaming stores: the block is not read again by these threads
-      for (int k = 0; k < 36; k += 2)
-        __builtin_nontemporal_store(double2_t{o[k], o[k + 1]}, reinterpret_cast<double2_t*>(d + k));
-    } else {
-      for (int k = 0; k < 36; ++k) d[k] = o[k];
-    }
-  }
-}
-
-// The same block from 32 B/point: (c1, c2, c3, w) and the STRESS, which crosses PCIe anyway.  The kernel builds its
-// tangent with n = dev(sigma) w (small_strain.hpp, steps 3 and 5); the three lines that form n are repeated here with
-// every operation individually rounded (no contraction), so the block is the kernel's, bit for bit.
-#if !defined(__HIP_DEVICE_COMPILE__)
-__attribute__((target("fma")))
-#endif
-// With `rows` (a map over a subset of the cells): point p belongs in row rows[p] of the caller's arrays -- its block goes to
-// dbase + rows[p] * 36 and its stress, which landed in the library's own page-locked area, to fdst + rows[p] * 6.
-static void expand_pack4_tangent(const double* __restrict__ sg, const double* __restrict__ cw, double* __restrict__ dbase, int64_t n,
-                                 const int64_t* __restrict__ rows = nullptr, double* __restrict__ fdst = nullptr) {
-#pragma clang fp contract(off)
-  const bool aligned = (reinterpret_cast<uintptr_t>(dbase) & 15) == 0;
-  for (int64_t p = 0; p < n; ++p, sg += 6, cw += 4) {
-    double* d = dbase + (rows ? rows[p] : p) * 36;
-    if (rows) {
-      double* f = fdst + rows[p] * 6;
-      for (int k = 0; k < 6; ++k) f[k] = sg[k];
-    }
-    const double k1 = cw[0], k2 = cw[1], k3 = cw[2], w = cw[3];
-    const double third = (sg[0] + sg[1] + sg[2]) * SS_THIRD;
-    double nv[6];
-    nv[0] = (sg[0] - third) * w; nv[1] = (sg[1] - third) * w; nv[2] = (sg[2] - third) * w;
-    nv[3] = sg[3] * w; nv[4] = sg[4] * w; nv[5] = sg[5] * w;
-    double o[36];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
-        const double nij = nv[i] * nv[j];
-        o[i * 6 + j] = __builtin_fma(k3, nij, t0);
-      }
-    if (aligned) {
-      for (int k = 0; k < 36; k += 2)
-        __builtin_nontemporal_store(double2_t{o[k], o[k + 1]}, reinterpret_cast<double2_t*>(d + k));
-    } else {
-      for (int k = 0; k < 36; ++k) d[k] = o[k];
-    }
-  }
-}
-
-// FeFp: the 9x9 block from its 54 building blocks (fefp.hpp step 6):
-//   A[row=(i,J)][col=(k,L)] = Vc[col] Fi[J][i] + Wc[col] Sr[row] + U[i][L] Fi[J][k] + (i==k) g[L][J]
-// evaluated as the kernel evaluates it (one product, three fused multiply-adds, the Kronecker delta as a 0/1 factor).
-#if !defined(__HIP_DEVICE_COMPILE__)
-__attribute__((target("fma")))
-#endif
-// (rows / fdst / pk as in expand_pack4_tangent: block to dbase + rows[p] * 81, the stress pk[p] to fdst + rows[p] * 9)
-static void expand_fefp_tangent(const double* __restrict__ s, double* __restrict__ dbase, int64_t n, const int64_t* __restrict__ rows = nullptr,
-                                double* __restrict__ fdst = nullptr, const double* __restrict__ pk = nullptr) {
-  static const int TI[9] = {0, 1, 2, 0, 1, 0, 2, 1, 2}, TJ[9] = {0, 1, 2, 1, 0, 2, 0, 2, 1};
-  for (int64_t p = 0; p < n; ++p, s += 54) {
-    double* d = dbase + (rows ? rows[p] : p) * 81;
-    if (rows) {
-      double* f = fdst + rows[p] * 9;
-      for (int k = 0; k < 9; ++k) f[k] = pk[p * 9 + k];
-    }
-    const double* fi = s;
-    for (int r = 0; r < 9; ++r) {
-      const int i = TI[r], J = TJ[r];
-      for (int c = 0; c < 9; ++c) {
-        const int k = TI[c], L = TJ[c];
-        double t = s[9 + c] * fi[J * 3 + i];
-        t = __builtin_fma(s[27 + c], s[36 + r], t);
-        t = __builtin_fma(s[18 + i * 3 + L], fi[J * 3 + k], t);
-        t = __builtin_fma(i == k ? 1.0 : 0.0, s[45 + L * 3 + J], t);
-        d[r * 9 + c] = t;
-      }
-    }
-  }
-}
-
-// elastic law: the same constant block for every point
-static void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, double* __restrict__ dbase, int64_t n, const int64_t* __restrict__ rows = nullptr,
-                               double* __restrict__ fdst = nullptr, const double* __restrict__ sg = nullptr) {
-  double o[36];
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) o[i * 6 + j] = ((i < 3 && j < 3) ? s[0] : 0.0) + ((i == j) ? 2.0 * s[1] : 0.0);
-  for (int64_t p = 0; p < n; ++p) {
-    double* d = dbase + (rows ? rows[p] : p) * 36;
-    for (int k = 0; k < 36; ++k) d[k] = o[k];
-    if (rows)
-      for (int k = 0; k < 6; ++k) fdst[rows[p] * 6 + k] = sg[p * 6 + k];
-  }
-}
-
-// A few persistent worker threads per handle (created on the first host-path call that needs them).
-struct HostPool {
-  // stride 9: J2 coefficients -> 6x6, 4: (c1, c2, c3, w) + the stress rows `aux` -> 6x6, 54: FeFp building blocks -> 9x9,
-  // 0: constant block, -1: plain copy of n BYTES
-  struct Job { const double* src; double* dst; int64_t n; int stride; int tag; const double* aux; const int64_t* rows; double* dst2; };
-  std::vector<std::thread> threads;
-  std::mutex mu;
-  std::condition_variable cv, cv_done, cv_copy;
-  std::deque<Job> queue;
-  int pending = 0;
-  int pending_copy[64] = {};   // plain copies still running, per tag (the chunk they belong to)
-  bool stop = false;
-  explicit HostPool(int nthreads) {
-    for (int t = 0; t < nthreads; ++t) threads.emplace_back([this] { run(); });
-  }
-  ~HostPool() {
-    { std::lock_guard<std::mutex> lk(mu); stop = true; }
-    cv.notify_all();
-    for (auto& t : threads) t.join();
-  }
-  void run() {
-    for (;;) {
-      Job j;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [this] { return stop || !queue.empty(); });
-        if (queue.empty()) return;
-        j = queue.front();
-        queue.pop_front();
-      }
-      if (j.stride == 9) expand_coef_tangent(j.src, j.dst, j.n);
-      else if (j.stride == 4) expand_pack4_tangent(j.aux, j.src, j.dst, j.n, j.rows, j.dst2);
-      else if (j.stride == 54) expand_fefp_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
-      else if (j.stride == -1) memcpy(j.dst, j.src, (size_t)j.n);
-      else fill_const_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        if (j.stride == -1) { if (--pending_copy[j.tag] == 0) cv_copy.notify_all(); }
-        else if (--pending == 0) cv_done.notify_all();
-      }
-    }
-  }
-  // rows [0, n) of one chunk, cut into one piece per thread
-  // (rows != nullptr: dst / dst2 are the BASES of the caller's tangent / flux arrays, rows the index of this chunk, aux the
-  // stress of the chunk where it landed)
-  void submit(const double* src, double* dst, int64_t n, int stride, const double* aux = nullptr, const int64_t* rows = nullptr, double* dst2 = nullptr) {
-    const int64_t pieces = (int64_t)threads.size();
-    const int64_t per = (n + pieces - 1) / pieces;
-    const int nf = stride == 54 ? 9 : 6;
-    std::lock_guard<std::mutex> lk(mu);
-    for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * stride, rows ? dst : dst + o * (stride == 54 ? 81 : 36), std::min(per, n - o), stride, 0, aux ? aux + o * nf : nullptr,
-                          rows ? rows + o : nullptr, dst2});
-      ++pending;
-    }
-    cv.notify_all();
-  }
-  void wait() {
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [this] { return pending == 0; });
-  }
-  // `bytes` from src to dst, cut over the threads and queued AHEAD of any rebuild work; wait_copy(tag) returns when
-  // every piece submitted under that tag (0..63) has been copied
-  void copy_async(const void* src, void* dst, size_t bytes, int tag) {
-    if (bytes <= (256u << 10)) {   // waking the threads costs more than copying this much
-      memcpy(dst, src, bytes);
-      return;
-    }
-    const size_t pieces = std::min<size_t>(threads.size(), 8);
-    const size_t per = ((bytes + pieces - 1) / pieces + 63) / 64 * 64;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      for (size_t o = 0; o < bytes; o += per) {
-        queue.push_front(Job{reinterpret_cast<const double*>(static_cast<const char*>(src) + o),
-                             reinterpret_cast<double*>(static_cast<char*>(dst) + o), (int64_t)std::min(per, bytes - o), -1, tag, nullptr, nullptr, nullptr});
-        ++pending_copy[tag];
-      }
-    }
-    cv.notify_all();
-  }
-  void wait_copy(int tag) {
-    std::unique_lock<std::mutex> lk(mu);
-    cv_copy.wait(lk, [this, tag] { return pending_copy[tag] == 0; });
-  }
-};
+using dxm_host::HostPool;
+using dxm_host::expand_coef_tangent;
+using dxm_host::expand_pack4_tangent;
+using dxm_host::expand_fefp_tangent;
+using dxm_host::fill_const_tangent;
+static_assert(dxm_host::THIRD == SS_THIRD && dxm_host::FEFP_RECORD == FEFP_REC, "host rebuilds and kernels share these constants");
 
 // ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
-constexpr int DXM_MAX_CHUNKS = 64;
-constexpr int DXM_RING = 16;   // slots of the page-locked staging ring
+constexpr int DXM_MAX_CHUNKS = dxm_host::MAX_CHUNKS;
+constexpr int DXM_RING = dxm_host::RING;   // slots of the page-locked staging ring
 
 struct dxm_material {
   int law = 0;
@@ -356,9 +165,7 @@ struct dxm_material {
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
   bool opt_tune_verbose = false;
-  int opt_register_input = 1;             // host path, pageable gradient array: 2 page-lock it for the call (DMA upload), 0 stage it, 1 measure and keep the faster
-  int register_skip = 0;                  // calls left that stage instead (the last registrations were expensive: small pages)
-  int register_calls = 0, register_slow = 0;
+  dxm_host::UploadChooser up;             // option register_input (host path, pageable gradient array): 2 page-lock it for the call (DMA upload), 0 stage it, 1 measure and keep the faster
   int last_upload = DXM_UPLOAD_NONE;      // dxm_stats.upload of the last host-buffer call
   int opt_host_threads = 16;
   int opt_pageable_dma = 0;   // 1: hand pageable host arrays to the runtime (faster uploads; see upload_from_host)
@@ -391,10 +198,6 @@ struct dxm_material {
   hipEvent_t ring_done[DXM_RING] = {};
   int opt_stage_ahead = 3;
   double unregister_ms = 0.0;   // what releasing the call-scoped page-lock of the gradient array took in the last call
-  // option register_input = 1: the handle measures which way a pageable gradient array goes up faster (integrate_host)
-  int up_calls = 0, up_pref = 1, up_since_probe = 0;
-  bool up_probing = false;
-  double up_ms[3] = {0.0, 0.0, 0.0};   // [1] page-locked for the call, [2] staged: best of the calibration calls, then a running mean
 };
 
 static int sync_last(dxm_material* m);
@@ -644,7 +447,7 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   // dxm_set_option("blocks_per_cu") allows); the chunked host path appends the records of up to DXM_MAX_CHUNKS
   // launches, each of min(ceil(chunk / 256), num_cu * blocks_per_cu) workgroups: never more than one record per
   // 256 points plus one partial block per chunk
-  m->stats_capacity = (int)std::min<int64_t>(INT32_MAX, std::max<int64_t>((int64_t)m->num_cu * 256, (npoints + 255) / 256 + DXM_MAX_CHUNKS));
+  m->stats_capacity = dxm_host::stats_capacity(m->num_cu, npoints);
   if (hipMalloc(&m->d_stats, sizeof(BlockStats) * m->stats_capacity) != hipSuccess) {
     fail(-3, "hipMalloc of stats failed"); return bail();
   }
@@ -760,25 +563,11 @@ static int materialize_s1(dxm_material* m) {
 // is used directly; anything else goes through this page-locked staging (two halves in flight) and a CPU copy.
 constexpr size_t BOUNCE_BYTES = 16u << 20;
 // Host ranges this library has page-locked itself (dxm_host_alloc, dxm_host_register): start -> bytes.
-static std::mutex g_locked_mu;
-static std::map<uintptr_t, size_t> g_locked_ranges;
+static dxm_host::LockedTable g_locked;
 static std::atomic<int> g_query_foreign{1};   // ask the runtime about pointers that are not in the table (option "query_foreign_pointers")
-static void note_locked(const void* p, size_t bytes) {
-  std::lock_guard<std::mutex> lk(g_locked_mu);
-  g_locked_ranges[reinterpret_cast<uintptr_t>(p)] = bytes;
-}
-static void forget_locked(const void* p) {
-  std::lock_guard<std::mutex> lk(g_locked_mu);
-  g_locked_ranges.erase(reinterpret_cast<uintptr_t>(p));
-}
-static bool in_locked_table(const void* host, size_t bytes) {
-  const uintptr_t a = reinterpret_cast<uintptr_t>(host);
-  std::lock_guard<std::mutex> lk(g_locked_mu);
-  auto it = g_locked_ranges.upper_bound(a);
-  if (it == g_locked_ranges.begin()) return false;
-  --it;
-  return a >= it->first && a + bytes <= it->first + it->second;
-}
+static void note_locked(const void* p, size_t bytes) { g_locked.note(p, bytes); }
+static void forget_locked(const void* p) { g_locked.forget(p); }
+static bool in_locked_table(const void* host, size_t bytes) { return g_locked.contains(host, bytes); }
 static bool page_locked_byte(const void* host) {
   hipPointerAttribute_t attr{};
   const bool locked = host && hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost;
@@ -1019,10 +808,8 @@ static int launch_range(dxm_material* m, int64_t off, int64_t cnt, const double*
   if (((uintptr_t)grad | (uintptr_t)flux | (uintptr_t)ct) & 15)
     return fail(-1, "gradient / flux / tangent device arrays must be 16-byte aligned");
   m->io1_valid = 0;   // s1 is being rewritten; a host-buffer call that completes sets it again
-  const int64_t ntiles = (cnt + WAVE - 1) / WAVE;
-  int64_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  const int64_t cap = (int64_t)m->num_cu * m->blocks_per_cu;
-  if (blocks > cap) blocks = cap;
+  static_assert(WAVE * WAVES_PER_BLOCK == 256, "dxm_host::launch_grid counts workgroups of 256 points");
+  const int64_t blocks = dxm_host::launch_grid(cnt, m->num_cu, m->blocks_per_cu);
   if (stats_off + blocks > m->stats_capacity) return fail(-1, "internal: stats buffer too small");
   const int grid = (int)blocks;
   switch (m->law) {
@@ -1335,15 +1122,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     m->elastic_lm[0] = m->prm.lambda;
     m->elastic_lm[1] = m->prm.mu;
   }
-  // the last chunk's host expansion is not hidden behind any transfer: many small chunks keep that tail short
-  int nchunks = (int)(n / (packed ? (n >= 2097152 ? 65536 : 32768) : 131072));
-  if (nchunks < 1) nchunks = 1;
-  if (!packed && nchunks > (host_grad ? 32 : 8)) nchunks = host_grad ? 32 : 8;   // staged uploads start later: shorter chunks
-  if (nchunks > m->opt_max_chunks) nchunks = m->opt_max_chunks;
-  if (!m->opt_pipeline) nchunks = 1;
+  const dxm_host::ChunkPlan plan = dxm_host::plan_chunks(n, packed, host_grad != nullptr, m->opt_max_chunks, m->opt_pipeline);
+  const int nchunks = plan.nchunks;
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));
-  const int64_t csize = ((n + nchunks - 1) / nchunks + 255) / 256 * 256;
+  const int64_t csize = plan.csize;
   if (host_grad) {
     const int64_t need = csize * d.n_grad;
     if (m->ring_slot_doubles < need) {
@@ -1391,8 +1174,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   auto stage_chunk = [&](int p) -> int {
     const int64_t o = (int64_t)p * csize;
     if (!host_grad || p >= nchunks || o >= n) return 0;
-    if (p >= DXM_RING) HIP_TRY(hipEventSynchronize(m->ring_done[p % DXM_RING]));   // the copy kernel of chunk p - DXM_RING has read this slot
-    m->pool->copy_async(host_grad + o * d.n_grad, m->h_grad_ring + (int64_t)(p % DXM_RING) * m->ring_slot_doubles,
+    if (p >= DXM_RING) HIP_TRY(hipEventSynchronize(m->ring_done[dxm_host::ring_slot(p)]));   // the copy kernel of chunk p - DXM_RING has read this slot
+    m->pool->copy_async(host_grad + o * d.n_grad, m->h_grad_ring + (int64_t)dxm_host::ring_slot(p) * m->ring_slot_doubles,
                         sizeof(double) * ((n - o) < csize ? (n - o) : csize) * d.n_grad, p);
     return 0;
   };
@@ -1407,7 +1190,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (int rc = upload(off, cnt, st)) return rc;
     const double* gptr = fused ? m->d_flux : m->d_grad + off * d.n_grad;
     if (host_grad) {
-      const int slot = c % DXM_RING;
+      const int slot = dxm_host::ring_slot(c);
       double* dst = m->h_grad_ring + (int64_t)slot * m->ring_slot_doubles;
       if (int rc = stage_chunk(c + ahead)) return rc;   // keep `ahead` chunks ahead of the launches
       {
@@ -1538,29 +1321,12 @@ static int integrate_host_impl(dxm_material* m, const double* grad_aos, double* 
     }
   } temp;
   temp.m = m;
-  if (!locked_in && m->opt_register_input && (size_t)n * d.n_grad * sizeof(double) >= ((size_t)1 << 20)) {
+  if (!locked_in && (size_t)n * d.n_grad * sizeof(double) >= ((size_t)1 << 20)) {
     // Which of the two is faster depends on the host (where the caller's pages sit relative to the GPU, what else runs on the
-    // machine): DMA out of a freshly page-locked range is 2-3 ms ahead of the staging ring on most boxes of the pool and 5-9 ms
-    // behind on some (profiles/r03_hostpath_adaptive_upload.md).  With option register_input = 1 the handle finds out: its
-    // first call is not judged (one-time set-up), calls 2-5 alternate between the two ways, the faster one (by the call's
-    // whole duration; page-locking wins a tie within 5 %) is kept, and the other gets one call in 32 to prove itself.
-    // 2 = always page-lock, 0 = always stage.
-    int way = 1;
-    if (m->opt_register_input == 1) {
-      const int k = m->up_calls;
-      if (k >= 1 && k <= 4) way = (k % 2 == 1) ? 1 : 2;
-      else if (k > 4) {
-        way = m->up_pref;
-        if (++m->up_since_probe >= 32) { way = 3 - m->up_pref; m->up_probing = true; m->up_since_probe = 0; }
-      }
-    }
+    // machine): the handle measures it (dxm_host::UploadChooser, option register_input).
+    const int way = m->up.choose();   // 0: option off, 1: page-lock for the call, 2: stage through the ring
     *upload_choice = way;
-    if (way == 2) {
-      // staged through the ring
-    } else if (m->register_skip > 0) {
-      --m->register_skip;
-      *upload_choice = 2;
-    } else {
+    if (way == 1) {
       void* p = const_cast<double*>(grad_aos);
       const size_t bytes = sizeof(double) * n * d.n_grad;
       const auto t0 = std::chrono::steady_clock::now();
@@ -1571,18 +1337,10 @@ static int integrate_host_impl(dxm_material* m, const double* grad_aos, double* 
         // then takes 43 instead of 28 ms: such arrays go through the staging ring for the next 20 calls, then one more try
         const double ms_lock = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] page-locking the gradient array took %.3f ms (releasing it after the previous call: %.3f ms)\n", ms_lock, m->unregister_ms);
-        const double ms = ms_lock + m->unregister_ms;   // what the previous call paid to release its range counts too
-        const double ms_per_gb = ms > 0.5 ? (ms - 0.5) / ((double)bytes / 1e9) : 0.0;   // half a millisecond of fixed cost is fine for any size
-        // (the first registration of a handle also pays for one-time set-up in the runtime and is not judged; three expensive
-        // ones in a row -- above 10 ms/GB: a loaded host makes a huge-page registration take 2-4 ms now and then -- are)
-        if (m->register_calls++ > 0 && ms_per_gb > 10.0) {
-          if (++m->register_slow >= 3) { m->register_skip = 20; m->register_slow = 0; }
-        } else {
-          m->register_slow = 0;
-        }
+        m->up.registered(ms_lock + m->unregister_ms, bytes);   // what the previous call paid to release its range counts too
       } else {
         (void)hipGetLastError();
-        m->register_skip = 20;
+        m->up.refused();
         *upload_choice = 2;
       }
     }
@@ -1616,29 +1374,13 @@ static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_
   int way = 0;
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = integrate_host_impl(m, grad_aos, flux_aos, isv_aos, ct_aos, stats, rows, &way);
-  if (rc < 0 || way == 0 || m->opt_register_input != 1) return rc;
+  if (rc < 0) return rc;
   // the adaptive choice between page-locking the caller's gradient array for the call and staging it (see above)
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  const int k = m->up_calls++;
-  if (k == 0) return rc;
-  if (k <= 4) {
-    m->up_ms[way] = m->up_ms[way] == 0.0 ? ms : std::min(m->up_ms[way], ms);
-    if (k == 4) {
-      m->up_pref = (m->up_ms[2] > 0.0 && m->up_ms[1] > 0.0 && m->up_ms[2] < 0.95 * m->up_ms[1]) ? 2 : 1;
-      if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] gradient upload: page-locked for the call %.2f ms, staged %.2f ms per call -> %s\n",
-                                       m->up_ms[1], m->up_ms[2], m->up_pref == 1 ? "page-locking" : "staging");
-    }
-  } else if (m->up_probing) {
-    m->up_probing = false;
-    const bool better = way == 2 ? ms < 0.95 * m->up_ms[m->up_pref] : ms < 1.05 * m->up_ms[m->up_pref];
-    if (way != m->up_pref && better) {
-      if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] gradient upload: switching to %s (%.2f against %.2f ms)\n", way == 1 ? "page-locking" : "staging", ms, m->up_ms[m->up_pref]);
-      m->up_pref = way;
-    }
-    m->up_ms[way] = ms;
-  } else {
-    m->up_ms[way] = 0.75 * m->up_ms[way] + 0.25 * ms;
-  }
+  const bool changed = m->up.record(way, ms);
+  if (m->opt_tune_verbose && way && m->up.opt == 1 && (changed || m->up.calls == 5))
+    fprintf(stderr, "[dxm host path] gradient upload: page-locked for the call %.2f ms, staged %.2f ms per call -> %s\n",
+            m->up.ms[1], m->up.ms[2], m->up.pref == 1 ? "page-locking" : "staging");
   return rc;
 }
 
@@ -2184,8 +1926,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   }
   else if (k == "register_input") {
     if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(-1, "register_input must be 0, 1 or 2");
-    m->opt_register_input = (int)value;
-    m->up_calls = 0; m->up_pref = 1; m->up_since_probe = 0; m->up_probing = false; m->up_ms[1] = m->up_ms[2] = 0.0;
+    m->up.set_option((int)value);
   }
   else if (k == "keep_initial_io") m->opt_keep_initial_io = on;
   else if (k == "pageable_dma") m->opt_pageable_dma = value != 0.0;
@@ -2230,39 +1971,15 @@ int dxm_isv_host(dxm_material* m, int which, double* isv_aos) {
 int dxm_host_copy(void* dst, const void* src, uint64_t bytes, int threads) {
   if (bytes == 0) return 0;
   if (!dst || !src) return fail(-1, "null host pointer");
-  int nt = threads > 0 ? threads : 8;
-  if (nt > 64) nt = 64;
-  if (bytes < (uint64_t)(4u << 20) || nt == 1) { memcpy(dst, src, bytes); return 0; }
-  const uint64_t per = ((bytes + nt - 1) / nt + 4095) / 4096 * 4096;
-  std::vector<std::thread> pool;
-  for (uint64_t o = per; o < bytes; o += per)
-    pool.emplace_back([=] { memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, (size_t)std::min<uint64_t>(per, bytes - o)); });
-  memcpy(dst, src, (size_t)std::min<uint64_t>(per, bytes));
-  for (auto& t : pool) t.join();
+  dxm_host::host_copy(dst, src, bytes, threads);
   return 0;
 }
 
-// rows of `width` doubles moved through an index, the i-range cut over `threads` threads: what a QuadratureMap over a SUBSET of
-// the cells does with every result array per update (utils.py:136-143 `array[index] = values`; numpy's fancy assignment runs on
-// one core: 1 s per 1e7 x 36 doubles)
+// rows of `width` doubles moved through an index on several threads (utils.py:136-143 `array[index] = values`)
 static int move_rows(bool scatter, double* dst, const double* src, const int64_t* rows, int64_t n, int width, int threads) {
   if (n <= 0 || width <= 0) return 0;
   if (!dst || !src || !rows) return fail(-1, "null host pointer");
-  int nt = threads > 0 ? threads : 8;
-  if (nt > 64) nt = 64;
-  if ((uint64_t)n * width < (uint64_t)(1u << 18)) nt = 1;
-  auto work = [=](int64_t a, int64_t b) {
-    const size_t bytes = sizeof(double) * width;
-    for (int64_t i = a; i < b; ++i) {
-      if (scatter) memcpy(dst + rows[i] * width, src + i * width, bytes);
-      else memcpy(dst + i * width, src + rows[i] * width, bytes);
-    }
-  };
-  const int64_t per = (n + nt - 1) / nt;
-  std::vector<std::thread> pool;
-  for (int64_t a = per; a < n; a += per) pool.emplace_back(work, a, std::min<int64_t>(a + per, n));
-  work(0, std::min<int64_t>(per, n));
-  for (auto& t : pool) t.join();
+  dxm_host::move_rows(scatter, dst, src, rows, n, width, threads);
   return 0;
 }
 

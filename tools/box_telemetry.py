@@ -1,0 +1,418 @@
+#!/usr/bin/env python3
+"""What the BOX looks like from its own side: clocks, power, partition modes, VRAM co-tenancy, RAS.
+
+Pure sysfs / `rocm-smi` / `amd-smi` reads from an ordinary user process: no HIP call, no exec of a GPU program, never under
+rocprofv3.  Three entry points:
+
+    snapshot(pci=None)       one dict of everything readable now (static identity + current clocks / power / memory)
+    Sampler(pci, period_s)   a side thread that reads the cheap sysfs files (sclk, mclk, fclk, power, busy) every few ms
+    python tools/box_telemetry.py [--raw]   print one snapshot as JSON (``--raw`` adds the unparsed tool outputs)
+
+bench.py calls `snapshot` before and after its timed region and runs a `Sampler` across the K timed steps; tools/box_survey.py
+adds the bandwidth probes.  Every read is best-effort: a file or tool that is missing shows up as null, never as an exception.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+import threading
+import time
+
+DRM = "/sys/class/drm"
+
+
+def _read(path, limit=4096):
+    try:
+        with open(path, "r") as f:
+            return f.read(limit).strip()
+    except Exception:
+        return None
+
+
+def _num(text):
+    try:
+        return int(text)
+    except Exception:
+        try:
+            return float(text)
+        except Exception:
+            return None
+
+
+def cards():
+    """DRM card directories that belong to the amdgpu driver, in card order."""
+    out = []
+    for d in sorted(glob.glob(os.path.join(DRM, "card[0-9]*")), key=lambda s: int(re.sub(r"\D", "", os.path.basename(s)) or 0)):
+        if "-" in os.path.basename(d):
+            continue
+        dev = os.path.join(d, "device")
+        drv = os.path.realpath(os.path.join(dev, "driver"))
+        if os.path.basename(drv) == "amdgpu" or os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+            out.append(dev)
+    return out
+
+
+def _render_minor(dev):
+    r = glob.glob(os.path.join(dev, "drm", "renderD*"))
+    return int(re.sub(r"\D", "", os.path.basename(r[0]))) if r else None
+
+
+def my_card(pci=None):
+    """The sysfs device directory of the GPU THIS process can use.  A box of this pool exposes the sysfs of every GPU of the
+    node but the device nodes of one: the card whose /dev/dri/renderD<minor> is openable is ours.  `pci` (e.g. the bus id the
+    HIP runtime reports, "0000:0d:00.0") overrides; with several usable cards the first is returned."""
+    devs = cards()
+    if pci:
+        want = pci.lower()
+        for d in devs:
+            if os.path.basename(os.path.realpath(d)).lower() == want:
+                return d
+    usable = []
+    for d in devs:
+        m = _render_minor(d)
+        if m is not None and os.access(f"/dev/dri/renderD{m}", os.R_OK | os.W_OK):
+            usable.append(d)
+    if usable:
+        return usable[0]
+    return devs[0] if devs else None
+
+
+def _dpm(text):
+    """`pp_dpm_*` -> (current MHz, [levels MHz]); the current level carries a '*'."""
+    if not text:
+        return None, []
+    cur, levels = None, []
+    for line in text.splitlines():
+        m = re.search(r"(\d+)\s*Mhz", line, re.I)
+        if not m:
+            continue
+        levels.append(int(m.group(1)))
+        if "*" in line:
+            cur = int(m.group(1))
+    return cur, levels
+
+
+def _hwmon(dev):
+    hs = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+    return hs[0] if hs else None
+
+
+def fast_read(dev, hw=None):
+    """The cheap per-sample set (a handful of small sysfs files)."""
+    hw = hw or _hwmon(dev)
+    rec = {}
+    for key, f in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk"), ("socclk", "pp_dpm_socclk")):
+        rec[key] = _dpm(_read(os.path.join(dev, f)))[0]
+    rec["gpu_busy"] = _num(_read(os.path.join(dev, "gpu_busy_percent")))
+    rec["mem_busy"] = _num(_read(os.path.join(dev, "mem_busy_percent")))
+    if hw:
+        p = _num(_read(os.path.join(hw, "power1_average")))
+        if p is None:
+            p = _num(_read(os.path.join(hw, "power1_input")))
+        rec["power_w"] = round(p / 1e6, 1) if p is not None else None
+        t = _num(_read(os.path.join(hw, "temp1_input")))
+        rec["temp_c"] = round(t / 1e3, 1) if t is not None else None
+        f1 = _num(_read(os.path.join(hw, "freq1_input")))
+        f2 = _num(_read(os.path.join(hw, "freq2_input")))
+        rec["hwmon_sclk"] = round(f1 / 1e6) if f1 else None
+        rec["hwmon_mclk"] = round(f2 / 1e6) if f2 else None
+    return rec
+
+
+def _tool(cmd, timeout=20):
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        return r.returncode, r.stdout, r.stderr[-300:]
+    except Exception as exc:
+        return None, "", repr(exc)
+
+
+def _json_tool(cmd, timeout=25):
+    rc, out, err = _tool(cmd, timeout)
+    if not out:
+        return {"error": f"rc {rc}: {err}"}
+    try:
+        i = min([k for k in (out.find("{"), out.find("[")) if k >= 0])
+        return json.loads(out[i:])
+    except Exception as exc:
+        return {"error": f"unparsed ({exc!r})", "head": out[:300]}
+
+
+def snapshot(pci=None, tools=True, raw=False):
+    """Everything readable about this process's GPU (`my_card(pci)`) as one JSON-able dict."""
+    devs = cards()
+    rec = {"time": time.time(), "n_cards": len(devs), "host": {"cpus": os.cpu_count(), "loadavg": _read("/proc/loadavg")}}
+    try:
+        rec["host"]["kernel"] = os.uname().release
+    except Exception:
+        pass
+    rec["host"]["thp"] = _read("/sys/kernel/mm/transparent_hugepage/enabled")
+    rec["host"]["numa_nodes"] = len(glob.glob("/sys/devices/system/node/node[0-9]*")) or None
+    if not devs:
+        rec["error"] = "no amdgpu card under /sys/class/drm"
+        if tools:
+            rec["rocm_smi"] = _rocm_smi(raw)
+        return rec
+    dev = my_card(pci)
+    hw = _hwmon(dev)
+    rec["render_node_usable"] = bool(_render_minor(dev) is not None and os.access(f"/dev/dri/renderD{_render_minor(dev)}", os.R_OK | os.W_OK))
+    # the node's population: every GPU whose sysfs is visible, busy or not (other tenants' GPUs of a shared node)
+    rec["node_gpus"] = [{"pci": os.path.basename(os.path.realpath(d)), "unique_id": _read(os.path.join(d, "unique_id")),
+                         "gpu_busy": _num(_read(os.path.join(d, "gpu_busy_percent"))), "mem_busy": _num(_read(os.path.join(d, "mem_busy_percent"))),
+                         "vram_used": _num(_read(os.path.join(d, "mem_info_vram_used"))), "mine": d == dev} for d in devs]
+    rec["card"] = os.path.basename(os.path.dirname(dev))
+    rec["pci"] = os.path.basename(os.path.realpath(dev))
+    rec["now"] = fast_read(dev, hw)
+    for key, f in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk"), ("socclk", "pp_dpm_socclk")):
+        cur, lv = _dpm(_read(os.path.join(dev, f)))
+        rec[key + "_levels"] = lv
+        rec[key + "_max"] = max(lv) if lv else None
+    ident = {}
+    for f in ("vbios_version", "unique_id", "revision", "device", "subsystem_device", "current_link_speed", "current_link_width", "max_link_speed",
+              "max_link_width", "numa_node", "local_cpulist", "power_dpm_force_performance_level", "current_compute_partition",
+              "current_memory_partition", "available_compute_partition", "available_memory_partition", "mem_info_vram_total",
+              "mem_info_vram_used", "mem_info_vis_vram_used", "mem_info_gtt_used", "mem_info_vram_vendor", "pp_power_profile_mode",
+              "thermal_throttling_logging", "xgmi_plpd_policy", "pm_policy/soc_pstate", "pm_policy/xgmi_plpd", "pcie_replay_count",
+              "gpu_metrics"):
+        if f == "gpu_metrics":
+            continue
+        v = _read(os.path.join(dev, f))
+        if v is not None:
+            ident[f.replace("/", "_")] = _num(v) if re.fullmatch(r"-?\d+", v or "") else v
+    rec["sysfs"] = ident
+    if hw:
+        cap = {}
+        for f in ("power1_cap", "power1_cap_max", "power1_cap_min", "power1_cap_default", "power1_average", "power1_input", "temp1_input", "temp2_input",
+                  "temp3_input", "temp1_crit", "temp3_crit", "in0_input"):
+            v = _num(_read(os.path.join(hw, f)))
+            if v is not None:
+                cap[f] = v
+        rec["hwmon"] = cap
+    # RAS: retired / bad pages and error counts
+    ras = {}
+    for f in sorted(glob.glob(os.path.join(dev, "ras", "*"))):
+        name = os.path.basename(f)
+        if name in ("gpu_vram_bad_pages", "features", "schema", "event_state") or name.endswith("_err_count"):
+            v = _read(f, 2048)
+            if v is None:
+                continue
+            if name == "gpu_vram_bad_pages":
+                ras["bad_pages"] = max(0, len([ln for ln in v.splitlines() if ":" in ln and "0x" in ln]))
+            else:
+                ras[name] = v[:160]
+    rec["ras"] = ras or None
+    # KFD view: CU count, max engine clock, who else holds VRAM
+    kfd = {}
+    my_minor = _render_minor(dev)
+    for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*")):
+        props = _read(os.path.join(node, "properties"), 8192)
+        if not props or "simd_count 0" in props:
+            continue
+        p = dict(ln.split(None, 1) for ln in props.splitlines() if len(ln.split(None, 1)) == 2)
+        if my_minor is not None and _num(p.get("drm_render_minor")) != my_minor:
+            continue   # another GPU of the node
+        kfd["gpu_id"] = _read(os.path.join(node, "gpu_id"))
+        kfd.setdefault("nodes", []).append({k: _num(p.get(k)) for k in ("simd_count", "cu_count", "array_count", "num_xcc", "max_engine_clk_fcompute",
+                                                                          "local_mem_size", "gfx_target_version", "drm_render_minor", "num_sdma_engines",
+                                                                          "num_sdma_xgmi_engines", "simd_per_cu", "max_waves_per_simd")})
+    procs = glob.glob("/sys/class/kfd/kfd/proc/[0-9]*")
+    kfd["processes_visible"] = len(procs)
+    vram_by_proc = []
+    for p in procs:
+        for f in glob.glob(os.path.join(p, "vram_*")):
+            v = _num(_read(f))
+            if v:
+                vram_by_proc.append({"pid": int(os.path.basename(p)), "gpuid": f.rsplit("_", 1)[-1], "vram_bytes": v})
+    kfd["vram_by_process"] = vram_by_proc
+    rec["kfd"] = kfd
+    rec["driver_version"] = _read("/sys/module/amdgpu/version") or rec["host"].get("kernel")
+    if tools:
+        rec["rocm_smi"] = _rocm_smi(raw)
+        rec["amd_smi"] = _amd_smi(raw)
+    return rec
+
+
+def _rocm_smi(raw=False):
+    exe = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "rocm-smi not found"}
+    j = _json_tool([exe, "--showclocks", "--showpower", "--showmaxpower", "--showmemuse", "--showmeminfo", "vram", "--showcomputepartition",
+                    "--showmemorypartition", "--showperflevel", "--showtemp", "--showretiredpages", "--showvbios", "--showdriverversion", "--showuse",
+                    "--showpids", "--json"])
+    return j
+
+
+def _amd_smi(raw=False):
+    exe = "/opt/rocm/bin/amd-smi"
+    if not os.path.exists(exe):
+        return {"error": "amd-smi not found"}
+    out = {}
+    out["metric"] = _json_tool([exe, "metric", "--clock", "--power", "--mem-usage", "--usage", "--json"], timeout=30)
+    out["static"] = _json_tool([exe, "static", "--vbios", "--limit", "--partition", "--vram", "--driver", "--json"], timeout=30)
+    return out
+
+
+METRIC_KEYS = ("accumulation_counter", "ppt_residency_acc", "prochot_residency_acc", "socket_thm_residency_acc", "vr_thm_residency_acc",
+               "hbm_thm_residency_acc", "gfx_activity_acc", "mem_activity_acc", "energy_accumulator", "current_uclk", "current_gfxclk",
+               "current_socket_power", "temperature_hotspot", "temperature_mem", "temperature_vrsoc", "average_umc_activity",
+               "average_gfx_activity", "throttle_status", "indep_throttle_status", "vram_max_bandwidth", "firmware_timestamp",
+               "pcie_bandwidth_inst", "gfx_below_host_limit_acc", "gfx_below_host_limit_ppt_acc", "gfx_below_host_limit_thm_acc",
+               "gfx_low_utilization_acc", "gfx_below_host_limit_total_acc")
+
+
+def metrics():
+    """The firmware's `gpu_metrics` table through `rocm-smi --showmetrics --json` (a child process; ~0.3 s): accumulated
+    throttle residencies (power, thermal, HBM thermal), activity and energy accumulators, uclk.  Keys without the unit suffix."""
+    exe = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "rocm-smi not found"}
+    j = _json_tool([exe, "--showmetrics", "--json"], timeout=20)
+    if "error" in j:
+        return j
+    card = next((v for k, v in j.items() if k.startswith("card")), None)
+    if not isinstance(card, dict):
+        return {"error": "no card in rocm-smi --showmetrics", "keys": list(j)[:5]}
+    out = {"t": time.time()}
+    for k, v in card.items():
+        base = k.split(" (")[0].strip()
+        if base in METRIC_KEYS or base.startswith("xcp_stats.gfx_below_host_limit"):
+            if isinstance(v, str):
+                try:
+                    v = json.loads(v.replace("'", '"'))
+                except Exception:
+                    pass
+            if isinstance(v, str) and re.fullmatch(r"-?\d+(\.\d+)?", v):
+                v = float(v) if "." in v else int(v)
+            out[base] = v
+    return out
+
+
+def metrics_delta(a, b):
+    """What the accumulators did between two `metrics()` reads: throttle residencies as fractions of the firmware's sample
+    count, mean activity, mean socket power from the energy accumulator."""
+    if not a or not b or "error" in a or "error" in b:
+        return {"error": (a or {}).get("error") or (b or {}).get("error") or "no metrics"}
+    out = {"seconds": round(b["t"] - a["t"], 3)}
+
+    def d(key):
+        x, y = a.get(key), b.get(key)
+        return (y - x) if isinstance(x, (int, float)) and isinstance(y, (int, float)) else None
+
+    n = d("accumulation_counter")
+    out["firmware_samples"] = n
+    for key in ("ppt_residency_acc", "prochot_residency_acc", "socket_thm_residency_acc", "vr_thm_residency_acc", "hbm_thm_residency_acc"):
+        v = d(key)
+        out[key.replace("_acc", "_frac")] = round(v / n, 4) if (v is not None and n) else None
+    for key in ("gfx_activity_acc", "mem_activity_acc"):
+        v = d(key)
+        out[key.replace("_acc", "_mean_pct")] = round(v / n, 2) if (v is not None and n) else None
+    e = d("energy_accumulator")
+    if e is not None and out["seconds"] > 0:
+        out["mean_socket_power_w"] = round(e * 15.259e-6 / out["seconds"], 1)
+    for key in ("current_uclk", "current_gfxclk", "temperature_hotspot", "temperature_mem", "temperature_vrsoc", "throttle_status", "indep_throttle_status"):
+        out[key + "_end"] = b.get(key)
+    for k, v in b.items():
+        if k.startswith("xcp_stats.gfx_below_host_limit") and isinstance(v, list) and isinstance(a.get(k), list):
+            try:
+                out[k.replace("xcp_stats.", "") + "_delta"] = [int(y) - int(x) for x, y in zip(a[k], v) if str(x).lstrip("-").isdigit() and str(y).lstrip("-").isdigit()]
+            except Exception:
+                pass
+    return out
+
+
+def condensed(snap):
+    """The dozen figures of a snapshot that go into a bench line."""
+    if not snap or "sysfs" not in snap:
+        return {"error": (snap or {}).get("error", "no snapshot"), "rocm_smi": (snap or {}).get("rocm_smi")}
+    s, h, now = snap["sysfs"], snap.get("hwmon", {}), snap["now"]
+    node = (snap.get("kfd", {}).get("nodes") or [{}])[0]
+    mine = os.getpid()
+    gid = snap.get("kfd", {}).get("gpu_id")
+    others = [p for p in snap.get("kfd", {}).get("vram_by_process", []) if p["pid"] != mine and (gid is None or p["gpuid"] == gid)]
+    elsewhere = [p for p in snap.get("kfd", {}).get("vram_by_process", []) if gid is not None and p["gpuid"] != gid]
+    return {
+        "card": snap.get("card"), "pci": snap.get("pci"), "unique_id": s.get("unique_id"), "vbios": s.get("vbios_version"), "driver": snap.get("driver_version"),
+        "num_cu": node.get("cu_count"), "num_xcc": node.get("num_xcc"), "max_engine_clk": node.get("max_engine_clk_fcompute"),
+        "compute_partition": s.get("current_compute_partition"), "memory_partition": s.get("current_memory_partition"),
+        "perf_level": s.get("power_dpm_force_performance_level"),
+        "sclk": now.get("sclk"), "sclk_max": snap.get("sclk_max"), "mclk": now.get("mclk"), "mclk_max": snap.get("mclk_max"),
+        "fclk": now.get("fclk"), "fclk_max": snap.get("fclk_max"), "socclk": now.get("socclk"),
+        "power_w": now.get("power_w"), "power_cap_w": round(h["power1_cap"] / 1e6) if h.get("power1_cap") else None,
+        "power_cap_max_w": round(h["power1_cap_max"] / 1e6) if h.get("power1_cap_max") else None,
+        "temp_c": now.get("temp_c"), "hbm_temp_c": round(h["temp3_input"] / 1e3, 1) if h.get("temp3_input") else None,
+        "gpu_busy": now.get("gpu_busy"), "mem_busy": now.get("mem_busy"),
+        "vram_total": s.get("mem_info_vram_total"), "vram_used": s.get("mem_info_vram_used"),
+        "vram_other_processes_on_my_gpu": sum(p["vram_bytes"] for p in others) if others else 0,
+        "vram_processes_on_other_gpus_of_the_node": sum(p["vram_bytes"] for p in elsewhere) if elsewhere else 0, "kfd_processes_visible": snap.get("kfd", {}).get("processes_visible"),
+        "ras_bad_pages": (snap.get("ras") or {}).get("bad_pages"),
+        "pcie": f"{s.get('current_link_speed')} x{s.get('current_link_width')}", "numa_node": s.get("numa_node"),
+        "host_cpus": snap["host"].get("cpus"), "host_loadavg": snap["host"].get("loadavg"),
+        "render_node_usable": snap.get("render_node_usable"),
+        "node_gpus_visible": len(snap.get("node_gpus") or []),
+        "node_gpus_busy_besides_mine": sum(1 for g in (snap.get("node_gpus") or []) if not g["mine"] and ((g.get("gpu_busy") or 0) > 0 or (g.get("vram_used") or 0) > 2**30)),
+    }
+
+
+class Sampler:
+    """Reads the cheap sysfs set every `period_s` on a side thread (pure file reads: no GPU runtime call)."""
+
+    def __init__(self, pci=None, period_s=0.005):
+        self.dev = my_card(pci)
+        self.hw = _hwmon(self.dev) if self.dev else None
+        self.period = period_s
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+
+    def __enter__(self):
+        self.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+
+    def start(self):
+        if self.dev is None:
+            return
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        t0 = time.perf_counter()
+        while not self._stop.is_set():
+            rec = fast_read(self.dev, self.hw)
+            rec["t"] = round(time.perf_counter() - t0, 4)
+            self.samples.append(rec)
+            self._stop.wait(self.period)
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=2.0)
+            self._thread = None
+
+    def summary(self):
+        """min / median / max per field over the samples."""
+        if not self.samples:
+            return {"samples": 0, "note": "no amdgpu sysfs on this box" if self.dev is None else "no sample taken"}
+        out = {"samples": len(self.samples), "span_s": self.samples[-1]["t"], "period_s": self.period}
+        for k in ("sclk", "mclk", "fclk", "socclk", "power_w", "gpu_busy", "mem_busy", "temp_c", "hwmon_sclk", "hwmon_mclk"):
+            vals = sorted(v for v in (s.get(k) for s in self.samples) if v is not None)
+            if vals:
+                out[k] = [vals[0], vals[len(vals) // 2], vals[-1]]
+        return out
+
+
+def main():
+    raw = "--raw" in sys.argv
+    snap = snapshot(raw=raw)
+    print(json.dumps({"condensed": condensed(snap), "snapshot": snap}, indent=1 if sys.stdout.isatty() else None))
+
+
+if __name__ == "__main__":
+    main()

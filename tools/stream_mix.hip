@@ -241,3 +241,41 @@ extern "C" int stream_mix_fefp_shape_launch(const void* F, const void* s0, void*
 #undef DXM_SHAPE
   return (int)hipGetLastError();
 }
+
+// Clock-stamped variant of the non-temporal probe (box survey): workgroup 0..gridDim-1 records the shader-clock counter
+// (s_memtime) and the constant 100 MHz counter (s_memrealtime) on entry and exit into stamps[4 * block .. +3], memory that
+// nothing else reads.  Host side: shader clock under THIS load = d(memtime) / d(memrealtime) x 100 MHz, median over
+// workgroups (MI355X_MICROARCH.md, DVFS give-back, item 6).
+__global__ void __launch_bounds__(256) stream_mix_clock_kernel(const double2_t* __restrict__ rbuf, double2_t* __restrict__ wbuf,
+                                                               int64_t ntiles, int rpairs, int wpairs,
+                                                               unsigned long long* __restrict__ stamps) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const double2_t* r = rbuf + t * rpairs;
+    double2_t acc = {0.0, 0.0};
+#pragma unroll 4
+    for (int idx = lane; idx < rpairs; idx += 64) acc += r[idx];
+    double2_t* w = wbuf + t * wpairs;
+#pragma unroll 8
+    for (int idx = lane; idx < wpairs; idx += 64) __builtin_nontemporal_store(acc, w + idx);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    unsigned long long* s = stamps + 4 * (int64_t)blockIdx.x;
+    s[0] = c0; s[1] = r0; s[2] = c1; s[3] = r1;
+  }
+}
+
+extern "C" int stream_mix_clock_launch(const void* rbuf, void* wbuf, int64_t npoints, int read_bytes_per_point,
+                                       int write_bytes_per_point, int blocks, void* stamps, void* stream) {
+  hipLaunchKernelGGL(stream_mix_clock_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double2_t*)rbuf,
+                     (double2_t*)wbuf, npoints / 64, read_bytes_per_point * 4, write_bytes_per_point * 4,
+                     (unsigned long long*)stamps);
+  return (int)hipGetLastError();
+}
