@@ -14,20 +14,18 @@ converged state of the previous increment -- the cadence of QuadratureMap.update
 solve (reference solvers.py:72, quadrature_map.py:297-334).  Inputs and outputs are device
 resident in the AoS layout of the dolfinx quadrature Functions.
 
-Setup (untimed, before the W warm-up steps): the three load-step contexts are built by integrating the
-earlier increments, and every handle runs ``tune_placement`` once with the real arrays (the library's
-recommended budget: 4 candidate allocations, at most 2 GiB of skip blocks) -- the kernel has a fast and a
-slow mode in where the resident state sits relative to them (DESIGN.md section 3);
-``config.placement_tuning`` reports what that did, ``roofline.untuned`` carries the figure of the same
-launches before it, ``--no-tune`` skips it, ``--tune-candidates 24 --tune-skip-gib 16`` is round 1's deep search; a handle
-that is still in the slow mode after the small search (below ``--tune-extend-below`` = 0.72 of the HBM peak: on some boxes
-every nearby allocation is slow) gets that deep search once, and the record says so.  Then the caller's own side of it: the
-bench allocates its tangent array up to ``--tangent-candidates`` (8) times -- the kernel has two levels 3 % apart in where
-THAT array sits -- keeps the fastest and reports the first allocation's figure as ``roofline.first_tangent_allocation``.
+Setup (untimed): the three load-step contexts are built by integrating the earlier increments; every array stays where its
+FIRST allocation put it -- no placement search before the timed region.  Then ~0.5 s of back-to-back launches (the box leaves
+its idle state), the W warm-up steps, and the K timed steps with a side thread sampling the GPU's sysfs telemetry (sclk, mclk,
+fclk, power, busy) every 5 ms.  `value`, `roofline.frac` and `roofline.kernel_ms` are of THAT configuration.  Afterwards, as
+context: the same kernel interleaved with two arithmetic-free streaming probes of its traffic mix on the same box
+(`roofline.frac_of_stream_probe`), and what a caller gets who searches placements (`roofline.after_placement_search`:
+dxm_tune_placement with its small budget + up to `--tangent-candidates` allocations of the tangent array; `--no-tune` skips it).
 
 The JSON line also carries
   roofline      achieved algorithmic HBM GB/s of the constitutive kernel (496 B/point x points
                 per launch / mean launch duration from HIP events on the launch stream);
+  box           what the box looked like from its own side before, during and after the timed steps (tools/box_telemetry.py);
   cpu_baseline  the plain-C oracle ("port") timed on this box's host cores on a bounded sample;
   gather_inclusive  (N > 1) the same steps followed by an RCCL all-gather of stress and tangent;
   other_laws    (N = 1) kernel rates of the elastic, J2-Voce and FeFp laws at the same batch size.
@@ -502,10 +500,10 @@ def devices_child(G, n, seed, reps=7):
                     "GPU's DMA delivering into its rows of the one bound host array; no collective (new strain array every call)"}
 
 
-def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, tune=True, blocks_per_cu=0):
-    """Kernel rates of the other laws of the path at the same batch size (device-resident,
-    HIP events), for context next to the headline: elastic, J2 Voce (cfg 3 parameters), FeFp J2
-    (cfg 4 parameters, F = I + t (eps diag(1,-1/2,-1/2) + 0.2 eps G) as in SURVEY.md 8(d))."""
+def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, blocks_per_cu=0):
+    """Kernel rates of the other laws of the path at the same batch size (device-resident, HIP events, every array where
+    its first allocation put it), for context next to the headline: elastic, J2 Voce (cfg 3 parameters), FeFp J2 (cfg 4
+    parameters, F = I + t (eps diag(1,-1/2,-1/2) + 0.2 eps G) as in SURVEY.md 8(d))."""
     out = {}
     st = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator(device=dev).manual_seed(4321)
@@ -539,78 +537,84 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, tune=True, blocks_per_cu
         ng, nf = m._info.n_grad, m._info.n_flux
         g0, g1 = make_inputs()
         ab = m.algorithmic_bytes_per_point
-        # three fresh (flux, tangent) allocation pairs, the earlier ones kept alive so that the allocator hands out new
-        # memory: the kernel time depends on where the caller's arrays landed (the elastic law, which
-        # has no state to re-place, by up to 17 %), and one allocation per run hid that spread
-        pairs, per_pair, deep, stats = [], [], None, None
-        for trial in range(3):
-            flux = torch.empty((n, nf), dtype=torch.float64, device=dev)
-            ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)
-            pairs.append((flux, ct))
-            if trial == 0:
-                m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
-                m.data_manager.update()
-            if tune and m._info.n_isv_total > 0:
-                try:
-                    info = m.tune_placement(g1.data_ptr(), flux.data_ptr(), ct.data_ptr())
-                    # same fall-back as for the headline handles: one deep search when the small one leaves the slow mode
-                    f0 = ab * n / (info["ms_after"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                    if trial == 0 and f0 < (0.66 if name.startswith("fefp") else 0.72):
-                        m.set_option("tune_max_skip_bytes", 16 * 2**30)
-                        d2 = m.tune_placement(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=24)
-                        deep = {"because_frac": round(f0, 4), "ms_after": round(d2["ms_after"], 4), "candidates_tried": d2["candidates_tried"]}
-                        m.set_option("tune_max_skip_bytes", 2 * 2**30)
-                except Exception:
-                    pass
-            def median_ms(flux_, ct_):
-                # a newly allocated array needs 10-20 launches to reach its steady time (the FeFp kernel: 1.70 -> 1.63 ms over
-                # the first fifteen, profiles/r03_fefp_v2_kernel_stats.csv): ten untimed launches, then the median of `reps`
-                for _ in range(10):
-                    m.integrate_device(g1.data_ptr(), flux_.data_ptr(), ct_.data_ptr(), st)
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-                for a, b in ev:
-                    a.record()
-                    m.integrate_device(g1.data_ptr(), flux_.data_ptr(), ct_.data_ptr(), st)
-                    b.record()
-                torch.cuda.synchronize()
-                return float(np.median([a.elapsed_time(b) for a, b in ev]))
-
-            per_pair.append(median_ms(flux, ct))
-            rc, stats = m.stats()
-        ms = float(np.median(per_pair))
-        frac = lambda t: round(ab * n / t / 1e6 / HBM_PEAK_GBS, 4)   # noqa: E731
+        flux = torch.empty((n, nf), dtype=torch.float64, device=dev)
+        ct = torch.empty((n, nf * ng), dtype=torch.float64, device=dev)
+        m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+        m.data_manager.update()
+        # a newly allocated array needs 10-20 launches to reach its steady time (the FeFp kernel: 1.70 -> 1.63 ms over the first
+        # fifteen, profiles/r03_fefp_v2_kernel_stats.csv): twenty untimed launches, then the median of `reps`
+        for _ in range(20):
+            m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
+            b.record()
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in ev]
+        ms = float(np.median(ts))
+        rc, stats = m.stats()
         out[name] = {
             "Mpoints_per_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 4), "algorithmic_bytes_per_point": ab,
-            "GBs": round(ab * n / ms / 1e6, 1), "frac": frac(ms),
-            "kernel_ms_min_median_max": [round(min(per_pair), 4), round(ms, 4), round(max(per_pair), 4)],
-            "frac_max_median_min": [frac(min(per_pair)), frac(ms), frac(max(per_pair))],
-            "allocation_pairs": len(per_pair),
-            "plastic_fraction": round(stats["n_plastic"] / n, 4), "not_converged": stats["n_not_converged"],
+            "GBs": round(ab * n / ms / 1e6, 1), "frac": round(ab * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+            "kernel_ms_min_max": [round(min(ts), 4), round(max(ts), 4)], "launches": reps,
+            "plastic_fraction": round(stats["n_plastic"] / n, 4), "not_converged": stats["n_not_converged"], "n_nan": stats["n_nan"],
         }
-        if deep:
-            out[name]["deep_placement_search"] = deep
-        # ... and what a caller gets who allocates its tangent array a few times and keeps the fastest
-        # (HIPMaterial.fastest_tangent_array: up to eight allocations, stops when a contrast has been seen and two in a row did not improve)
-        if tune:
-            try:
-                ct_best, t_search, k_best = m.fastest_tangent_array(lambda: torch.empty((n, nf * ng), dtype=torch.float64, device=dev),
-                                                                    g1.data_ptr(), flux.data_ptr(), candidates=8, launches=12)
-                t_best = median_ms(flux, ct_best)
-                out[name]["tangent_array_search"] = {"best_launch_per_allocation_ms": [round(t, 4) for t in t_search], "kept": k_best,
-                                                     "kernel_ms": round(t_best, 4), "frac": frac(t_best),
-                                                     "note": "median launch time, as above, with the tangent array the search kept"}
-                del ct_best
-            except Exception as exc:  # context only
-                out[name]["tangent_array_search"] = {"error": repr(exc)}
-            torch.cuda.empty_cache()
         if name.startswith("fefp"):
             # SURVEY 8(d) counts an F_n read (976 B/point) that this kernel does not need: its state is the material
             # tensor Cp^-1, so 952 B/point actually cross the HBM interface
             out[name].update(bytes_moved_per_point=952, GBs_moved=round(952 * n / ms / 1e6, 1),
                              frac_moved=round(952 * n / ms / 1e6 / HBM_PEAK_GBS, 4))
         m.close()
-        del g0, g1, flux, ct, pairs
+        del g0, g1, flux, ct
         torch.cuda.empty_cache()
+    return out
+
+
+def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30):
+    """The headline kernel interleaved, launch by launch, with two arithmetic-free kernels of tools/libstreammix.so that move
+    its 496 B/point: `linear` = two perfectly linear 16 B-per-lane streams (104 B read, 392 B written with non-temporal
+    stores), `j2_shape` = the kernel's own stream structure (strain AoS + 7 SoA slots in; stress AoS + 7 SoA slots + tangent
+    out), reading the bench's strain array and writing its flux / tangent arrays.  Medians over `reps` rounds after 5 untimed
+    ones.  Measurement infrastructure (never on the product path); what the box gives a streaming kernel of this mix NOW."""
+    import ctypes as C
+
+    lib = C.CDLL(os.path.join(ROOT, "tools", "libstreammix.so"))
+    lib.stream_mix_nt_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.stream_mix_j2_shape_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    n64 = n // 64 * 64
+    rb, wb, nblk = 104, 392, 2048
+    rbuf = torch.randn(n64 * rb // 8, dtype=torch.float64, device=dev)
+    wbuf = torch.empty(n64 * wb // 8, dtype=torch.float64, device=dev)
+    ld = n64 + 32
+    sa = torch.randn(7 * ld, dtype=torch.float64, device=dev)
+    sb = torch.empty(7 * ld, dtype=torch.float64, device=dev)
+    legs = {
+        "kernel": kernel_launch,
+        "linear": lambda: lib.stream_mix_nt_launch(rbuf.data_ptr(), wbuf.data_ptr(), n64, rb, wb, nblk, stream or None),
+        "j2_shape": lambda: lib.stream_mix_j2_shape_launch(eps.data_ptr(), sa.data_ptr(), sb.data_ptr(), ld, flux.data_ptr(), ct.data_ptr(), n64, nblk, stream or None),
+    }
+    times = {k: [] for k in legs}
+    for r in range(reps + 5):
+        for k, fn in legs.items():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            if r >= 5:
+                times[k].append(a.elapsed_time(b))
+    kernel_launch()   # flux / tangent hold the kernel's results again
+    torch.cuda.synchronize()
+    med = {k: float(np.median(v)) for k, v in times.items()}
+    out = {"kernel_ms": round(med["kernel"], 4), "linear_probe_ms": round(med["linear"], 4), "j2_shape_probe_ms": round(med["j2_shape"], 4),
+           "linear_probe_GBs": round(496 * n64 / med["linear"] / 1e6, 1), "j2_shape_probe_GBs": round(496 * n64 / med["j2_shape"] / 1e6, 1),
+           "kernel_over_linear_probe": round(med["linear"] / med["kernel"], 4), "kernel_over_j2_shape_probe": round(med["j2_shape"] / med["kernel"], 4),
+           "rounds": reps,
+           "note": "tools/stream_mix.hip: no arithmetic, the kernel's bytes; interleaved with the kernel in one process (each launch waited for), so all three "
+                   "see the same box at the same time; > 1 means the kernel is faster than the probe"}
+    del rbuf, wbuf, sa, sb
+    torch.cuda.empty_cache()
     return out
 
 
@@ -789,16 +793,14 @@ def main():
                          "(the device-tensor collectives of the N > 1 path on a 1-GPU box; never for reported numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true",
-                    help="skip dxm_tune_placement (setup step, outside the timed region): keep the state where hipMalloc first put it")
-    ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle")
+                    help="skip the context leg `roofline.after_placement_search` (the timed region never uses a placement search)")
+    ap.add_argument("--settle-seconds", type=float, default=0.5, help="back-to-back launches before the warm-up steps (the box leaves its idle state)")
+    ap.add_argument("--no-telemetry", action="store_true", help="skip the box block (sysfs / rocm-smi reads around and during the timed steps)")
+    ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle (context leg after the timed region)")
     ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="option blocks_per_cu for every handle of the run (0: the library's default per law)")
-    ap.add_argument("--tangent-candidates", type=int, default=8,
-                    help="allocations of the caller's tangent array the bench may try (the kernel has two levels ~3 %% apart in where that array "
-                         "sits); stops once a contrast has been seen and two in a row did not improve; 1 = keep the first")
-    ap.add_argument("--tune-extend-below", type=float, default=0.72,
-                    help="a handle whose kernel is still below this fraction of the HBM peak after the small search gets one "
-                         "deep search (24 candidates, skip blocks up to 16 GiB); 0 disables")
+    ap.add_argument("--tangent-candidates", type=int, default=4,
+                    help="allocations of the caller's tangent array the context leg `roofline.after_placement_search` tries; 1 = keep the first")
     ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -822,6 +824,16 @@ def main():
         args.share_gpu = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    # the box, from its own side, before this process touches the GPU (rank 0; pure sysfs + rocm-smi child processes)
+    telemetry, box_before = None, None
+    if not args.no_telemetry and int(os.environ.get("RANK", "0")) == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import box_telemetry as telemetry
+
+            box_before = telemetry.condensed(telemetry.snapshot(tools=False))
+        except Exception as exc:   # context only
+            telemetry, box_before = None, {"error": repr(exc)}
     # roofline.traffic: measured now, before this process initialises the GPU (rank 0 of a 1-GPU run only)
     traffic, traffic_detail = None, None
     if args.gpus == 1 and not args.no_live_traffic and "WORLD_SIZE" not in os.environ:
@@ -862,7 +874,7 @@ def main():
 
     c = argparse.Namespace(torch=torch, dist=dist, jm=jm, JAXMaterial=JAXMaterial, ShardPlan=ShardPlan, allgather_rows=allgather_rows,
                            allgather_rows_p2p=allgather_rows_p2p, allgather_tangent=allgather_tangent, rank=rank, world=world, dev=dev,
-                           dev_index=dev_index, share=share, grouped=grouped, args=args)
+                           dev_index=dev_index, share=share, grouped=grouped, args=args, telemetry=telemetry)
     n = args.points
     K, W = args.steps, args.warmup
     seed = 1234 + rank
@@ -883,16 +895,8 @@ def main():
         dist.destroy_process_group()
 
     if rank == 0:
-        elapsed, kern_ms, untuned_ms, copy_gbs = head["elapsed"], head["kernel_ms"], head["untuned_ms"], head["copy_gbs"]
-        ta = head.get("tangent_array")
-        first_tangent = None
-        if ta and "first_ms" in ta:
-            first_tangent = {"kernel_ms": round(ta["first_ms"], 4), "frac": round(ALG_BYTES * n / (ta["first_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "allocations_ms": ta["allocations_ms"], "kept": ta["kept"],
-                             "note": "state placed by dxm_tune_placement, tangent array where the caller's first allocation put it; the caller then "
-                                     "tried further allocations of that array (two levels ~3 % apart) and kept the fastest"}
-        elif ta:
-            first_tangent = ta
+        elapsed, kern_ms, copy_gbs = head["elapsed"], head["kernel_ms"], head["copy_gbs"]
+        probe = head.get("stream_probe")
         sig0 = SIG0 if args.law == "j2_linear" else 350.0
         value = n * world * K / elapsed / 1e6
         achieved = ALG_BYTES * n / (kern_ms * 1e-3) / 1e9
@@ -928,7 +932,8 @@ def main():
                 "plastic_fraction_inc2_3_4": head["plastic_fraction"],
                 "layout": "AoS (N,6)/(N,36) boundary arrays in HBM, SoA resident state",
                 "sharding": "independent contiguous point blocks, no data-path collective",
-                "placement_tuning": head["tuning"] if head["tuning"] else None,
+                "placement": "every array where its first allocation put it (no placement search before or inside the timed region)",
+                "settle_launches_before_warmup": head["settle_launches"],
             },
             "roofline": {
                 "bound": "hbm",
@@ -942,14 +947,26 @@ def main():
                 "source_hash": source_hash(),
                 "kernel": head["kernel"],
                 "kernel_ms": round(kern_ms, 4),
-                "untuned": {"kernel_ms": round(untuned_ms, 4), "frac": round(ALG_BYTES * n / (untuned_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                            "note": "same launches before dxm_tune_placement (state where hipMalloc first put it)"},
-                "first_tangent_allocation": first_tangent,
+                "frac_of_stream_probe": (probe or {}).get("kernel_over_j2_shape_probe"),
+                "stream_probe": probe,
+                "after_placement_search": head.get("searched"),
                 "algorithmic_bytes_per_point": ALG_BYTES,
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                 "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
             },
         }
+        if telemetry is not None or box_before is not None:
+            box_after = None
+            try:
+                box_after = {k: v for k, v in telemetry.condensed(telemetry.snapshot(tools=False)).items()
+                             if k in ("sclk", "mclk", "fclk", "power_w", "temp_c", "hbm_temp_c", "gpu_busy", "mem_busy", "vram_used", "vram_other_processes_on_my_gpu")} if telemetry else None
+            except Exception as exc:
+                box_after = {"error": repr(exc)}
+            out["box"] = {"before": box_before, "during_timed_steps": head.get("box_during"), "after": box_after,
+                          "note": "tools/box_telemetry.py: sysfs of the leased GPU (the card whose render node this process can open) + the firmware's "
+                                  "gpu_metrics through rocm-smi; read by this process and its children, never under a profiler.  What eight leases of six "
+                                  "different GPUs showed (profiles/r04_box_survey.jsonl): clocks, power cap, partition mode, temperatures, throttle "
+                                  "residencies and VRAM co-tenancy are the same on boxes that run this kernel at 0.67 and at 0.79 of peak"}
         if group_info is not None:
             out["process_group"] = group_info
         if head["gather"] is not None:
@@ -962,7 +979,7 @@ def main():
                     "value": round(n3_ * world * k3 / e3 / 1e6, 3), "unit": "Mpoints/s", "steps": k3, "ms_per_step": round(e3 / k3 * 1e3, 4),
                     "kernel": cfg3["kernel"], "kernel_ms": round(cfg3["kernel_ms"], 4),
                     "frac": round(ALG_BYTES * n3_ / (cfg3["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "plastic_fraction_inc2_3_4": cfg3["plastic_fraction"], "placement_tuning": cfg3["tuning"] or None,
+                    "plastic_fraction_inc2_3_4": cfg3["plastic_fraction"], "after_placement_search": cfg3.get("searched"),
                     "gather_inclusive": cfg3["gather"],
                     "note": "SURVEY.md 8(d) cfg 3: compute-only (`value`, no data-path collective) and, in `gather_inclusive`, stress + tangent reassembled "
                             "on every rank by the RCCL all-gather, by the point-to-point schedule and as coefficients rebuilt locally",
@@ -971,7 +988,7 @@ def main():
         if world == 1 and not args.no_other_laws:
             try:
                 torch.cuda.empty_cache()
-                out["other_laws"] = other_laws(torch, jm, JAXMaterial, dev, n, tune=not args.no_tune, blocks_per_cu=args.blocks_per_cu)
+                out["other_laws"] = other_laws(torch, jm, JAXMaterial, dev, n, blocks_per_cu=args.blocks_per_cu)
             except Exception as exc:  # context only: never lose the headline line
                 out["other_laws"] = {"error": repr(exc)}
         if world == 1 and not args.no_host_path and args.law == "j2_linear":
@@ -1024,10 +1041,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
             m.data_manager.update()
         mats.append(m)
 
-    # setup, outside the timed region: where the resident state sits relative to the boundary arrays
-    # decides between a fast and a slow mode of the kernel (+14 %); let every
-    # handle measure a few allocations with the real buffers and keep the fastest
-    def events_ms(nsteps):
+    def events_ms(nsteps, reduce=np.mean):
         ev_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
         for i, (a_, b_) in enumerate(ev_):
             a_.record()
@@ -1035,63 +1049,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
             mats[j_].integrate_device(eps[j_ + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), stream)
             b_.record()
         torch.cuda.synchronize()
-        return float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev_]))
-
-    # the same launches with the state where hipMalloc first put it (reported next to the tuned figure)
-    events_ms(3)
-    untuned_ms = events_ms(12)
-    tuning = []
-    if not args.no_tune:
-        for j, m in enumerate(mats):
-            try:
-                m.set_option("tune_max_skip_bytes", args.tune_skip_gib * 2**30)
-                info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
-                rec = {"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4),
-                       "candidates_tried": info["candidates_tried"]}
-                # still in the slow mode after the small search (some boxes put every nearby allocation there, DESIGN.md
-                # section 3): one deep search for this handle -- more candidates, skip blocks of up to 16 GiB
-                frac = ALG_BYTES * n / (info["ms_after"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                if frac < args.tune_extend_below and args.tune_candidates < 24 and not share:
-                    m.set_option("tune_max_skip_bytes", 16 * 2**30)
-                    deep = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=24)
-                    rec["deep_search"] = {"because_frac": round(frac, 4), "ms_after": round(deep["ms_after"], 4),
-                                          "candidates_tried": deep["candidates_tried"]}
-                tuning.append(rec)
-            except Exception as exc:  # an optimisation of the setup: never lose the run over it
-                tuning.append({"error": repr(exc)})
-
-    # The caller's side of the same effect: with the state placed, WHERE THE TANGENT ARRAY SITS (58 % of the kernel's bytes) still
-    # decides between two levels 3 % apart (0.814 / 0.792 ms per 1e7 points over six allocations in one process,
-    # profiles/r03_tangent_array_allocations.jsonl).  The caller owns that array, so the caller tries: up to
-    # --tangent-candidates allocations, the fastest kept, then the state search once more against it.  Setup, outside the
-    # timed region; `roofline.first_tangent_allocation` carries the figure without it.
-    tangent_array = None
-    if not args.no_tune and args.tangent_candidates > 1:
-        try:
-            events_ms(3)
-            first_ms = events_ms(12)
-            cands, times, stale = [ct], [first_ms], 0
-            for _ in range(args.tangent_candidates - 1):
-                # (the rule of HIPMaterial.fastest_tangent_array) a contrast has been seen and two candidates in a row
-                # have not improved the best by 0.5 %: the fast level is in hand
-                if stale >= 2 and min(times) <= 0.985 * max(times):
-                    break
-                ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
-                cands.append(ct)
-                events_ms(15)   # a newly allocated array needs 10-20 launches to reach its steady time
-                t_ = events_ms(12)
-                stale = 0 if t_ < 0.995 * min(times) else stale + 1
-                times.append(t_)
-            kept = int(np.argmin(times))
-            ct = cands[kept]
-            del cands
-            torch.cuda.empty_cache()
-            if kept != 0:   # the three states were placed against the first allocation: once more against the one kept
-                for j, m in enumerate(mats):
-                    m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
-            tangent_array = {"allocations_ms": [round(t, 4) for t in times], "kept": kept, "first_ms": first_ms}
-        except Exception as exc:  # an optimisation of the setup: never lose the run over it
-            tangent_array = {"error": repr(exc)}
+        return float(reduce([a_.elapsed_time(b_) for a_, b_ in ev_]))
 
     def step(i):
         j = i % 3
@@ -1103,6 +1061,16 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the box leaves its idle state: back-to-back launches for --settle-seconds, no host work in between (telemetry of the boxes
+    # in profiles/r04_box_survey.jsonl: clocks do not move under this load and no launch but the very first after an idle gap
+    # is slow -- the settling costs nothing and takes the question off the table)
+    t_settle = time.perf_counter()
+    n_settle = 0
+    while time.perf_counter() - t_settle < args.settle_seconds:
+        for i in range(20):
+            step(n_settle + i)
+        n_settle += 20
+        torch.cuda.synchronize()
     for i in range(W):
         step(i)
     for j in range(3):
@@ -1111,8 +1079,17 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         assert rc == 0 and st["n_nan"] == 0
         plastic_frac.append(st["n_plastic"] / n)
 
+    # ---- the timed region: EXACTLY K steps between barrier + synchronize, every array where its first allocation put it -------
+    sampler = box_before = fw_before = None
+    tel = c.telemetry if rank == 0 else None
+    if tel is not None:
+        fw_before = tel.metrics()
+        box_before = tel.fast_read(tel.my_card()) if tel.my_card() else None
+        sampler = tel.Sampler(period_s=0.005)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     barrier()
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for i in range(K):
         ev[i][0].record()
@@ -1120,8 +1097,61 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         ev[i][1].record()
     barrier()
     t1 = time.perf_counter()
+    if sampler is not None:
+        sampler.stop()
     elapsed = t1 - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    per_launch = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = float(np.mean(per_launch))
+    box_during = None
+    if sampler is not None:
+        fw_after = tel.metrics()
+        box_during = {"sysfs_samples": sampler.summary(), "firmware_counters": tel.metrics_delta(fw_before, fw_after), "clocks_at_start": box_before,
+                      "kernel_ms_min_median_max": [round(float(np.min(per_launch)), 4), round(float(np.median(per_launch)), 4), round(float(np.max(per_launch)), 4)],
+                      "note": "sysfs_samples: min / median / max of a 5 ms sampler thread across the K timed steps (20 steps are ~20 ms: a handful of samples); "
+                              "firmware_counters: gpu_metrics accumulators read just before and just after (they bracket the region plus ~0.6 s of tool time)"}
+
+    # ---- context, after the timed region -----------------------------------------------------------------------------------
+    # (1) the same kernel against two arithmetic-free streaming kernels that move its bytes, interleaved launch by launch on this
+    # box now: a linear 104 B-in / 392 B-out pair of streams with non-temporal stores, and the kernel's own 17-stream shape
+    stream_probe = None
+    if rank == 0 and copy_probe and not share:
+        try:
+            stream_probe = stream_probes(torch, dev, n, stream, lambda: step(1), eps[2], flux, ct)
+        except Exception as exc:   # context only
+            stream_probe = {"error": repr(exc)}
+
+    # (2) what a caller gets who searches: dxm_tune_placement per handle (small budget) and a few allocations of the tangent array
+    searched = None
+    if not args.no_tune and not share:
+        try:
+            events_ms(3)
+            before_ms = events_ms(12)
+            tuning = []
+            for j, m in enumerate(mats):
+                m.set_option("tune_max_skip_bytes", args.tune_skip_gib * 2**30)
+                info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
+                tuning.append({"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4), "candidates_tried": info["candidates_tried"]})
+            events_ms(3)
+            times, cands = [events_ms(12)], [ct]
+            for _ in range(max(0, args.tangent_candidates - 1)):
+                ct = torch.empty((n, 36), dtype=torch.float64, device=dev)   # (events_ms / step read `ct` of this scope)
+                cands.append(ct)
+                events_ms(15)   # a newly allocated array needs 10-20 launches to reach its steady time
+                times.append(events_ms(12))
+            kept = int(np.argmin(times))
+            ct = cands[kept]
+            del cands
+            torch.cuda.empty_cache()
+            events_ms(5)
+            after_ms = events_ms(20)
+            searched = {"kernel_ms": round(after_ms, 4), "frac": round(ALG_BYTES * n / (after_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "kernel_ms_before_the_search": round(before_ms, 4), "state_placement": tuning,
+                        "tangent_allocations_ms": [round(t, 4) for t in times], "tangent_allocation_kept": kept,
+                        "note": "context, never `value`: dxm_tune_placement (dxmat_experimental.h; 4 state allocations, <= 2 GiB of skip blocks) per handle, then "
+                                "the fastest of a few allocations of the caller's tangent array; the kernel time has two levels in where these "
+                                "arrays sit physically (profiles/NOTES.md, placement)"}
+        except Exception as exc:   # context only
+            searched = {"error": repr(exc)}
 
     # device-copy bandwidth of THIS box (read + write bytes of a 1 GiB fp64 copy): the practical
     # ceiling a streaming kernel sees here.  The rate depends on which physical regions the two
@@ -1261,7 +1291,8 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         m.close()
     del eps, flux, ct
     torch.cuda.empty_cache()
-    return {"elapsed": elapsed, "kernel_ms": kern_ms, "untuned_ms": untuned_ms, "tuning": tuning, "tangent_array": tangent_array, "plastic_fraction": [round(x, 4) for x in plastic_frac],
+    return {"elapsed": elapsed, "kernel_ms": kern_ms, "searched": searched, "stream_probe": stream_probe, "box_during": box_during, "settle_launches": n_settle,
+            "plastic_fraction": [round(x, 4) for x in plastic_frac],
             "copy_gbs": copy_gbs, "gather": gather_out, "group_info": group_info, "kernel": kernel, "steps": K, "points": n}
 
 

@@ -93,10 +93,6 @@ SYMBOLS = {
     "dxm_isv_device": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_void_p]),
     "dxm_state_ptr": (C.c_void_p, [_h, C.c_int, C.c_int, C.c_int]),
     "dxm_integrate_displacement_device": (C.c_int, [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "dxm_tune_placement": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double),
-                                     C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "dxm_time_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
-    "dxm_place_state": (C.c_int, [_h, C.c_int, C.c_uint64, C.c_uint64]),
     "dxm_expand_tangent_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "dxm_expand_tangent_pack4_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "dxm_kernel_name": (C.c_char_p, [_h]),
@@ -107,6 +103,7 @@ SYMBOLS = {
     "dxm_host_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "dxm_host_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     "dxm_host_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "dxm_host_index_range": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dxm_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dxm_host_unregister": (C.c_int, [C.c_void_p]),
     "dxm_host_alloc": (C.c_void_p, [C.c_uint64]),
@@ -121,10 +118,6 @@ SYMBOLS = {
     "dxm_mesh_npoints": (C.c_int64, [_h]),
     "dxm_mesh_displacement_size": (C.c_int64, [_h]),
     "dxm_mesh_gradient_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "dxm_mesh_set_weights": (C.c_int, [_h, C.c_void_p]),
-    "dxm_mesh_internal_force_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "dxm_mesh_tangent_apply_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "dxm_mesh_tangent_diagonal_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dxm_integrate_displacement": (
         C.c_int,
         [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],
@@ -133,6 +126,18 @@ SYMBOLS = {
         C.c_int,
         [_h, _h, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)],
     ),
+}
+
+#: every symbol include/dxmat_experimental.h declares (measurement helpers, assembly-side research kernels)
+EXPERIMENTAL_SYMBOLS = {
+    "dxm_tune_placement": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "dxm_time_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "dxm_place_state": (C.c_int, [_h, C.c_int, C.c_uint64, C.c_uint64]),
+    "dxm_mesh_set_weights": (C.c_int, [_h, C.c_void_p]),
+    "dxm_mesh_internal_force_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dxm_mesh_tangent_apply_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dxm_mesh_tangent_diagonal_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -183,7 +188,7 @@ def load() -> C.CDLL:
 
 
 def _bind(lib: C.CDLL, strict: bool = True) -> C.CDLL:
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in {**SYMBOLS, **EXPERIMENTAL_SYMBOLS}.items():
         try:
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         except AttributeError:
@@ -258,7 +263,7 @@ def load_custom(expr_R: str, expr_dR: str) -> C.CDLL:
     if key in _custom_libs:
         return _custom_libs[key]
     srcs = [os.path.join(CSRC_DIR, f) for f in sorted(os.listdir(CSRC_DIR)) if f.endswith((".hip", ".hpp"))]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "dxmat.h"))
+    srcs += [os.path.join(os.path.dirname(_HERE), "include", h) for h in ("dxmat.h", "dxmat_experimental.h")]
     h = hashlib.sha1()
     h.update(expr_R.encode() + b"\0" + expr_dR.encode())
     for f in srcs:

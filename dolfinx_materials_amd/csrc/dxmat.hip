@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/dxmat.h"
+#include "../../include/dxmat_experimental.h"
 #include "dxm_common.hpp"
 #include "fefp.hpp"
 #include "gradient.hpp"
@@ -729,8 +730,10 @@ int dxm_advance(dxm_material* m) {
     if (m->opt_keep_initial_io && m->io1_valid) {
       if (m->io1_valid & 1) { double* g = m->d_grad0; m->d_grad0 = m->d_grad; m->d_grad = g; }
       if (m->io1_valid & 2) { double* f = m->d_flux0; m->d_flux0 = m->d_flux; m->d_flux = f; }
-      m->io0_valid |= m->io1_valid;
     }
+    // the copies held for the state that has just been replaced belong to nobody now: s0 holds what the accepted state
+    // brought along and nothing else (a state accepted from a device-pointer call brings nothing)
+    m->io0_valid = m->opt_keep_initial_io ? m->io1_valid : 0;
     m->io1_valid = 0;
   }
   return 0;
@@ -1989,6 +1992,13 @@ int dxm_host_scatter_rows(double* dst, const double* src, const int64_t* rows, i
 
 int dxm_host_gather_rows(double* dst, const double* src, const int64_t* rows, int64_t n, int width, int threads) {
   return move_rows(false, dst, src, rows, n, width, threads);
+}
+
+int dxm_host_index_range(const int64_t* rows, int64_t n, int threads, int64_t* lo, int64_t* hi) {
+  if (!lo || !hi) return fail(-1, "null result pointer");
+  if (n > 0 && !rows) return fail(-1, "null index");
+  dxm_host::index_min_max(rows, n, threads, lo, hi);
+  return 0;
 }
 
 int dxm_host_register(void* p, uint64_t bytes) {

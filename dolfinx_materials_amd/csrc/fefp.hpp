@@ -392,11 +392,12 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         for (int Jx = 0; Jx < 3; ++Jx)
           P[i * 3 + Jx] = tau[DXM_SYM(i, 0)] * Fi[Jx * 3] + tau[DXM_SYM(i, 1)] * Fi[Jx * 3 + 1] + tau[DXM_SYM(i, 2)] * Fi[Jx * 3 + 2];
     }
+    bool nonfinite;   // one bit per lane (an SGPR pair): settled after the tangent's building blocks exist (step 6)
     {
       double chk = p_new;
 #pragma unroll
       for (int k = 0; k < 9; ++k) chk += P[k];
-      if (valid && !(fabs(chk) <= 1.79769313486231570e308)) ++c_nan;
+      nonfinite = !(fabs(chk) <= 1.79769313486231570e308);
     }
     // new isochoric Cp^-1 = J^(2/3) F^-1 be F^-T with be F^-T = P / mu + (Ie - pr / mu) F^-T
     double gn[6];
@@ -475,6 +476,12 @@ fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin
         // Sd[i][J] = d[i][m] Fi[J][m]   (i = k, J = L here)
         Sd[k * 3 + L] = d[DXM_SYM(k, 0)] * Fi[L * 3] + d[DXM_SYM(k, 1)] * Fi[L * 3 + 1] + d[DXM_SYM(k, 2)] * Fi[L * 3 + 2];
       }
+    {
+      // the tangent counts too (quadrature_map.py:324): W carries everything that depends on the hardening SLOPE (M, eq), which
+      // the stress never sees -- a slope that is not finite at the returned state leaves PK1 finite and the tangent not
+      const double wsum = ((W[0] + W[1]) + (W[2] + W[3])) + ((W[4] + W[5]) + (W[6] + W[7])) + W[8];
+      if (valid && (nonfinite || !(fabs(wsum) <= 1.79769313486231570e308))) ++c_nan;
+    }
 
     if constexpr (TLF == 1) {
       // building blocks only: every lane leaves its own record (rare path: the transfer behind it is 50x the kernel)

@@ -268,6 +268,10 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
         {
           const double rho = 1.0 - 3.0 * mu * beta;
           wn = rho > 0.0 ? 1.5 * iseq / rho : 0.0;   // (a division: with the 5-instruction reciprocal the fused tet4 Voce variant spills 2 registers)
+          // rho = R(p) / seq of the returned state: <= 0 only for a yield stress that is not positive there (a softening law
+          // driven to zero, an overshooting iterate).  The direction is then undefined (wn = 0 drops the n x n term): reported
+          // as a point that did not converge, never silently
+          if constexpr (LAW != LAW_J2_LINEAR) { if (valid && !(rho > 0.0)) ++c_notconv; }
         }
         const double gamma = 1.0 / (hardening_dR<LAW>(prm, p_n + dp) + 3.0 * mu);
         // Dt = lambda IxI + 2mu Id - 4mu^2 [beta (M - n^n) + gamma n^n]      mfront:66-69
@@ -296,7 +300,9 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
     s[4] = 2.0 * mu * e[4];
     s[5] = 2.0 * mu * e[5];
     {
-      const double chk = s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + p_new;
+      // stress, p and what the tangent is made of (quadrature_map.py:322-324 asserts on flux, state and Ct): a hardening
+      // slope that is not finite at the returned state leaves the stress finite and c3 not
+      const double chk = s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + p_new + ((c1 + c2) + (c3 + wn));
       if (valid && !(fabs(chk) <= 1.79769313486231570e308)) ++c_nan;
     }
 

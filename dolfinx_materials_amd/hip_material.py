@@ -332,8 +332,9 @@ class HIPMaterial:
         # for UFL-valued properties (quadrature_map.py:160-172); a uniform field is a number
         if not np.all(arr == arr[0]):
             raise NotImplementedError(
-                f"material property {key!r} varies from point to point: the fused kernels take uniform parameters "
-                "(split the domain into one QuadratureMap per material, tests/mfront/test_multimaterials.py:23-172)")
+                f"material property {key!r} varies from point to point: the fused kernels take uniform parameters. "
+                "Split the domain into one QuadratureMap per material (QuadratureMap(mesh, deg, material, cells=...), as the "
+                "reference's multi-material demo does) -- the reference's own JAX back-end ignores per-point values altogether")
         value = float(arr[0])
         setattr(obj, parts[-1], value)
         self.material_properties[key] = value
@@ -543,6 +544,8 @@ class HIPMaterial:
                 new.append(LazyInitialRows(self, cur.shape, kind))
             elif isinstance(cur, LazyInitialRows):
                 new.append(cur)
+            elif isinstance(cur, np.ndarray) and cur.size and cur.strides[0] == 0:   # the "unknown" placeholder of a device-pointer call
+                new.append(cur)
             elif key not in self._bound:
                 new.append(cur)
             elif held & (1 << kind):
@@ -699,11 +702,14 @@ class HIPMaterial:
             if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size % w == 0):
                 raise ValueError(f"{name} must be a C-contiguous float64 array of whole rows of {w}")
         total = min(flux.size // nf, tangent.size // (nf * ng))
-        key = (rows.ctypes.data, self._n, total)
-        if self.__dict__.get("_rows_checked") != key:   # once per index: the library does not range-check it
-            if self._n and (int(rows.min()) < 0 or int(rows.max()) >= total):
-                raise ValueError(f"rows must lie in [0, {total})")
-            self._rows_checked = key
+        # every call: dxm_integrate_rows does not range-check the index, and neither the address of the index array nor its
+        # length says that its CONTENT is still the one checked last time (~1 ms per 1e7 entries on the library's threads)
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.dxm_host_index_range(rows.ctypes.data, self._n, 8, C.byref(lo), C.byref(hi)))
+        if self._n and (lo.value < 0 or hi.value >= total):
+            raise ValueError(f"rows must lie in [0, {total})")
+        if not self.__dict__.get("_rows_checked"):
+            self._rows_checked = True
             self.set_option("keep_initial_io", 1)   # the contiguous flux exists on the device only: advance keeps it for s0
 
     def _after_rows(self, rc):
@@ -774,11 +780,15 @@ class HIPMaterial:
         return flux, (self._out_isv if eager else LazyISV(self, (self._n, self._info.n_isv_total))), self._out_ct
 
     def _host_mirrors_left_behind(self):
-        """The device-pointer forms produce a final state whose flux the host never sees: the mirrors of the state
-        dictionaries do not follow them (an array stays what the last host-buffer call left).  A lazy view of the device copy
-        of that call would fail instead -- the copy is invalidated by the launch -- so it becomes an all-NaN placeholder."""
-        if isinstance(self._flux[1], LazyFinalRows):
-            self._flux[1] = np.broadcast_to(np.nan, self._flux[1].shape)
+        """The device-pointer forms produce a final state whose gradient and flux the host never sees: the s1 mirrors of the
+        state dictionaries become all-NaN placeholders (no memory: a broadcast view) -- "unknown", loudly, instead of the
+        arrays of whatever host-buffer call came last.  ``advance`` carries them into s0 like any other mirror; the C side
+        holds no device copy for such a state either (``dxm_io_held`` is 0 after ``dxm_advance``)."""
+        if getattr(self, "_grad", None) is None:
+            return
+        self._grad[1] = np.broadcast_to(np.nan, (self._n, int(self._info.n_grad)))
+        self._flux[1] = np.broadcast_to(np.nan, (self._n, int(self._info.n_flux)))
+        self._serial += 1
 
     def integrate_device(self, grad_ptr, flux_ptr, ct_ptr, stream=0, dt=0.0):
         """Device-pointer form: asynchronous launch on ``stream`` (a ``hipStream_t`` value, e.g.

@@ -21,9 +21,15 @@ same job with what the engine offers:
   point index the constructor already built (``quadrature_map.py:231-233, :259-260``) -- nothing is rebuilt per call: the
   engine stores every point's stress and tangent block straight into its row of the Functions
   (``HIPMaterial.integrate_rows``); rows of other arrays are moved on several threads (``scatter_rows``);
-* NaNs are taken from the kernel's status record (``material.last_stats["n_nan"]``) instead of three host passes;
-* internal state variables cross PCIe when the increment is accepted (``advance``), not in every Newton iteration
-  (``refresh_internal_state_variables()`` / ``isv_every_update = True`` for callers that want them earlier);
+* NaNs are taken from the kernel's status record (``material.last_stats["n_nan"]``: stress, state AND tangent, like the
+  three asserts of ``quadrature_map.py:322-324``) instead of three host passes;
+* internal state variables cross PCIe when somebody looks at them: ``isv_every_update = "lazy"`` (default) refreshes the
+  Functions on the first access to ``qmap.internal_state_variables`` / ``qmap.variables`` / ``qmap.project_on`` after an
+  ``update()`` and at ``advance()``; ``True`` writes them in every ``update()`` exactly like the reference (``:332``); ``False``
+  only at ``advance()``.  The one thing the lazy mode cannot see is a Function object taken out of the dict EARLIER and read
+  directly between ``update()`` and ``advance()`` -- such callers set ``isv_every_update = True``;
+* the four phases carry the reference's timer names (``"dx_mat: ..."``, ``quadrature_map.py:302-331``), so ``list_timings`` keeps
+  its rows;
 * optionally the gradient is evaluated on the GPU from the displacement vector (``register_device_gradient``).
 
 With a material that offers none of this (any duck-typed ``Material``: the oracle-backed one of the tests, a
@@ -38,6 +44,14 @@ tested where dolfinx is absent.
 from __future__ import annotations
 
 import numpy as np
+
+try:  # the reference wraps the four phases of update() in dolfinx Timers (quadrature_map.py:302-331)
+    from dolfinx.common import Timer as _Timer
+except Exception:  # dolfinx is optional for the engine itself
+    import contextlib
+
+    def _Timer(name):
+        return contextlib.nullcontext()
 
 
 def rows_of(fun, dim):
@@ -58,6 +72,47 @@ def _same_memory(a, b):
     return a.size == b.size and a.ctypes.data == b.ctypes.data
 
 
+class _LazyFields(dict):
+    """``qmap.internal_state_variables``: name -> quadrature Function, refreshed from the device the first time anybody looks
+    after an ``update()`` (``isv_every_update = "lazy"``).  Every read access goes through :meth:`_sync`; ``{**d}`` /
+    ``dict(d)`` take the slow path (``keys`` + ``__getitem__``) because ``__iter__`` is overridden too."""
+
+    _owner = None
+
+    def _sync(self):
+        owner = self._owner
+        if owner is not None and owner.__dict__.get("_accel_isv_stale") and owner.isv_every_update == "lazy":
+            owner.refresh_internal_state_variables()
+
+    def __getitem__(self, key):
+        self._sync()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._sync()
+        return dict.get(self, key, default)
+
+    def __iter__(self):
+        self._sync()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._sync()
+        return dict.keys(self)
+
+    def values(self):
+        self._sync()
+        return dict.values(self)
+
+    def items(self):
+        self._sync()
+        return dict.items(self)
+
+    def raw(self):
+        """The Functions without a refresh (the mixin's own writes)."""
+        return dict(dict.items(self))
+
+
 class _Plan:
     """What is decided once per map (first ``update`` / ``advance``), not once per call."""
 
@@ -69,14 +124,15 @@ class _Plan:
     row_outputs = False       # subset maps: the material delivers flux and tangent into the Functions' rows itself
     state_buffers = None      # subset maps: persistent (page-locked) landing rows of the final state per field (advance)
     device_gradient = None    # (mesh, displacement callable)
+    bound_keys = ()           # what THIS map bound on the material (close() gives back exactly these)
 
 
 class AcceleratedUpdate:
     """Mixin: ``update / advance / initialize_state`` of ``QuadratureMap`` around a batched engine."""
 
-    #: write the internal state variables into their Functions in every ``update()`` like the reference
-    #: (``quadrature_map.py:332``) instead of at ``advance()`` only
-    isv_every_update = False
+    #: when the internal state variables reach their Functions: ``"lazy"`` on the first access after an ``update()`` (and at
+    #: ``advance()``), ``True`` in every ``update()`` like the reference (``quadrature_map.py:332``), ``False`` at ``advance()`` only
+    isv_every_update = "lazy"
 
     # ---- set-up, once ------------------------------------------------------------------------------------------
     def _accel_plan(self):
@@ -85,10 +141,15 @@ class AcceleratedUpdate:
             return plan
         plan = _Plan()
         m = self.material
+        isv = self.__dict__.get("internal_state_variables")
+        if isinstance(isv, dict) and not isinstance(isv, _LazyFields):   # same Functions, access-aware container
+            lazy = _LazyFields(isv)
+            lazy._owner = self
+            self.internal_state_variables = lazy
         dofs = np.asarray(self.dofs)
         plan.npoints = len(dofs)
         widths = {name: max(1, int(dim)) for name, dim in {**m.fluxes, **m.internal_state_variables}.items()}
-        total = {len(rows_of(f, widths[name])) for name, f in {**self.fluxes, **self.internal_state_variables}.items()}
+        total = {len(rows_of(f, widths[name])) for name, f in {**self.fluxes, **self._isv_functions()}.items()}
         total.add(len(self.jacobian_flatten.x.array) // self._jacobian_width())
         plan.identity = len(total) == 1 and total.pop() == plan.npoints and bool(np.array_equal(dofs, np.arange(plan.npoints)))
         if not plan.identity:
@@ -107,18 +168,27 @@ class AcceleratedUpdate:
             try:
                 m.bind_outputs(flux=flux_fun.x.array, tangent=self.jacobian_flatten.x.array)
                 plan.bound = True
+                plan.bound_keys += ("flux", "tangent")
             except Exception as exc:
                 _slow_path_warning("the flux / jacobian_flatten Functions", exc)
                 if hasattr(m, "_unbind"):
-                    m._unbind()
+                    for key in ("flux", "tangent"):
+                        m._unbind(key)
             pin_state = getattr(m, "bind_state_outputs", None)
-            if plan.bound and pin_state is not None and self.internal_state_variables:   # advance() downloads straight into these
+            fields = self._isv_functions()
+            if plan.bound and pin_state is not None and fields:   # advance() downloads straight into these
                 try:
-                    pin_state({name: f.x.array for name, f in self.internal_state_variables.items()})
+                    pin_state({name: f.x.array for name, f in fields.items()})
+                    plan.bound_keys += tuple("isv:" + name for name in fields)
                 except Exception as exc:
                     _slow_path_warning("the internal-state Functions", exc)
         self.__dict__["_accel"] = plan
         return plan
+
+    def _isv_functions(self):
+        """name -> Function of the internal state variables, without triggering a lazy refresh."""
+        d = self.internal_state_variables
+        return d.raw() if isinstance(d, _LazyFields) else d
 
     def _jacobian_width(self):
         return int(sum(int(np.prod(shape)) for shape in self.material.tangent_blocks.values())) or 1
@@ -142,7 +212,8 @@ class AcceleratedUpdate:
         are destroyed when the map and the material do not die together."""
         plan = self.__dict__.pop("_accel", None)
         if plan is not None and hasattr(self.material, "_unbind"):
-            self.material._unbind()
+            for key in plan.bound_keys:   # what this map page-locked; bindings the user or another map made stay
+                self.material._unbind(key)
 
     def __del__(self):
         try:
@@ -212,6 +283,7 @@ class AcceleratedUpdate:
                 if pin is not None and rows.size:
                     try:
                         pin(gradient=grad.function.x.array)
+                        plan.bound_keys += ("gradient",)
                     except Exception as exc:   # uploaded through the library's staging ring instead
                         _slow_path_warning(f"the '{name}' gradient Function", exc)
                 plan.grad_buffers[name] = rows
@@ -242,67 +314,95 @@ class AcceleratedUpdate:
             for name, dim in m.gradients.items():
                 if name in self.gradients:
                     state[name] = np.array(self._gradient_rows(name, dim))
-        for funs, sizes in ((self.fluxes, m.fluxes), (self.internal_state_variables, m.internal_state_variables)):
+        for funs, sizes in ((self.fluxes, m.fluxes), (self._isv_functions(), m.internal_state_variables)):
             for name, dim in sizes.items():
                 state[name] = np.array(self._take(funs[name], dim))
         m.set_initial_state_dict(state)
         self._initialized = True
 
     def update(self):
-        """One constitutive update of the map's points (once per global Newton iteration, ``solvers.py:173-176``)."""
+        """One constitutive update of the map's points (once per global Newton iteration, ``solvers.py:173-176``), in the
+        reference's four timed phases (``quadrature_map.py:302-331``)."""
         if not self._initialized:
             self.initialize_state()
         m = self.material
         plan = self._accel_plan()
-        if getattr(self, "external_state_variables", None):
-            self.update_external_state_variables()
+        with _Timer("dx_mat: External state variable update"):
+            if getattr(self, "external_state_variables", None):
+                self.update_external_state_variables()
         rotate = getattr(m, "rotation_matrix", None) is not None
-        if plan.row_outputs and not rotate:
-            # a map over a subset of the cells: the engine stores each point's stress and tangent block in its row of the
-            # Functions (the index the constructor built, quadrature_map.py:231-233) -- no scatter afterwards
-            (flux_fun,), (flux_dim,) = self.fluxes.values(), m.fluxes.values()
-            out = (plan.rows, rows_of(flux_fun, flux_dim), rows_of(self.jacobian_flatten, self._jacobian_width()))
-            if plan.device_gradient is not None:
+        rows_mode = plan.row_outputs and not rotate
+        grad = None
+        with _Timer("dx_mat: Gradients evaluation"):
+            if plan.device_gradient is None:   # (else: evaluated inside the update kernel from the displacement vector)
+                grad = self._gradient_block()
+        if rotate and grad is not None:   # in place, on the rows (quadrature_map.py:315-318); a bound gradient Function is re-evaluated next call
+            m.rotate_gradients(grad.ravel(), self.rotation_func.x.array)
+        flux = tangent = None
+        with _Timer("dx_mat: Material integration"):
+            if rows_mode:
+                # a map over a subset of the cells: the engine stores each point's stress and tangent block in its row of the
+                # Functions (the index the constructor built, quadrature_map.py:231-233) -- no scatter afterwards
+                (flux_fun,), (flux_dim,) = self.fluxes.values(), m.fluxes.values()
+                out = (plan.rows, rows_of(flux_fun, flux_dim), rows_of(self.jacobian_flatten, self._jacobian_width()))
+                if plan.device_gradient is not None:
+                    mesh, displacement = plan.device_gradient
+                    isv = m.integrate_displacement_rows(mesh, displacement(), *out)
+                else:
+                    isv = m.integrate_rows(grad, *out)
+            elif plan.device_gradient is not None:
                 mesh, displacement = plan.device_gradient
-                self._last_isv = m.integrate_displacement_rows(mesh, displacement(), *out)
+                flux, isv, tangent = m.integrate_displacement(mesh, displacement())
             else:
-                self._last_isv = m.integrate_rows(self._gradient_block(), *out)
-            assert m.last_stats["n_nan"] == 0, "non-finite constitutive update"
-            self.__dict__["_accel_rows_current"] = True     # the flux Function holds the final flux already (advance)
-            if self.isv_every_update:
-                self.refresh_internal_state_variables()
-            return
-        self.__dict__["_accel_rows_current"] = False
-        if plan.device_gradient is not None:
-            mesh, displacement = plan.device_gradient
-            flux, isv, tangent = m.integrate_displacement(mesh, displacement())
-        else:
-            grad = self._gradient_block()
-            if rotate:   # in place, on the rows (quadrature_map.py:315-318); a bound gradient Function is re-evaluated next call
-                m.rotate_gradients(grad.ravel(), self.rotation_func.x.array)
-            flux, isv, tangent = m.integrate(grad)
-        stats = getattr(m, "last_stats", None)
-        if stats is not None and "n_nan" in stats:
-            assert stats["n_nan"] == 0, "non-finite constitutive update"
-        else:   # quadrature_map.py:322-324
-            assert not np.any(np.isnan(flux))
-            assert not np.any(np.isnan(isv))
-            assert not np.any(np.isnan(tangent))
+                flux, isv, tangent = m.integrate(grad)
+            stats = getattr(m, "last_stats", None)
+            if stats is not None and "n_nan" in stats:   # counted by the kernel: flux, state and tangent
+                assert stats["n_nan"] == 0, "non-finite constitutive update"
+            else:   # quadrature_map.py:322-324
+                assert not np.any(np.isnan(flux))
+                assert not np.any(np.isnan(isv))
+                assert not np.any(np.isnan(tangent))
         if rotate:
             m.rotate_fluxes(np.asarray(flux).ravel(), self.rotation_func.x.array)
             m.rotate_tangent_operator(np.asarray(tangent).ravel(), self.rotation_func.x.array)
-        self._put_columns(self.fluxes, m.fluxes, flux)
-        self._put(self.jacobian_flatten, self._jacobian_width(), tangent)
-        self._last_isv = isv
-        if self.isv_every_update:
-            self.refresh_internal_state_variables()
+        with _Timer("dx_mat: Update values and tangent operators"):
+            self.__dict__["_accel_rows_current"] = rows_mode     # rows mode: the flux Function holds the final flux already (advance)
+            if not rows_mode:
+                self._put_columns(self.fluxes, m.fluxes, flux)
+                self._put(self.jacobian_flatten, self._jacobian_width(), tangent)
+            self._last_isv = isv
+            self.__dict__["_accel_isv_stale"] = bool(m.internal_state_variables)
+            if self.isv_every_update is True:
+                self.refresh_internal_state_variables()
 
     def refresh_internal_state_variables(self):
         """Internal state variables of the last ``update()`` into their Functions (what the reference does in every
         update, ``quadrature_map.py:332, :343-348``); with the engine this is where they are downloaded."""
         sizes = self.material.internal_state_variables
-        if sizes and getattr(self, "_last_isv", None) is not None:
-            self._put_columns(self.internal_state_variables, sizes, np.asarray(self._last_isv))
+        self.__dict__["_accel_isv_stale"] = False
+        if not sizes or getattr(self, "_last_isv", None) is None:
+            return
+        plan = self._accel_plan()
+        reader = getattr(self.material, "read_final_state", None)
+        fields = self._isv_functions()
+        if plan.identity and reader is not None:   # device -> the Function's (page-locked) memory, one transfer per field
+            for name, dim in sizes.items():
+                reader(name, rows_of(fields[name], dim))
+            return
+        self._put_columns(fields, sizes, np.asarray(self._last_isv))
+
+    @property
+    def variables(self):
+        """``quadrature_map.py``'s merged dict of gradients, fluxes and state Functions -- with the state refreshed first."""
+        if self.__dict__.get("_accel_isv_stale") and self.isv_every_update == "lazy":
+            self.refresh_internal_state_variables()
+        return super().variables
+
+    def project_on(self, *args, **kwargs):
+        """``quadrature_map.py:362-405`` on current fields (the lazy mode downloads the state here if an ``update()`` came since)."""
+        if self.__dict__.get("_accel_isv_stale") and self.isv_every_update == "lazy":
+            self.refresh_internal_state_variables()
+        return super().project_on(*args, **kwargs)
 
     def advance(self):
         """Accept the increment: initial state <- final state in the material, final flux and internal state
@@ -312,7 +412,8 @@ class AcceleratedUpdate:
         plan = self._accel_plan()
         reader = getattr(m, "read_final_state", None)
         final = None
-        for funs, sizes in ((self.fluxes, m.fluxes), (self.internal_state_variables, m.internal_state_variables)):
+        self.__dict__["_accel_isv_stale"] = False   # written below
+        for funs, sizes in ((self.fluxes, m.fluxes), (self._isv_functions(), m.internal_state_variables)):
             for name, dim in sizes.items():
                 if plan.identity and reader is not None:
                     reader(name, rows_of(funs[name], dim))     # device -> the Function's memory, no intermediate array

@@ -33,7 +33,9 @@
  *     device-pointer launches on one handle must be ordered on the same HIP stream (advance()
  *     and revert() only swap pointers on the host);
  *   - there is NO CPU fallback: every entry point that computes fails with a negative code when no
- *     HIP device is usable.
+ *     HIP device is usable;
+ *   - measurement and research entry points (placement tuning, launch timing, matrix-free assembly kernels) are declared in
+ *     dxmat_experimental.h: exported by the same library, not part of this contract.
  */
 #ifndef DXMAT_H
 #define DXMAT_H
@@ -44,9 +46,8 @@
 extern "C" {
 #endif
 
-#define DXM_ABI_VERSION 4   /* 3: DXM_TANGENT_PACK4, dxm_expand_tangent_pack4_device, dxm_host_copy, option "packed_transfer" = 2;
-                             * 4: option "keep_initial_io", dxm_io_held, dxm_get_io, dxm_integrate_rows, dxm_integrate_displacement_rows, dxm_time_device, dxm_host_scatter_rows,
-                             *    dxm_host_gather_rows */
+#define DXM_ABI_VERSION 5   /* 5: dxm_host_index_range; n_nan covers the tangent; placement tuning, launch timing and the
+                             *    assembly-side kernels moved to dxmat_experimental.h */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
 enum {
@@ -94,7 +95,7 @@ typedef struct dxm_stats {
   int64_t n_points;
   int64_t n_plastic;        /* points that took the plastic branch */
   int64_t n_not_converged;  /* local Newton hit maxit              */
-  int64_t n_nan;            /* points with a non-finite flux / isv */
+  int64_t n_nan;            /* points with a non-finite flux, isv or tangent (quadrature_map.py:322-324) */
   int32_t max_local_iters;
   int32_t upload;   /* host-buffer form: how the gradient reached the GPU in this call -- DXM_UPLOAD_* below; 0 otherwise */
 } dxm_stats;
@@ -123,19 +124,13 @@ int64_t dxm_npoints(const dxm_material* m);
 int dxm_law(const dxm_material* m);
 /* Material.update_material_property (generic.py:119-120): replace the parameter vector. */
 int dxm_set_params(dxm_material* m, const double* params, int n_params);
-/* Tangent layout written by integrate: the full row-major (n_flux*n_grad) block the reference's
- * `jacobian_flatten` holds (quadrature_map.py:83-105), or -- small-strain laws only, whose
- * tangent is symmetric -- the 21 upper-triangle entries (i <= j, row-major).  The packed form
- * cuts the dominant store / D2H / all-gather stream by 42 %; its consumer must index it itself
- * (the reference's UFL side expects the full block). */
-/* DXM_TANGENT_COEF (J2 laws): the algorithmic tangent of the radial return is Ct = c1 1x1 + c2 I + c3 n x n
- * (tests/mfront/IsotropicLinearHardeningPlasticity.mfront:66-69 with M expanded); integrate writes the nine
- * numbers (c1, c2, c3, n[0..5]) per point and a consumer that assembles B^T Ct B can use the rank structure
- * directly (examples/hex_fem.py): 72 instead of 288 B/point leave the device. */
-/* DXM_TANGENT_PACK4 (J2 laws): (c1, c2, c3, w) only, 32 B/point.  The kernels build the tangent with the flow direction
- * n = dev(stress) w (three individually rounded operations on the stress they store), so a consumer that holds the stress
- * of the same update rebuilds n and the block bit for bit: dxm_expand_tangent_pack4_device on the GPU,
- * conventions.tangent_from_pack4 in numpy; the host-buffer form does it internally (option "packed_transfer" = 2). */
+/* Tangent layout integrate writes, doubles per point:
+ *   DXM_TANGENT_FULL   n_flux*n_grad (36 / 81), row-major: what `jacobian_flatten` holds (quadrature_map.py:83-105);
+ *   DXM_TANGENT_SYM    21 upper-triangle entries (i <= j), small-strain laws (symmetric tangent);
+ *   DXM_TANGENT_COEF   9 = (c1, c2, c3, n[0..5]) of Ct = c1 1x1 + c2 I + c3 n x n, J2 laws
+ *                      (tests/mfront/IsotropicLinearHardeningPlasticity.mfront:66-69 with M expanded);
+ *   DXM_TANGENT_PACK4  4 = (c1, c2, c3, w), J2 laws: the kernels form n = dev(stress) w, so the stress of the same update
+ *                      and these four rebuild the block bit for bit (dxm_expand_tangent_pack4_device). */
 /* dxm_stats.upload */
 enum { DXM_UPLOAD_NONE = 0, DXM_UPLOAD_PAGE_LOCKED = 1 /* the caller's array was page-locked already: DMA */,
        DXM_UPLOAD_REGISTERED = 2 /* page-locked by the library for the duration of the call: DMA */,
@@ -158,15 +153,11 @@ int dxm_get_state(dxm_material* m, int which, int field, double* host_aos);
 int dxm_advance(dxm_material* m);
 /* DataManager.revert(): s1 <- s0   (generic.py:215-216, jaxmat.py:42-43) */
 int dxm_revert(dxm_material* m);
-/* The reference's state dictionaries also hold the gradient and the flux of each state (generic.py:194-201:
- * get_initial_state_dict()["Strain"] / ["Stress"]).  The kernels do not need them and the caller normally has them (they
- * are what it passed to and received from dxm_integrate) -- unless its own arrays are overwritten by the next update (the
- * Functions an accelerated QuadratureMap binds) or the results went to scattered rows (dxm_integrate_rows).  The device
- * copies of the last host-buffer call serve then: dxm_get_io(m, DXM_S1, kind, host_aos) downloads the gradient (kind 0) or
- * flux (kind 1) of the final state, (npoints, n_grad | n_flux); with option "keep_initial_io" dxm_advance keeps them as those
- * of s0 (a pointer swap, +96 B/point of HBM, no copy) for dxm_get_io(m, DXM_S0, ...).  They follow the host-buffer calls
- * only: a state produced through device pointers leaves them as they were.  dxm_io_held(m, which): bit 0 = a gradient is
- * held for that state, bit 1 = a flux (negative: bad arguments). */
+/* Gradient and flux of a state (generic.py:194-201: get_initial_state_dict()["Strain"] / ["Stress"]) from the device copies
+ * of the last HOST-BUFFER call: dxm_get_io(m, which, kind, host_aos) downloads the gradient (kind 0) or flux (kind 1),
+ * (npoints, n_grad | n_flux).  With option "keep_initial_io" dxm_advance keeps the copies of the accepted state as those of s0
+ * (a pointer swap).  A state accepted from a call without host arrays (device pointers; a fused displacement for the gradient)
+ * holds no copy.  dxm_io_held(m, which): bit 0 = a gradient is held for that state, bit 1 = a flux (negative: bad arguments). */
 int dxm_io_held(const dxm_material* m, int which);
 int dxm_get_io(dxm_material* m, int which, int kind, double* host_aos);
 
@@ -187,7 +178,8 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
  * rebuild the (6, 6) blocks store them, and the stress, straight into their rows; the caller's arrays need not be page-locked.
  * (The elastic law's constant block is filled in by the same threads, the FeFp laws move their 54 building blocks + 9 stress
  * components per point.)  DXM_TANGENT_FULL only (packed layouts: dxm_integrate + dxm_host_scatter_rows); the index holds each
- * row once and is not range-checked; internal state variables: dxm_isv_host / dxm_get_state when needed. */
+ * row once and is NOT range-checked here (dxm_host_index_range is the check; the Python layer runs it per call); internal
+ * state variables: dxm_isv_host / dxm_get_state when needed. */
 int dxm_integrate_rows(dxm_material* m, const double* grad_aos, double dt, double* flux_rows, double* ct_rows,
                        const int64_t* rows, dxm_stats* stats);
 /* Device-pointer form: all three arrays are device memory on the handle's device (e.g. torch
@@ -202,40 +194,6 @@ int dxm_get_stats(dxm_material* m, dxm_stats* stats);
 int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_stream);
 /* Device address of component `comp` of SoA state field `field` (npoints contiguous doubles). */
 const double* dxm_state_ptr(const dxm_material* m, int which, int field, int comp);
-/* Placement tuning (optional, synchronous; not capturable).  The update kernel's time depends on
- * where the handle's resident state sits relative to the caller's gradient / flux / tangent arrays
- * (bimodal, up to +13 % at 1e7 J2 points; physical placement, not steerable from user space -- neither
- * by offsets, strides or alignment (round 1) nor by assembling the state from permuted 2 MiB ... 256 MiB
- * physical chunks with the virtual-memory API (round 2, dxm_place_state): DESIGN.md section 3).
- * This call measures instead: it runs the update (exactly as dxm_integrate_device would, on the
- * handle's own stream) with the caller's real device arrays on up to max_candidates fresh state
- * allocations and keeps the fastest; s0 is preserved, s1 / flux_dev / ct_dev / the stats end up as
- * after one dxm_integrate_device(grad_dev, ...).  Stops six candidates after both modes have been seen.
- * The first half of the candidates are consecutive allocations, the second half jump ahead by skip
- * blocks of 1, 2, 4 ... GiB that together stay below option "tune_max_skip_bytes" (default 2 GiB);
- * everything but the winner is freed before returning.  The recommended budget is max_candidates = 4
- * (what HIPMaterial.tune_placement and bench.py use): ~10-50 ms, at most four state blocks + 2 GiB held
- * meanwhile; on a box where the first candidates are all in the slow mode the handle simply stays there
- * (a deeper search -- 24 candidates, 16 GiB skips -- found a fast region on every box of round 1, at up to
- * 2.5 s and tens of GB held).  Option "tune_verbose" logs every candidate to stderr.  No-op for laws
- * without state.  ms_before / ms_after: kernel time (ms) on the initial / chosen placement; n_tried:
- * candidates measured (any may be NULL).  No counterpart in the reference (its state lives in jax arrays). */
-int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
-                       int max_candidates, double* ms_before, double* ms_after, int* n_tried);
-/* The caller's side of the same effect: with the state placed, where the caller's TANGENT array sits still decides between two
- * levels of the J2 kernels 3 % apart (up to 12 % for the FeFp laws, 17 % for the elastic law, which has no state; flux and
- * gradient arrays <= 1 %).  A
- * device-resident caller that allocates its own arrays can try a few allocations of that array and keep the fastest;
- * dxm_time_device is the measurement: `launches` updates with these arrays on the handle's own stream (synchronous, two
- * warm-up launches first), best launch time in ms.  Acts like dxm_integrate_device otherwise (s0 preserved).
- * HIPMaterial.fastest_tangent_array(alloc, grad_ptr, flux_ptr) is the loop; bench.py uses it (--tangent-candidates). */
-int dxm_time_device(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev, int launches, double* best_ms);
-/* Experimental placement control: rebuild the resident state (contents preserved) in mode 0 a fresh hipMalloc
- * block, 1 separately created physical chunks of chunk_bytes (rounded up to the allocation granularity) mapped in
- * creation order, 2 the same chunks mapped in a pseudo-random order (seed) -- HIP virtual memory management
- * (hipMemCreate / hipMemMap).  Measured in round 2 as a deterministic alternative to dxm_tune_placement
- * (DESIGN.md section 3). */
-int dxm_place_state(dxm_material* m, int mode, uint64_t chunk_bytes, uint64_t seed);
 /* Rebuild full tangents from their coefficient form on the device: coef_dev (npoints, 9) as written with
  * DXM_TANGENT_COEF -> ct_dev (npoints, 36), the block DXM_TANGENT_FULL writes, bit for bit; asynchronous on
  * hip_stream of `device`.  For consumers that move the 72 B/point form (e.g. across xGMI: an all-gather of
@@ -251,7 +209,7 @@ const char* dxm_kernel_name(const dxm_material* m);
 /* Identity of the launch configuration: changes whenever a launch captured into a HIP graph before would
  * no longer do what a fresh call does -- dxm_advance (the two state buffers swap: the low bit flips and
  * flips back at the next advance), dxm_set_params / dxm_set_newton / dxm_set_tangent_layout /
- * dxm_set_option / dxm_tune_placement (the upper bits increase).  Replay a captured graph only while the
+ * dxm_set_option and anything else that moves the resident state (the upper bits increase).  Replay a captured graph only while the
  * value equals the one read at capture time.  dxm_revert does not change it. */
 uint64_t dxm_launch_generation(const dxm_material* m);
 /* Tell the handle that the caller has replayed a HIP graph containing a launch of this handle: the replay
@@ -296,9 +254,7 @@ int dxm_notify_replay(dxm_material* m);
  *                            allows (default 1)
  *   "blocks_per_cu"  1..256  grid size of the update kernel in workgroups per CU (default 32 small strain,
  *                            the resident 2 for FeFp)
- *   "tune_verbose"   1 | 0   dxm_tune_placement logs every candidate, the host-buffer form its chunk timeline, to
- *                            stderr (default 0)
- *   "tune_max_skip_bytes"    upper bound on the skip blocks dxm_tune_placement may hold (default 2 GiB) */
+ *   (dxmat_experimental.h adds "tune_verbose" and "tune_max_skip_bytes") */
 int dxm_set_option(dxm_material* m, const char* name, double value);
 /* get_initial_state_dict / get_final_state_dict without a device array of the caller: packs the
  * user-visible ISVs of state `which` and downloads them into host memory (npoints, n_isv_total).  This is
@@ -326,6 +282,9 @@ int dxm_host_copy(void* dst, const void* src, uint64_t bytes, int threads);
  * the index holds each row once (the caller's responsibility, as in the reference) and is not range-checked. */
 int dxm_host_scatter_rows(double* dst, const double* src, const int64_t* rows, int64_t n, int width, int threads);
 int dxm_host_gather_rows(double* dst, const double* src, const int64_t* rows, int64_t n, int width, int threads);
+/* Smallest and largest entry of such an index on `threads` threads (<= 0: 8): the range check that dxm_integrate_rows and the
+ * two calls above leave to the caller (~1 ms per 1e7 entries).  n == 0: *lo = INT64_MAX, *hi = INT64_MIN. */
+int dxm_host_index_range(const int64_t* rows, int64_t n, int threads, int64_t* lo, int64_t* hi);
 int dxm_host_register(void* p, uint64_t bytes);
 int dxm_host_unregister(void* p);
 
@@ -382,21 +341,6 @@ int dxm_integrate_displacement_rows(dxm_material* m, dxm_mesh* mesh, const doubl
 int dxm_integrate_displacement_device(dxm_material* m, dxm_mesh* mesh, const double* u_dev, double dt,
                                       double* flux_dev, double* ct_dev, void* hip_stream);
 
-/* ---- assembly-side consumers on the device (hex8 meshes with 8 Gauss points per cell, small strain) ----------
- * What dolfinx assembly does with the quadrature Functions that QuadratureMap.update filled -- the residual form
- * `dot(sig, strain(v)) * dx` and its derivative with the tangent blocks (tests/uniaxial_tension.py:62-67,
- * quadrature_map.py:132-158) -- restated matrix-free for a caller that keeps stress, tangent and displacement on the
- * GPU (no (N,6,6) array ever reaches the host):
- *   internal force   f = sum_q w detJ B_q^T sigma_q                       flux_dev (npoints,6) Mandel -> f_dev (n_nodes*3)
- *   tangent apply    y = sum_q w detJ B_q^T Ct_q B_q x                    ct_dev in `layout` (DXM_TANGENT_FULL or _COEF)
- *   tangent diagonal d = diag(sum_q w detJ B_q^T Ct_q B_q)                coefficient layout only
- * Deterministic (two passes: element values, then a node gather; no atomics), asynchronous on hip_stream, outputs
- * overwritten.  Quadrature weights default to 1 (2x2x2 Gauss-Legendre on [-1,1]^3). */
-int dxm_mesh_set_weights(dxm_mesh* mesh, const double* weights /* nqp */);
-int dxm_mesh_internal_force_device(dxm_mesh* mesh, const double* flux_dev, double* f_dev, void* hip_stream);
-int dxm_mesh_tangent_apply_device(dxm_mesh* mesh, const double* ct_dev, int layout, const double* x_dev, double* y_dev,
-                                  void* hip_stream);
-int dxm_mesh_tangent_diagonal_device(dxm_mesh* mesh, const double* coef_dev, double* d_dev, void* hip_stream);
 
 #ifdef __cplusplus
 }

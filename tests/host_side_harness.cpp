@@ -191,9 +191,10 @@ static void test_many_producers(const Input& in) {
       CHECK(same_bits(outs[t], ref.ct_pack4) && memcmp(copies[t].data(), in.sg.data(), sizeof(double) * n * 6) == 0, "producer %d on the shared pool", t);
   }
   // pools created and destroyed while idle, with work queued, and right after work
+  // (the destructor finishes whatever is still queued before it joins: the output array must outlive the pool)
   for (int k = 0; k < 50; ++k) {
-    HostPool pool(1 + k % 7);
     std::vector<double> o(64 * 36);
+    HostPool pool(1 + k % 7);
     if (k % 3) pool.submit(in.coef.data(), o.data(), std::min<int64_t>(64, in.n), 9);
     if (k % 3 == 1) pool.wait();
   }
@@ -359,7 +360,8 @@ static void test_chooser() {
       if (w == 1) u.registered(12.0, (size_t)480e6); else ++staged;   // 24 ms/GB
       u.record(w, 30.0);
     }
-    CHECK(staged == 20 && total == 30, "20 of 30 calls staged after three slow registrations (got %d)", staged);
+    // call 1 registers and is not judged, calls 2-4 are slow -> calls 5-24 staged, calls 25-27 slow again -> 28-30 staged
+    CHECK(staged == 23 && total == 30, "23 of 30 calls staged around two runs of three slow registrations (got %d)", staged);
     UploadChooser r;
     r.set_option(2);
     CHECK(r.choose() == 1, "option 2 page-locks");

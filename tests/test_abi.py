@@ -12,8 +12,8 @@ from dolfinx_materials_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "dxmat.h")).read()
+def header_symbols(name="dxmat.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dxm_[a-z_0-9]+)\s*\(", src)))
 
@@ -22,13 +22,28 @@ def test_header_and_binding_declare_the_same_symbols():
     syms = header_symbols()
     assert len(syms) >= 20
     assert syms == sorted(_lib.SYMBOLS)
+    exp = header_symbols("dxmat_experimental.h")
+    assert exp == sorted(_lib.EXPERIMENTAL_SYMBOLS) and not set(exp) & set(syms)
+    # the contract does not mention the lab equipment
+    core_text = open(os.path.join(ROOT, "include", "dxmat.h")).read()
+    for name in exp:
+        assert name not in core_text, name
 
 
 def test_library_exports_every_header_symbol():
     lib = _lib.load()
-    for s in header_symbols():
+    for s in header_symbols() + header_symbols("dxmat_experimental.h"):
         assert hasattr(lib, s), s
-    assert lib.dxm_abi_version() == 4
+    assert lib.dxm_abi_version() == 5
+
+
+def test_library_exports_nothing_else():
+    """Every dxm_* symbol the shared object exports is declared in one of the two headers."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "dolfinx_materials_amd", "libdxmat.so")], capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r"\sT\s+dxm_", ln)})
+    assert exported == sorted(header_symbols() + header_symbols("dxmat_experimental.h"))
 
 
 def test_law_table():

@@ -142,16 +142,28 @@ def test_bound_arrays_keep_the_initial_gradient_and_flux_on_the_device():
     m.data_manager.update()
     m.data_manager.update()
     assert lib.dxm_io_held(handle, 0) == 3 and np.array_equal(np.asarray(m.get_initial_state_dict()["strain"]), h[1])
-    # a state produced by a device-pointer form has no host arrays: like an unbound mirror, the views keep what they had
+    # a state produced by a device-pointer form has no host arrays and brings no device copy along: its gradient / flux
+    # mirrors say "unknown" (all NaN, no memory) instead of showing the arrays of an earlier increment, on both sides of the ABI
     import torch
     d_eps, d_flux, d_ct = to_device(h[3]), torch.empty((n, 6), dtype=torch.float64, device="cuda:0"), torch.empty((n, 36), dtype=torch.float64, device="cuda:0")
     m.integrate_device(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr())
     torch.cuda.synchronize()
+    assert np.isnan(m.get_final_state_dict()["stress"]).all() and m.get_final_state_dict()["stress"].strides == (0, 0)
+    assert np.array_equal(np.asarray(m.get_initial_state_dict()["stress"]), f1)          # s0 is still the accepted increment
     m.data_manager.update()
-    assert np.array_equal(np.asarray(m.get_initial_state_dict()["stress"]), f1)
+    assert lib.dxm_io_held(handle, 0) == 0
+    assert lib.dxm_get_io(handle, 0, 1, flux_fn.ctypes.data_as(C.c_void_p)) < 0
+    s0_after = m.get_initial_state_dict()
+    assert np.isnan(s0_after["stress"]).all() and np.isnan(s0_after["strain"]).all() and s0_after["stress"].shape == (n, 6)
+    assert np.isfinite(s0_after["p"]).all()                                              # the state proper is on the device, as always
+    # the next host-buffer call and advance bring real mirrors back
+    rows[...] = h[3]
+    f3 = np.array(m.integrate(rows)[0])
+    m.data_manager.update()
+    assert lib.dxm_io_held(handle, 0) == 3 and np.array_equal(np.asarray(m.get_initial_state_dict()["stress"]), f3)
     # an explicit initial stress replaces the view
     m.set_initial_state_dict({"stress": np.ones((n, 6))})
-    assert np.array_equal(np.asarray(s0["stress"]), np.ones((n, 6)))
+    assert np.array_equal(np.asarray(m.get_initial_state_dict()["stress"]), np.ones((n, 6)))
     m.close()
 
 
@@ -199,6 +211,16 @@ def test_integrate_rows_delivers_every_point_into_its_row(kind, n, total, device
         m.integrate_rows(h[3], rows.astype(np.int32), flux_fn, jac_fn)  # the index is int64
     with pytest.raises(ValueError):
         m.integrate_rows(h[3], rows + total, flux_fn, jac_fn)          # out of range
+    if n > 1:   # the SAME index array, changed in place since it was last checked: caught (the check runs in every call)
+        keep = rows[-1]
+        rows[-1] = total + 5
+        with pytest.raises(ValueError):
+            m.integrate_rows(h[3], rows, flux_fn, jac_fn)
+        rows[-1] = -1
+        with pytest.raises(ValueError):
+            m.integrate_rows(h[3], rows, flux_fn, jac_fn)
+        rows[-1] = keep
+        m.integrate_rows(h[3], rows, flux_fn, jac_fn)
     m.close()
     ref_m.close()
 

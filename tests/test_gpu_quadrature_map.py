@@ -99,7 +99,7 @@ def test_accelerated_map_matches_the_oracle_material_behind_the_reference_cadenc
     fast.material.close()
 
 
-def test_bound_map_delivers_into_the_fields_memory_and_fetches_isvs_at_advance_only():
+def test_bound_map_delivers_into_the_fields_memory_and_fetches_isvs_when_looked_at():
     ncell, nqp = 5000, 8
     n = ncell * nqp
     hist = j2_history(n, seed=2)
@@ -113,10 +113,16 @@ def test_bound_map_delivers_into_the_fields_memory_and_fetches_isvs_at_advance_o
     assert m._bound["tangent"].ctypes.data == q.jacobian_flatten.x.array.ctypes.data
     assert m._bound["gradient"].ctypes.data == q.gradients["strain"].function.x.array.ctypes.data
     assert isinstance(q._last_isv, LazyISV) and not q._last_isv.fetched        # nothing looked at the ISVs
-    assert not q.internal_state_variables["p"].x.array.any() and m.last_stats["n_plastic"] > 0
+    held = q._isv_functions()["p"]                                             # (no refresh through this accessor)
+    assert not held.x.array.any() and m.last_stats["n_plastic"] > 0
+    # the first look at the dict downloads them straight into the Functions' page-locked memory (isv_every_update = "lazy")
+    ref1 = onp.j2_update(hist[1], np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
+    assert np.abs(q.internal_state_variables["p"].x.array - ref1["p"]).max() < 1e-14 and held.x.array.any()
+    assert np.abs(q.variables["epsp"].values - ref1["epsp"]).max() < 1e-14
+    assert not q._last_isv.fetched                                             # ... not through a staged (N, 7) array
     now["g"] = hist[2]
     q.update()
-    assert not q._last_isv.fetched
+    assert q.__dict__["_accel_isv_stale"] and np.abs(held.x.array - ref1["p"]).max() < 1e-14   # stale until somebody looks / advance
     q.advance()
     ref = onp.j2_update(hist[2], np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(SIG0_LIN, H_LIN))
     assert np.abs(q.internal_state_variables["p"].x.array - ref["p"]).max() < 1e-14
@@ -241,3 +247,65 @@ def test_engine_behind_the_map_reproduces_the_reference_classs_fields(case):
             assert np.abs(_fields(q)[name] - gold[f"{case}_{i}_{name}"]).max() <= 1e-12 * scale[name], (case, i, op, name)
     q.close()
     q.material.close()
+
+
+def test_close_gives_back_only_what_the_map_bound():
+    """`close()` un-page-locks the arrays THIS map bound; a binding the caller made on the same material stays."""
+    ncell, nqp = 300, 8
+    n = ncell * nqp
+    cells = np.arange(0, ncell, 2, dtype=np.int32)
+    m = JAXMaterial(_behavior("j2_linear"))
+    q = QuadratureFieldMap(ncell, nqp, m, cells=cells)          # a subset map binds nothing itself
+    npts = len(cells) * nqp
+    mine = np.zeros(npts * 6)
+    m.bind_inputs(gradient=mine)                                # the caller's own page-locked gradient buffer
+    eps = j2_history(npts, seed=5)[2]
+    q.register_gradient("strain", lambda c: eps.reshape(len(cells), nqp, 6))
+    q.update()
+    assert set(m._bound) == {"gradient"}
+    q.close()
+    assert set(m._bound) == {"gradient"} and m._bound["gradient"] is mine
+    # ... and a map over everything gives back its five, not the sixth
+    m2 = JAXMaterial(_behavior("j2_linear"))
+    q2 = QuadratureFieldMap(ncell, nqp, m2)
+    e2 = j2_history(n, seed=6)[2]
+    q2.register_gradient("strain", lambda c: e2.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    q2.update()
+    assert set(m2._bound) == {"flux", "tangent", "gradient", "isv:p", "isv:epsp"}
+    q2.close()
+    assert not m2._bound
+    m.close()
+    m2.close()
+
+
+def test_update_keeps_the_references_timer_rows_with_the_engine(monkeypatch):
+    import contextlib
+
+    import dolfinx_materials_amd.hip_material as hm
+    import dolfinx_materials_amd.quadrature_map as qm
+
+    seen = []
+
+    @contextlib.contextmanager
+    def recorder(name):
+        seen.append(name)
+        yield
+
+    monkeypatch.setattr(qm, "_Timer", recorder)
+    monkeypatch.setattr(hm, "_Timer", recorder)
+    ncell, nqp = 64, 8
+    eps = j2_history(ncell * nqp, seed=1)[2]
+    m = JAXMaterial(_behavior("j2_voce"))
+    q = QuadratureFieldMap(ncell, nqp, m)
+    q.register_gradient("strain", lambda c: eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    q.update()
+    q.update()
+    dx = [s for s in seen if s.startswith("dx_mat:")]
+    assert dx == 2 * ["dx_mat: External state variable update", "dx_mat: Gradients evaluation", "dx_mat: Material integration",
+                      "dx_mat: Update values and tangent operators"]
+    # the material's own rows nest inside "Material integration" (jaxmat.py:209-223)
+    i0, i1 = seen.index("dx_mat: Material integration"), seen.index("dx_mat: Update values and tangent operators")
+    assert [s for s in seen[i0:i1] if s.startswith("jaxmat:")] == ["jaxmat: dolfinx to jaxmat conversion", "jaxmat: First pass (includes jit compilation)",
+                                                                    "jaxmat: jaxmat to dolfinx conversion"]
+    q.close()
+    m.close()

@@ -1,0 +1,187 @@
+"""What the kernels promise about the TANGENT beyond the seeds of test_gpu_parity.py:
+
+* the flow direction of every J2 tangent is formed as ``n = dev(sigma) w`` (``small_strain.hpp`` step 3/5) instead of the
+  oracle's ``n = 3 s_e / (2 seq)`` (``tests/mfront/IsotropicLinearHardeningPlasticity.mfront:61``): parity where that is worst
+  conditioned -- rho = R / seq -> 0 (H = 1e-6 as in ``tests/mfront/test_elastoplasticity.py:14-36``, trial stress 1e2 ... 1e4 x
+  sig0, large hydrostatic part), all four layouts, with the tolerance the construction implies written down;
+* ``n_nan`` covers the tangent like the reference's third assert (``quadrature_map.py:324``): a hardening law whose SLOPE is not
+  finite at the returned state leaves the stress finite and the tangent not."""
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from dolfinx_materials_amd.conventions import tangent_from_coefficients, tangent_from_pack4, unpack_sym_tangent
+from dolfinx_materials_amd.jaxmat import JAXMaterial
+from oracle import constitutive_np as onp
+
+from helpers import E, NU, eps_yield, fefp_path
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(float).eps
+
+
+def _strains(n, lo, hi, seed):
+    """Directions with a hydrostatic part, amplitudes lo ... hi yield strains (log-uniform)."""
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((n, 6))
+    d[:, :3] += rng.uniform(-2.0, 2.0, (n, 1))          # tr(eps) of the order of the deviator and larger
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    s = np.exp(rng.uniform(np.log(lo), np.log(hi), n)) * eps_yield(250.0)
+    return d * s[:, None]
+
+
+@pytest.mark.parametrize("hardening", ["linear_H1e-6", "voce_saturated"])
+@pytest.mark.parametrize("n", [64, 20_011])
+def test_flow_direction_from_the_stress_at_vanishing_rho(hardening, n):
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if hardening == "linear_H1e-6":
+        hd, ho = jm.LinearHardening(250.0, 1e-6), onp.LinearHardening(250.0, 1e-6)
+    else:   # saturates at sigu within p ~ 1e-2: perfect plasticity for everything larger
+        hd, ho = jm.VoceHardening(250.0, 251.0, 1e3), onp.VoceHardening(250.0, 251.0, 1e3)
+    beh = jm.vonMisesIsotropicHardening(el, hd)
+    eps = _strains(n, 1e2, 1e4, seed=77)
+    ref = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, ho)
+    assert ref["plastic"].all()
+    lam, mu = onp.lame(E, NU)
+    sig = ref["sig"]
+    third = sig[:, :3].sum(axis=1) / 3.0
+    dev = sig.copy()
+    dev[:, :3] -= third[:, None]
+    q = np.sqrt(1.5) * np.linalg.norm(dev, axis=1)
+    seq_trial = ref["f_trial"] + ho.R(np.zeros(n))
+    rho = q / seq_trial
+    assert rho.max() < 1.1e-2 and rho.min() < 2e-4             # R / seq: down to 1e-4
+    # what n = dev(sigma) w costs against n = 3 s_e / (2 seq): dev(sigma) is a difference of numbers of size |sigma_ii|, so
+    # n carries a relative error of a few eps |sigma_ii| / |dev sigma|; the tangent entry c3 n_i n_j twice that, c3 <= 2 mu
+    cond = (np.abs(sig[:, :3]).max(axis=1) / (np.sqrt(2.0 / 3.0) * q))
+    ct_scale = np.abs(ref["Ct"]).max()
+    tol = (1e-12 + 16.0 * EPS * cond)[:, None, None] * ct_scale
+    assert cond.max() > 1e3                                       # the case is what it claims to be
+
+    got = {}
+    for layout in ("full", "sym", "coef", "pack4"):
+        m = JAXMaterial(beh, tangent_layout=layout)
+        m.set_data_manager(n)
+        s_, isv, ct = m.integrate(eps)
+        assert m.last_stats["n_nan"] == 0 and m.last_stats["n_not_converged"] == 0 and m.last_stats["n_plastic"] == n
+        assert np.abs(s_ - sig).max() <= 1e-12 * np.abs(sig).max()
+        assert np.abs(np.asarray(isv)[:, 0] - ref["p"]).max() <= 1e-12 * ref["p"].max()
+        if layout == "full":
+            full = ct
+        elif layout == "sym":
+            full = unpack_sym_tangent(ct)
+        elif layout == "coef":
+            full = tangent_from_coefficients(ct).reshape(n, 6, 6)
+        else:
+            full = tangent_from_pack4(s_, ct).reshape(n, 6, 6)
+        got[layout] = np.array(full)
+        err = np.abs(full - ref["Ct"])
+        assert np.all(err <= tol), (layout, float((err / tol).max()))
+        m.close()
+    # the four layouts describe one tangent (packed forms rebuilt by numpy without fused multiply-add: a few ulp of the block)
+    for layout in ("sym", "coef", "pack4"):
+        assert np.abs(got[layout] - got["full"]).max() <= 8 * EPS * ct_scale
+    # ... and the device-pointer and host-buffer forms deliver the same bits at this conditioning too (the host rebuilds the block
+    # from (c1, c2, c3, w) and the stress it received)
+    m = JAXMaterial(beh)
+    m.set_data_manager(n)
+    m.set_option("packed_min_points", 0)
+    ct_packed = np.array(m.integrate(eps)[2])          # (the material reuses its output arrays from call to call)
+    m.set_option("packed_transfer", 0)
+    ct_plain = np.array(m.integrate(eps)[2])
+    assert np.array_equal(ct_packed, got["full"]) and np.array_equal(ct_plain, got["full"])
+    m.close()
+
+
+def test_a_yield_stress_that_is_not_positive_is_reported_not_hidden():
+    """rho = R(p) / seq <= 0 at the returned state (a softening law driven through zero): the flow direction is undefined, the
+    n x n term is dropped, and the point is counted as not converged instead of passing silently."""
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    soft = jm.CustomHardening("sig0 - K * p", "(-K)", sig0=250.0, K=5e4)    # R = 0 at p = 5e-3; K < 3 mu: the return still has a root
+    with pytest.warns(RuntimeWarning):
+        beh = jm.vonMisesIsotropicHardening(el, soft)
+        m = JAXMaterial(beh)
+        n = 256
+        m.set_data_manager(n)
+        eps = _strains(n, 30.0, 60.0, seed=5)
+        sig, isv, ct = m.integrate(eps)
+    st = m.last_stats
+    assert st["n_plastic"] == n and st["n_not_converged"] > 0 and st["n_nan"] == 0
+    assert np.isfinite(ct).all() and np.isfinite(sig).all()
+    m.close()
+
+
+LINEAR_R = "sig0 + H * p"
+
+
+@pytest.mark.parametrize("slope,expect_nan", [("(p <= 0.0 ? H : NAN)", True), ("(p <= 0.0 ? H : INFINITY)", False)])
+@pytest.mark.parametrize("layout", ["full", "pack4"])
+def test_small_strain_nan_count_covers_the_tangent(slope, expect_nan, layout):
+    """R(p) = sig0 + H p with a slope that is H at p = 0 and not finite beyond: the Newton iteration of the first increment
+    sees the finite slope, lands on the root in one step, and evaluates gamma = 1 / (R' + 3 mu) at the returned state.  NaN
+    there: finite stress, c3 = NaN -> every plastic point is counted and QuadratureMap.update() raises; infinite there:
+    gamma = 0, a finite (perfectly rigid-hardening) tangent, nothing to report."""
+    from dolfinx_materials_amd.field_map import QuadratureFieldMap
+
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    law = jm.CustomHardening(LINEAR_R, slope, sig0=250.0, H=5e3)
+    n = 1000
+    eps = _strains(n, 0.2, 3.0, seed=11)
+    ref = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, onp.LinearHardening(250.0, 5e3))
+    nplast = int(ref["plastic"].sum())
+    assert 0 < nplast < n
+    m = JAXMaterial(jm.vonMisesIsotropicHardening(el, law), tangent_layout=layout)
+    m.set_data_manager(n)
+    sig, isv, ct = m.integrate(eps)
+    st = m.last_stats
+    assert np.isfinite(sig).all() and np.isfinite(np.asarray(isv)).all()
+    assert np.abs(sig - ref["sig"]).max() <= 1e-12 * np.abs(ref["sig"]).max()      # the stress never saw the slope's defect
+    assert st["n_plastic"] == nplast and st["n_not_converged"] == 0
+    bad_rows = ~np.isfinite(np.asarray(ct).reshape(n, -1)).all(axis=1)
+    if expect_nan:
+        assert st["n_nan"] == nplast and np.array_equal(bad_rows, ref["plastic"])
+    else:
+        assert st["n_nan"] == 0 and not bad_rows.any()
+    m.close()
+    if layout == "full":   # the caller's view: the accelerated map asserts like quadrature_map.py:322-324
+        mat = JAXMaterial(jm.vonMisesIsotropicHardening(el, law))
+        q = QuadratureFieldMap(n // 8, 8, mat)
+        q.register_gradient("strain", lambda c: eps.reshape(n // 8, 8, 6)[c].reshape(-1, 6))
+        if expect_nan:
+            with pytest.raises(AssertionError, match="non-finite"):
+                q.update()
+        else:
+            q.update()
+        q.close()
+        mat.close()
+
+
+def test_fefp_nan_count_covers_the_tangent():
+    """FeFp: a point whose trial state is above yield by less than the Newton tolerance converges at its first iterate
+    (dp = 0) and takes the hardening slope of the yield test into the tangent's building blocks.  With a slope that is NaN the
+    stress is finite and the tangent is not: counted."""
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    n = 256
+    F = np.tile(fefp_path(1, n_exact=1)[9], (n, 1))            # the path of tests/test_FeFp_jax.py:28-30, one state for all points
+    st0 = onp.fefp_initial_state(n)
+    probe = onp.fefp_update(F, st0["cpinv"], st0["p"], E, NU, onp.LinearHardening(1.0, 1e3), tangent=False)
+    q_trial = float(probe["f_trial"][0] + 1.0)                 # sqrt(3/2) mu |dev be_trial|
+    sig0 = q_trial * (1.0 - 1e-12)                             # yield surface a hair inside the trial state
+    law = jm.CustomHardening(LINEAR_R, "NAN", sig0=sig0, H=1e3)
+    m = JAXMaterial(jm.FeFpJ2Plasticity(el, law))
+    m.set_data_manager(n)
+    m.set_newton(maxit=25, rtol=1e-9)
+    P, isv, ct = m.integrate(F)
+    st = m.last_stats
+    assert st["n_plastic"] == n and st["n_not_converged"] == 0
+    assert np.isfinite(P).all() and np.isfinite(np.asarray(isv)).all()
+    assert not np.isfinite(ct).all()
+    assert st["n_nan"] == n
+    # the same state with a finite slope: nothing to count
+    ok = JAXMaterial(jm.FeFpJ2Plasticity(el, jm.CustomHardening(LINEAR_R, "H", sig0=sig0, H=1e3)))
+    ok.set_data_manager(n)
+    ok.set_newton(maxit=25, rtol=1e-9)
+    P2, _, ct2 = ok.integrate(F)
+    assert ok.last_stats["n_nan"] == 0 and np.isfinite(ct2).all() and np.array_equal(P2, P)
+    m.close()
+    ok.close()

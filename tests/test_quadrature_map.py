@@ -33,9 +33,9 @@ class EngineLikeMaterial(OracleJ2Material):
         self.calls.append("bind_inputs")
         self._gradient_memory = gradient
 
-    def _unbind(self):
-        self.calls.append("unbind")
-        self._out = {}
+    def _unbind(self, key=None):
+        self.calls.append(f"unbind:{key}")
+        self._out.pop(key, None)
 
     def integrate(self, g, dt=0):
         if getattr(self, "_gradient_memory", None) is not None:   # the map must hand over the registered memory itself
@@ -127,18 +127,78 @@ def test_accelerated_update_equals_the_reference_cadence(material, subset):
             assert calls.count("pinned_array") == 1 + 2   # the gradient rows + the two ISV landing buffers
 
 
-def test_internal_state_variables_are_written_at_advance_only_by_default():
+def test_internal_state_variables_follow_isv_every_update():
+    """"lazy" (default): the Functions are refreshed by the first access to the dict after an update; False: at advance only
+    (the held Function object stays stale until then); True: in every update (quadrature_map.py:332)."""
     ncell, nqp = 5, 4
-    eps = j2_history(ncell * nqp, seed=9)[2]
+    hist = j2_history(ncell * nqp, seed=9)
+    now = {"eps": hist[1]}
+
+    def make(mode):
+        q = QuadratureFieldMap(ncell, nqp, OracleJ2Material(E, NU, _hard()))
+        q.isv_every_update = mode
+        q.register_gradient("strain", lambda c: now["eps"].reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+        return q
+
+    now["eps"] = hist[2]
+    ref = make(True)
+    ref.update()
+    p_ref = ref.internal_state_variables["p"].x.array.copy()
+    assert p_ref.any()
+
+    lazy = make("lazy")
+    held = lazy._isv_functions()["p"]            # a Function object taken out earlier
+    lazy.update()
+    assert lazy.fluxes["stress"].x.array.any() and not held.x.array.any()        # nothing has looked yet
+    assert np.array_equal(lazy.internal_state_variables["p"].x.array, p_ref)    # the access refreshes ...
+    assert np.array_equal(held.x.array, p_ref)                                   # ... the same Function object
+    lazy.update()
+    assert np.array_equal(lazy.variables["p"].x.array, p_ref) and not lazy.__dict__["_accel_isv_stale"]
+    assert {**lazy.internal_state_variables}.keys() == {"p", "epsp"}             # dict unpacking goes through the container
+    lazy.advance()
+    assert np.array_equal(held.x.array, p_ref)
+
+    off = make(False)
+    off.update()
+    assert not off.internal_state_variables["p"].x.array.any()                   # opted out: advance only
+    off.refresh_internal_state_variables()
+    assert np.array_equal(off.internal_state_variables["p"].x.array, p_ref)
+    off.advance()
+    assert np.array_equal(off.internal_state_variables["p"].x.array, p_ref)
+
+
+def test_update_runs_in_the_references_four_timed_phases(monkeypatch):
+    """`list_timings` keeps its "dx_mat: ..." rows (quadrature_map.py:302-331): a recording stub in place of dolfinx's Timer."""
+    import contextlib
+
+    import dolfinx_materials_amd.quadrature_map as qm
+
+    seen = []
+
+    @contextlib.contextmanager
+    def recorder(name):
+        seen.append(("enter", name))
+        yield
+        seen.append(("exit", name))
+
+    monkeypatch.setattr(qm, "_Timer", recorder)
+    ncell, nqp = 3, 4
+    eps = j2_history(ncell * nqp, seed=2)[2]
     q = QuadratureFieldMap(ncell, nqp, OracleJ2Material(E, NU, _hard()))
-    q.register_gradient("strain", lambda c: eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    calls = []
+    inner = q.material.integrate
+    q.material.integrate = lambda g, dt=0: (calls.append(list(seen)), inner(g, dt))[1]
+    q.register_gradient("strain", lambda c: (calls.append("grad"), eps.reshape(ncell, nqp, 6)[c].reshape(-1, 6))[1])
     q.update()
-    assert q.fluxes["stress"].x.array.any() and not q.internal_state_variables["p"].x.array.any()
-    q.refresh_internal_state_variables()
-    p_now = q.internal_state_variables["p"].x.array.copy()
-    assert p_now.any()
-    q.advance()
-    assert np.array_equal(q.internal_state_variables["p"].x.array, p_now)
+    names = ["dx_mat: External state variable update", "dx_mat: Gradients evaluation", "dx_mat: Material integration",
+             "dx_mat: Update values and tangent operators"]
+    # (the first update also evaluates the gradient once for initialize_state, outside the timers, like the reference)
+    assert [n for kind, n in seen if kind == "enter"] == names and [n for kind, n in seen if kind == "exit"] == names
+    during = calls[-1]    # what had been entered / left when integrate ran
+    assert ("enter", names[2]) in during and ("exit", names[2]) not in during and ("exit", names[1]) in during
+    del seen[:]
+    q.update()
+    assert [n for kind, n in seen if kind == "enter"] == names
 
 
 def test_map_over_all_cells_binds_the_functions_memory_and_scatters_nothing():
@@ -158,8 +218,8 @@ def test_map_over_all_cells_binds_the_functions_memory_and_scatters_nothing():
     assert m.calls.count("bind_outputs") == 1 and m.calls.count("bind_inputs") == 1   # once per map, not per call
     q.advance()
     assert [c for c in m.calls if c.startswith("read:")] == ["read:stress", "read:p", "read:epsp"]
-    q.close()
-    assert m.calls[-1] == "unbind"
+    q.close()   # gives back exactly what the map bound, key by key
+    assert [c for c in m.calls if c.startswith("unbind")] == ["unbind:flux", "unbind:tangent", "unbind:gradient"]
 
 
 def test_subset_map_does_not_bind_and_keeps_one_gradient_buffer():
