@@ -202,7 +202,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
     kernel, is the whole cost when the consumer lives on the host."""
     h = history(n, seed)
 
-    def timed(bind, pageable_dma=False, fresh=False, devices=None):
+    def timed(bind, pageable_dma=False, fresh=False, devices=None, calls=25):
         m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index, devices=devices)
         m.set_data_manager(n)
         if pageable_dma:
@@ -213,10 +213,15 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
         m.integrate(h[0])
         m.data_manager.update()
         ts = []
+        same = np.array(h[1])
         # five untimed calls first: the handle measures in its calls 2-5 whether page-locking the pageable strain array for the
-        # call or staging it is faster on this host (option register_input = 1) and keeps the winner
-        for k in range(5 + reps):
-            g = np.array(h[1]) if fresh else h[1]   # QuadratureMap.update builds a new gradient array per call
+        # call or staging it is faster on this host (option register_input = 1) and keeps the winner; then `calls` timed ones
+        for k in range(5 + calls):
+            if fresh:
+                g = np.array(h[1])   # QuadratureMap.update builds a new gradient array per call (quadrature_map.py:304-313)
+            else:
+                g = same
+                g[...] = h[1]        # ... or the same Function memory, rewritten by Expression.eval before every update
             t0 = time.perf_counter()
             m.integrate(g)
             if k >= 5:
@@ -224,9 +229,10 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
             del g
         uploads.append(m.last_upload)
         m.close()
+        spread.append([round(float(np.min(ts)) * 1e3, 2), round(float(np.median(ts)) * 1e3, 2), round(float(np.max(ts)) * 1e3, 2)])
         return float(np.median(ts))
 
-    uploads = []
+    uploads, spread = [], []
 
     def update_cadence(accelerated, reps, nqp=8):
         """One ``QuadratureMap.update()`` at n points (n / 8 hexahedra with 8 Gauss points), numpy stand-ins for the
@@ -418,8 +424,8 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
 
     # the first host-buffer leg of the process runs 0-8 ms slower than the same leg later on (whichever variant comes first:
     # worker threads, page-locked areas and the runtime's transfer paths are set up in it): one throw-away leg, then the figures
-    timed(True)
-    del uploads[:]
+    timed(True, calls=3)
+    del uploads[:], spread[:]
     dt_own, dt, dt_fast = timed(False), timed(True), timed(True, pageable_dma=True)
     dt_fresh, dt_fresh_fast = timed(True, fresh=True), timed(True, pageable_dma=True, fresh=True)
     out = {"value": round(n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_call": round(dt * 1e3, 3), "points": n,
@@ -433,6 +439,13 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
                                                 "staging ring: faster, but exposed to the runtime's cache of on-the-fly page-locked ranges (DESIGN.md section 1)"},
            "page_lock_ms_per_480MB": page_lock_probe(),
            "strain_upload": {"own_arrays": uploads[0], "bound_arrays": uploads[1], "pageable_dma": uploads[2], "new_array_every_call": uploads[3]},
+           "ms_per_call_min_median_max": {"own_arrays": spread[0], "bound_arrays": spread[1], "pageable_dma": spread[2], "new_array_every_call": spread[3],
+                                          "new_array_every_call_pageable_dma": spread[4]},
+           "calls_timed_per_leg": 25, "host_loadavg": open("/proc/loadavg").read().split()[:3] if os.path.exists("/proc/loadavg") else None,
+           "legs_note": "every leg: 5 untimed calls (the handle's upload probing), then the median of 25; the same-array legs rewrite the array before each call like "
+                        "Expression.eval does.  The call is bound by 16 host threads writing 288 B/point into host memory shared with the node's other tenants: "
+                        "on this pool single legs move by +-4 ms from run to run and their ORDER is not significant (profiles/r04_hostpath_upload_modes.md: "
+                        "register_input forced to 0 / 2 / adaptive x same / new / re-copied / rewritten array, 30 calls each, three boxes)",
            "pcie_bytes_per_point": {"h2d_strain": 48, "d2h_stress": 48, "d2h_tangent_coefficients": 32, "isv": "on demand (56)"},
            "GBs_over_pcie": round(n * 128 / dt / 1e9, 1),
            "note": "host buffers in and out through dxm_integrate: chunk-pipelined on two streams; of the tangent only (c1, c2, c3, w) cross PCIe -- the flow "
@@ -959,7 +972,7 @@ def main():
             box_after = None
             try:
                 box_after = {k: v for k, v in telemetry.condensed(telemetry.snapshot(tools=False)).items()
-                             if k in ("sclk", "mclk", "fclk", "power_w", "temp_c", "hbm_temp_c", "gpu_busy", "mem_busy", "vram_used", "vram_other_processes_on_my_gpu")} if telemetry else None
+                             if k in ("sclk", "mclk", "fclk", "power_w", "temp_c", "hbm_temp_c", "gpu_busy", "mem_busy", "vram_used", "vram_of_kfd_processes_on_my_gpu")} if telemetry else None
             except Exception as exc:
                 box_after = {"error": repr(exc)}
             out["box"] = {"before": box_before, "during_timed_steps": head.get("box_during"), "after": box_after,
@@ -1061,6 +1074,13 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # (the firmware counters are read through a rocm-smi child process, ~0.3 s during which the GPU idles: before the settling
+    # launches and the warm-up, not between them and the timed steps)
+    sampler = fw_before = None
+    tel = c.telemetry if rank == 0 else None
+    if tel is not None:
+        fw_before = tel.metrics()
+        sampler = tel.Sampler(period_s=0.005)
     # the box leaves its idle state: back-to-back launches for --settle-seconds, no host work in between (telemetry of the boxes
     # in profiles/r04_box_survey.jsonl: clocks do not move under this load and no launch but the very first after an idle gap
     # is slow -- the settling costs nothing and takes the question off the table)
@@ -1080,12 +1100,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         plastic_frac.append(st["n_plastic"] / n)
 
     # ---- the timed region: EXACTLY K steps between barrier + synchronize, every array where its first allocation put it -------
-    sampler = box_before = fw_before = None
-    tel = c.telemetry if rank == 0 else None
-    if tel is not None:
-        fw_before = tel.metrics()
-        box_before = tel.fast_read(tel.my_card()) if tel.my_card() else None
-        sampler = tel.Sampler(period_s=0.005)
+    box_before = tel.fast_read(tel.my_card()) if (tel is not None and tel.my_card()) else None   # a few file reads
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     barrier()
     if sampler is not None:
@@ -1108,7 +1123,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         box_during = {"sysfs_samples": sampler.summary(), "firmware_counters": tel.metrics_delta(fw_before, fw_after), "clocks_at_start": box_before,
                       "kernel_ms_min_median_max": [round(float(np.min(per_launch)), 4), round(float(np.median(per_launch)), 4), round(float(np.max(per_launch)), 4)],
                       "note": "sysfs_samples: min / median / max of a 5 ms sampler thread across the K timed steps (20 steps are ~20 ms: a handful of samples); "
-                              "firmware_counters: gpu_metrics accumulators read just before and just after (they bracket the region plus ~0.6 s of tool time)"}
+                              "firmware_counters: gpu_metrics accumulators read before the settling launches and after the timed steps (settling + warm-up + timed steps + ~0.3 s of tool time)"}
 
     # ---- context, after the timed region -----------------------------------------------------------------------------------
     # (1) the same kernel against two arithmetic-free streaming kernels that move its bytes, interleaved launch by launch on this

@@ -211,10 +211,10 @@ def test_tune_placement_preserves_state_and_results():
     torch.cuda.synchronize()
     assert torch.equal(flux, ref_flux) and torch.equal(ct, ref_ct)       # acts like integrate_device
     s0_after, s1_after = mat.get_initial_state_dict(), mat.get_final_state_dict()
-    for k in s0_before:
-        assert np.array_equal(s0_before[k], s0_after[k])
+    for k in s0_before:   # (gradient / flux mirrors of a device-pointer state are NaN placeholders)
+        assert np.array_equal(s0_before[k], s0_after[k], equal_nan=True)
     for k in s1_before:
-        assert np.array_equal(s1_before[k], s1_after[k])
+        assert np.array_equal(s1_before[k], s1_after[k], equal_nan=True)
     rc, stats = mat.stats()
     assert rc == 0 and stats["n_plastic"] > 0
     # the handle keeps working on the new block: advance + next increment against the oracle-free identity
@@ -316,6 +316,6 @@ def test_time_device_and_the_tangent_array_search_act_like_an_update():
     assert 1 <= len(times) <= 4 and len(made) == len(times) and best is made[k] and times[k] == min(times)
     assert torch.equal(best, ref_ct) and torch.equal(flux, ref_flux)          # every candidate received the update's tangent
     for name, a in mat.get_initial_state_dict().items():
-        assert np.array_equal(np.asarray(a), np.asarray(s0[name])), name
+        assert np.array_equal(np.asarray(a), np.asarray(s0[name]), equal_nan=True), name
     assert mat._lib.dxm_time_device(mat._handles()[0], None, None, None, 3, None) < 0
     mat.close()

@@ -282,8 +282,12 @@ def test_integrate_displacement_device_equals_gradient_then_update(law, cells):
         scale_f = float(fa.abs().max())
         assert float((fa - fb).abs().max()) <= 1e-12 * scale_f
         assert float((ca - cb).abs().max()) <= 1e-12 * float(ca.abs().max())
-        for k, v in a.get_final_state_dict().items():
-            assert np.abs(v - b.get_final_state_dict()[k]).max() <= 1e-12 * max(np.abs(v).max(), 1e-300), k
+        fin_a, fin_b = a.get_final_state_dict(), b.get_final_state_dict()
+        for k, v in fin_a.items():
+            if k in a.gradients or k in a.fluxes:   # device-pointer forms: the host never saw them ("unknown" placeholders)
+                assert np.isnan(v).all() and np.isnan(fin_b[k]).all(), k
+                continue
+            assert np.abs(v - fin_b[k]).max() <= 1e-12 * max(np.abs(v).max(), 1e-300), k
         a.data_manager.update()
         b.data_manager.update()
 

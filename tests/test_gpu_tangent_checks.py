@@ -50,7 +50,7 @@ def test_flow_direction_from_the_stress_at_vanishing_rho(hardening, n):
     q = np.sqrt(1.5) * np.linalg.norm(dev, axis=1)
     seq_trial = ref["f_trial"] + ho.R(np.zeros(n))
     rho = q / seq_trial
-    assert rho.max() < 1.1e-2 and rho.min() < 2e-4             # R / seq: down to 1e-4
+    assert rho.max() < 0.2 and np.median(rho) < 5e-3 and rho.min() < 2e-4   # R / seq: down to 1e-4
     # what n = dev(sigma) w costs against n = 3 s_e / (2 seq): dev(sigma) is a difference of numbers of size |sigma_ii|, so
     # n carries a relative error of a few eps |sigma_ii| / |dev sigma|; the tangent entry c3 n_i n_j twice that, c3 <= 2 mu
     cond = (np.abs(sig[:, :3]).max(axis=1) / (np.sqrt(2.0 / 3.0) * q))

@@ -330,9 +330,10 @@ def condensed(snap):
         return {"error": (snap or {}).get("error", "no snapshot"), "rocm_smi": (snap or {}).get("rocm_smi")}
     s, h, now = snap["sysfs"], snap.get("hwmon", {}), snap["now"]
     node = (snap.get("kfd", {}).get("nodes") or [{}])[0]
-    mine = os.getpid()
     gid = snap.get("kfd", {}).get("gpu_id")
-    others = [p for p in snap.get("kfd", {}).get("vram_by_process", []) if p["pid"] != mine and (gid is None or p["gpuid"] == gid)]
+    # (pids under /sys/class/kfd are the HOST's: this process cannot tell its own entry from another tenant's, so the sum is of
+    # every process on this GPU -- zero before this process initialises the GPU means nobody else is there)
+    others = [p for p in snap.get("kfd", {}).get("vram_by_process", []) if (gid is None or p["gpuid"] == gid)]
     elsewhere = [p for p in snap.get("kfd", {}).get("vram_by_process", []) if gid is not None and p["gpuid"] != gid]
     return {
         "card": snap.get("card"), "pci": snap.get("pci"), "unique_id": s.get("unique_id"), "vbios": s.get("vbios_version"), "driver": snap.get("driver_version"),
@@ -346,7 +347,7 @@ def condensed(snap):
         "temp_c": now.get("temp_c"), "hbm_temp_c": round(h["temp3_input"] / 1e3, 1) if h.get("temp3_input") else None,
         "gpu_busy": now.get("gpu_busy"), "mem_busy": now.get("mem_busy"),
         "vram_total": s.get("mem_info_vram_total"), "vram_used": s.get("mem_info_vram_used"),
-        "vram_other_processes_on_my_gpu": sum(p["vram_bytes"] for p in others) if others else 0,
+        "vram_of_kfd_processes_on_my_gpu": sum(p["vram_bytes"] for p in others) if others else 0,
         "vram_processes_on_other_gpus_of_the_node": sum(p["vram_bytes"] for p in elsewhere) if elsewhere else 0, "kfd_processes_visible": snap.get("kfd", {}).get("processes_visible"),
         "ras_bad_pages": (snap.get("ras") or {}).get("bad_pages"),
         "pcie": f"{s.get('current_link_speed')} x{s.get('current_link_width')}", "numa_node": s.get("numa_node"),

@@ -8,7 +8,7 @@ for path in sys.argv[1:] or ["gpurun_out/box_survey.jsonl"]:
         r = json.loads(line)
         b = r["box"]
         print(f"== {r.get('label')} {r.get('time')} uid {b.get('unique_id')} pci {b.get('pci')} (hip {r.get('hip_pci_bus_id')}) {b.get('compute_partition')}/{b.get('memory_partition')} "
-              f"cap {b.get('power_cap_w')} W vram_used {b.get('vram_used')} others_on_gpu {b.get('vram_other_processes_on_my_gpu')} "
+              f"cap {b.get('power_cap_w')} W vram_used {b.get('vram_used')} others_on_gpu {b.get('vram_of_kfd_processes_on_my_gpu', b.get('vram_other_processes_on_my_gpu'))} "
               f"node busy GPUs besides mine {b.get('node_gpus_busy_besides_mine')} load {b.get('host_loadavg')}")
         for k, v in r["legs"].items():
             s = v["sampler"]
