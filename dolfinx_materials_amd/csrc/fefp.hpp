@@ -39,7 +39,13 @@ constexpr int F2_REC = 73;   // record stride: 54 staged doubles per point, padd
 // kernel's streams, occupancy and compute gaps runs 1.63 ms per 1e7 points with 16-point rounds against 1.77 with 14
 // (tools/fefp_shape_probe.py, profiles/r03_fefp_shape_probe.md).  The price is a third, mostly idle, step per round
 // (7 + 7 + 2 point slots): 12 instead of 10 tangent steps per tile.
-constexpr int F2_PPR = 16;
+#ifndef DXM_FEFP_PPR
+#define DXM_FEFP_PPR 16
+#endif
+#ifndef DXM_FEFP_WGS
+#define DXM_FEFP_WGS 2
+#endif
+constexpr int F2_PPR = DXM_FEFP_PPR;
 constexpr int F2_STEPS = (F2_PPR + 6) / 7;
 constexpr int F2_NIT = (F2_PPR * 81 + 2 * WAVE - 1) / (2 * WAVE);   // 1 KiB wave stores per round (the last one partial)
 constexpr int F2_OUT = F2_PPR * 81;                                 // out-tile; the copy-out's last, partial KiB reads on into the records
@@ -125,7 +131,7 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
 //      same four-term expression, dxmat.hip::expand_fefp_tangent)
 constexpr int FEFP_REC = 54;
 template <int HARD, int GRAD = 0, int TLF = 0>
-__global__ void __launch_bounds__(BLOCK, 2)
+__global__ void __launch_bounds__(BLOCK, DXM_FEFP_WGS)
 fefp_kernel(const LawParams prm, const int64_t n, const double* __restrict__ Fin,
             const double* __restrict__ s0, double* __restrict__ s1, const int64_t ld,
             double* __restrict__ Pout, double* __restrict__ ct, BlockStats* __restrict__ stats,

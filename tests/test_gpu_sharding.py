@@ -141,35 +141,46 @@ def test_bench_starts_its_own_ranks(gpu_available):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["kernel_ms"] > 0
     pg = out["process_group"]
     assert pg["ranks_in_group"] == 2 and pg["ranks_counted_by_all_reduce"] == 2 and pg["launcher"] == "self"
     assert out["gather_inclusive"]["value"] > 0 and out["gather_inclusive"]["p2p_schedule"]["value"] > 0
     assert out["value"] > out["gather_inclusive"]["value"]
 
 
-def test_bench_with_eight_ranks_on_one_gpu_carries_the_cfg3_block(gpu_available):
-    """What an 8-GPU driver runs is `python bench.py --gpus 8`: here the same command in the debug share mode (all ranks on
-    GPU 0, gloo), small batches: eight ranks counted by the all-reduce, the cfg 2 weak-scaling headline with its gather
-    legs, and the `cfg3` block (Voce, its own points per rank) with the three reassembly schedules at >= 10 steps."""
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_line_of_the_drivers_scaling_sweep_on_one_gpu(gpu_available, world):
+    """What the driver's 1 -> 8 sweep runs is `python bench.py --gpus N`: here the same command for N = 4 and 8 in the debug
+    share mode (all ranks on GPU 0, gloo; N = 2 above), small batches, so that no N of the sweep is an unexercised path: N ranks
+    counted by the all-reduce, the cfg 2 weak-scaling headline with `roofline`, `cpu_baseline` and its gather legs, the `box`
+    block of rank 0, and the `cfg3` block (Voce, its own points per rank) with the three reassembly schedules at >= 10 steps."""
     if not gpu_available:
         pytest.skip("no GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--points", "200000",
-                        "--cfg3-points", "25000", "--steps", "6", "--warmup", "2", "--cpu-sample", "100000", "--gather-steps", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--share-gpu", "--points", "200000",
+                        "--cfg3-points", "25000", "--steps", "6", "--warmup", "2", "--cpu-sample", "100000", "--gather-steps", "1", "--settle-seconds", "0.1"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["config"]["law"] == "j2_linear" and out["value"] > 0
+    assert out["n_gpus"] == world and out["config"]["law"] == "j2_linear" and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["steps"] == 6 and out["warmup"] == 2 and out["dtype"] == "f64" and out["vs_baseline"] is None
     pg = out["process_group"]
-    assert pg["ranks_in_group"] == 8 and pg["ranks_counted_by_all_reduce"] == 8 and pg["launcher"] == "self"
+    assert pg["ranks_in_group"] == world and pg["ranks_counted_by_all_reduce"] == world and pg["launcher"] == "self"
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["kernel"].startswith("small_strain_kernel<1")
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert abs(rf["achieved"] - 496 * 200000 / (rf["kernel_ms"] * 1e-3) / 1e9) <= 0.01 * rf["achieved"]
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1
+    assert "before" in out["box"] and out["box"]["during_timed_steps"] is not None
+    g2 = out["gather_inclusive"]
+    assert g2["value"] > 0 and g2["p2p_schedule"]["value"] > 0 and g2["coefficient_gather"]["value"] > 0
     c3 = out["cfg3"]
-    assert "error" not in c3 and c3["points_per_gpu"] == 25000 and c3["points_total"] == 200000 and c3["value"] > 0
+    assert "error" not in c3 and c3["points_per_gpu"] == 25000 and c3["points_total"] == 25000 * world and c3["value"] > 0
     assert "Voce" in c3["workload"] and c3["kernel"].startswith("small_strain_kernel<2")
     g = c3["gather_inclusive"]
     assert g["steps"] >= 10 and g["value"] > 0 and g["p2p_schedule"]["value"] > 0 and g["coefficient_gather"]["value"] > 0
-    assert out["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.parametrize("n", [64, 1000, 250_007])
