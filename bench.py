@@ -808,6 +808,7 @@ def main():
     ap.add_argument("--no-tune", action="store_true",
                     help="skip the context leg `roofline.after_placement_search` (the timed region never uses a placement search)")
     ap.add_argument("--settle-seconds", type=float, default=0.5, help="back-to-back launches before the warm-up steps (the box leaves its idle state)")
+    ap.add_argument("--no-stream-probe", action="store_true", help="skip the context leg `roofline.stream_probe` (the kernel interleaved with two arithmetic-free streaming kernels)")
     ap.add_argument("--no-telemetry", action="store_true", help="skip the box block (sysfs / rocm-smi reads around and during the timed steps)")
     ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle (context leg after the timed region)")
     ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
@@ -1129,7 +1130,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
     # (1) the same kernel against two arithmetic-free streaming kernels that move its bytes, interleaved launch by launch on this
     # box now: a linear 104 B-in / 392 B-out pair of streams with non-temporal stores, and the kernel's own 17-stream shape
     stream_probe = None
-    if rank == 0 and copy_probe and not share:
+    if rank == 0 and copy_probe and not share and not args.no_stream_probe:
         try:
             stream_probe = stream_probes(torch, dev, n, stream, lambda: step(1), eps[2], flux, ct)
         except Exception as exc:   # context only

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-other-laws --no-host-path --no-live-traffic"   # bench.py defaults (200 steps, 10 warm-up), minus the context legs
+ARGS="--no-cpu-baseline --no-other-laws --no-host-path --no-live-traffic --no-tune --no-stream-probe --no-telemetry"   # bench.py defaults (200 steps, 10 warm-up), minus the context legs
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/pmc_write.log 2>&1

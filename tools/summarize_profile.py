@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--alg-bytes", type=int, default=496)
     ap.add_argument("--no-traffic-json", action="store_true")
     ap.add_argument("--command-text", default="`bash tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around\n"
-                    "`python3 bench.py --no-cpu-baseline --no-other-laws --no-host-path --no-live-traffic` (the default bench command: 200 steps, 10 warm-up, without its context legs).")
+                    "`python3 bench.py --no-cpu-baseline --no-other-laws --no-host-path --no-live-traffic --no-tune --no-stream-probe --no-telemetry` (the default bench command: 200 steps, 10 warm-up, every array where its first allocation put it, without the context legs).")
     ap.add_argument("--steps", type=int, default=200, help="timed steps of the bench command = the LAST dispatches of the kernel")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.prefix) or ".", exist_ok=True)
@@ -132,7 +132,7 @@ def main():
                     f"**{out['achieved_GBs_from_rocprof_avg']:.0f} GB/s** = {out['achieved_GBs_from_rocprof_avg']/8000:.3f} of the 8 TB/s HBM3E peak.\n")
         if timed:
             f.write(f"\nTimed region = the last {timed['dispatches']} of the {timed['of']} dispatches of this kernel in the trace (the earlier ones "
-                    f"are setup: load-step contexts, placement tuning including its rejected slow candidates, warm-up): average "
+                    f"are setup: load-step contexts, ~0.5 s of settling launches, warm-up): average "
                     f"**{timed['avg_ns']/1e3:.1f} us** (min {timed['min_ns']/1e3:.1f}, max {timed['max_ns']/1e3:.1f}) = **{alg/timed['avg_ns']:.0f} GB/s** = "
                     f"{alg/timed['avg_ns']/8000:.3f} of peak; this is the figure `roofline.achieved` of the bench line corresponds to.\n")
         f.write("\n## PMC (mean per launch)\n\n| counter | value |\n|---|---|\n")
