@@ -886,6 +886,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if telemetry is not None:   # the card of THIS rank's HIP device (several usable render nodes on a multi-GPU node)
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            telemetry.DEFAULT_PCI = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            if box_before and box_before.get("pci") and box_before["pci"].lower() != telemetry.DEFAULT_PCI:
+                box_before = dict(telemetry.condensed(telemetry.snapshot(tools=False)), taken_after_gpu_init=True)
+        except Exception:
+            pass
     c = argparse.Namespace(torch=torch, dist=dist, jm=jm, JAXMaterial=JAXMaterial, ShardPlan=ShardPlan, allgather_rows=allgather_rows,
                            allgather_rows_p2p=allgather_rows_p2p, allgather_tangent=allgather_tangent, rank=rank, world=world, dev=dev,
                            dev_index=dev_index, share=share, grouped=grouped, args=args, telemetry=telemetry)

@@ -39,6 +39,8 @@ constexpr int F2_REC = 73;   // record stride: 54 staged doubles per point, padd
 // kernel's streams, occupancy and compute gaps runs 1.63 ms per 1e7 points with 16-point rounds against 1.77 with 14
 // (tools/fefp_shape_probe.py, profiles/r03_fefp_shape_probe.md).  The price is a third, mostly idle, step per round
 // (7 + 7 + 2 point slots): 12 instead of 10 tangent steps per tile.
+// (A/B knobs of the residency study, profiles/r04_fefp_third_wave_and_subwave.md: 8-point rounds cost 9 %, a 168-register budget
+// spills 78 VGPRs and costs 80 %; the defaults are what ships)
 #ifndef DXM_FEFP_PPR
 #define DXM_FEFP_PPR 16
 #endif

@@ -61,11 +61,16 @@ def _render_minor(dev):
     return int(re.sub(r"\D", "", os.path.basename(r[0]))) if r else None
 
 
+#: PCI bus id of the GPU this process computes on, once known (e.g. from the HIP runtime): overrides the render-node heuristic
+DEFAULT_PCI = None
+
+
 def my_card(pci=None):
     """The sysfs device directory of the GPU THIS process can use.  A box of this pool exposes the sysfs of every GPU of the
     node but the device nodes of one: the card whose /dev/dri/renderD<minor> is openable is ours.  `pci` (e.g. the bus id the
     HIP runtime reports, "0000:0d:00.0") overrides; with several usable cards the first is returned."""
     devs = cards()
+    pci = pci or DEFAULT_PCI
     if pci:
         want = pci.lower()
         for d in devs:
