@@ -98,15 +98,25 @@ class LazyISV(np.lib.mixins.NDArrayOperatorsMixin):
     def _download(self):
         return self._m._fetch_isv()
 
+    _frozen = False
+
     def _get(self):
+        if self._frozen:
+            return self._value
         if self._seen != self._serial():
             self._value = self._download()
             self._seen = self._serial()
         return self._value
 
+    def _freeze(self):
+        """Stop following the material: keep showing the state this view stands for now (downloads it if nobody has looked yet)."""
+        if not self._frozen:
+            self._value = self._get()
+            self._frozen = True
+
     @property
     def fetched(self):
-        return self._seen == self._serial()
+        return self._frozen or self._seen == self._serial()
 
     def __array__(self, dtype=None, copy=None):
         a = self._get()
@@ -139,7 +149,10 @@ class LazyInitialRows(LazyISV):
     ``generic.py:194-198`` -- kept on the device by ``dxm_advance`` (option ``keep_initial_io``) and downloaded when
     first looked at.  Used when the host array that held the accepted state is a bound Function that the next update
     overwrites: accepting an increment then costs a pointer swap instead of a 480 MB host copy per array (1e7 points).
-    A view like :class:`LazyISV`: after a later ``advance`` it shows the then-current s0."""
+    It stands for ONE initial state: when that state is replaced (``advance`` with a new state, ``set_initial_state_dict``) a view
+    that somebody still holds or has looked at keeps its content (it is downloaded at that moment if need be), like the arrays the
+    reference hands out, which ``DataManager.update`` rebinds rather than overwrites (``generic.py:212-213``); a view nobody
+    holds is simply dropped."""
 
     _which = 0
 
@@ -503,9 +516,11 @@ class HIPMaterial:
             dim = self.variables[key]
             a = _as_c(value, (self._n, max(1, dim)))
             if key == self._gname:
+                self._retire_initial_views((0,))
                 self._grad[0] = a.copy()
                 self._serial0 += 1
             elif key == self._fname:
+                self._retire_initial_views((1,))
                 self._flux[0] = a.copy()
                 self._serial0 += 1
             elif key == "be_bar" and self._info.n_grad == 9:
@@ -526,8 +541,21 @@ class HIPMaterial:
             if hi > lo:
                 self._chk(self._lib.dxm_set_state(h, S0, field, ptrs[0]))
 
+    def _retire_initial_views(self, replaced):
+        """s0 is about to be replaced in the fields named by `replaced` (0 gradient, 1 flux): lazy views of the OLD s0 that are
+        held outside the material (or were looked at) keep what they show."""
+        import sys
+
+        for kind in replaced:
+            v = (self._grad, self._flux)[kind][0]
+            # references of an unheld view: the mirror list, `v`, the argument of getrefcount
+            if type(v) is LazyInitialRows and not v._frozen and (v._seen == v._serial() or sys.getrefcount(v) > 3):
+                v._freeze()
+
     def _advance(self):
         self._handles()
+        if self._serial != self.__dict__.get("_serial_of_s0"):   # an update came since the last advance / revert: s0 is replaced
+            self._retire_initial_views((0, 1))
         held = 3
         for h, lo, hi, _dev in self._parts:
             self._chk(self._lib.dxm_advance(h))
@@ -554,6 +582,7 @@ class HIPMaterial:
                 new.append(self._snapshot(cur))
         self._grad[0], self._flux[0] = new
         self._serial0 += 1
+        self._serial_of_s0 = self._serial
         for a in old:   # the mirrors of the increment before: freed off this thread
             if isinstance(a, np.ndarray) and a is not self._grad[0] and a is not self._flux[0] and not any(a is b for b in self._flux_buf):
                 _reaper.drop(a)
@@ -584,6 +613,7 @@ class HIPMaterial:
         self._grad[1] = self._grad[0]
         self._flux[1] = self._flux[0]
         self._serial += 1   # s1 changed: lazy ISV views refetch
+        self._serial_of_s0 = self._serial
 
     # ---- protocol: the hot path -----------------------------------------------------------------
     def integrate(self, gradients, dt=0):

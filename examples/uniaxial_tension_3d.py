@@ -4,7 +4,8 @@ driver ``tests/uniaxial_tension.py:11-118`` (BASELINE.json configs[4]) with the 
 loop of ``examples/hex_fem.py`` (dolfinx is not available) and the GPU constitutive update.
 
     python examples/uniaxial_tension_3d.py [--n 16] [--steps 10] [--law j2_linear|fefp] [--layout full|sym|coef]
-    python examples/uniaxial_tension_3d.py --n 64 --steps 3 --layout coef --device-gradient     # the config-5 stand-in
+    python examples/uniaxial_tension_3d.py --n 64 --steps 8 --layout coef --device-gradient     # the config-5 stand-in (8 load steps: the
+                                                                                                  # bare Newton of hex_fem.py has no line search for bigger jumps)
 
 Symmetry planes x=0, y=0, z=0 are clamped in their normal direction and u_x is imposed on x=1, so
 the solution is the homogeneous uniaxial stress state sigma_xx = R(p): a known answer the run

@@ -148,6 +148,34 @@ def test_bench_starts_its_own_ranks(gpu_available):
     assert out["value"] > out["gather_inclusive"]["value"]
 
 
+def test_bench_under_the_drivers_launcher(gpu_available):
+    """The driver's N > 1 command verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks sharing GPU 0 (DXM_BENCH_SHARE_GPU=1: gloo): RANK /
+    LOCAL_RANK / WORLD_SIZE come from the launcher, rank 0 prints the one line."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(DXM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--points", "200000", "--cfg3-points", "20000", "--cpu-sample", "100000", "--gather-steps", "1", "--settle-seconds", "0.1"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["value"] > 0
+    pg = out["process_group"]
+    assert pg["ranks_counted_by_all_reduce"] == 2 and pg["launcher"] == "torch.distributed.run" and pg["share_gpu_debug_mode"]
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0 and "error" not in out["cfg3"]
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_bench_line_of_the_drivers_scaling_sweep_on_one_gpu(gpu_available, world):
     """What the driver's 1 -> 8 sweep runs is `python bench.py --gpus N`: here the same command for N = 4 and 8 in the debug

@@ -20,26 +20,28 @@ pytestmark = pytest.mark.gpu
 EPS = np.finfo(float).eps
 
 
-def _strains(n, lo, hi, seed):
-    """Directions with a hydrostatic part, amplitudes lo ... hi yield strains (log-uniform)."""
+def _strains(n, lo, hi, seed, hydro=2.0):
+    """Deviatoric directions with amplitudes lo ... hi yield strains (log-uniform) plus a hydrostatic part of up to `hydro` times that."""
     rng = np.random.default_rng(seed)
     d = rng.standard_normal((n, 6))
-    d[:, :3] += rng.uniform(-2.0, 2.0, (n, 1))          # tr(eps) of the order of the deviator and larger
+    d[:, :3] -= d[:, :3].mean(axis=1, keepdims=True)
     d /= np.linalg.norm(d, axis=1)[:, None]
     s = np.exp(rng.uniform(np.log(lo), np.log(hi), n)) * eps_yield(250.0)
-    return d * s[:, None]
+    eps = d * s[:, None]
+    eps[:, :3] += (s * rng.uniform(-hydro, hydro, n))[:, None]
+    return eps
 
 
 @pytest.mark.parametrize("hardening", ["linear_H1e-6", "voce_saturated"])
-@pytest.mark.parametrize("n", [64, 20_011])
-def test_flow_direction_from_the_stress_at_vanishing_rho(hardening, n):
+@pytest.mark.parametrize("n,hydro", [(64, 2.0), (20_011, 2.0), (5_003, 300.0)])
+def test_flow_direction_from_the_stress_at_vanishing_rho(hardening, n, hydro):
     el = jm.LinearElasticIsotropic(E=E, nu=NU)
     if hardening == "linear_H1e-6":
         hd, ho = jm.LinearHardening(250.0, 1e-6), onp.LinearHardening(250.0, 1e-6)
     else:   # saturates at sigu within p ~ 1e-2: perfect plasticity for everything larger
         hd, ho = jm.VoceHardening(250.0, 251.0, 1e3), onp.VoceHardening(250.0, 251.0, 1e3)
     beh = jm.vonMisesIsotropicHardening(el, hd)
-    eps = _strains(n, 1e2, 1e4, seed=77)
+    eps = _strains(n, 1e2, 1e4, seed=77, hydro=hydro)   # hydro = 300: |sigma_ii| / q up to ~1e6 (ADVICE r03: "|p| / q ~ 1e6")
     ref = onp.j2_update(eps, np.zeros((n, 6)), np.zeros(n), E, NU, ho)
     assert ref["plastic"].all()
     lam, mu = onp.lame(E, NU)
@@ -50,13 +52,13 @@ def test_flow_direction_from_the_stress_at_vanishing_rho(hardening, n):
     q = np.sqrt(1.5) * np.linalg.norm(dev, axis=1)
     seq_trial = ref["f_trial"] + ho.R(np.zeros(n))
     rho = q / seq_trial
-    assert rho.max() < 0.2 and np.median(rho) < 5e-3 and rho.min() < 2e-4   # R / seq: down to 1e-4
+    assert rho.max() < 1.1e-2 and rho.min() < 2e-4               # R / seq: 1e-2 down to 1e-4
     # what n = dev(sigma) w costs against n = 3 s_e / (2 seq): dev(sigma) is a difference of numbers of size |sigma_ii|, so
     # n carries a relative error of a few eps |sigma_ii| / |dev sigma|; the tangent entry c3 n_i n_j twice that, c3 <= 2 mu
     cond = (np.abs(sig[:, :3]).max(axis=1) / (np.sqrt(2.0 / 3.0) * q))
     ct_scale = np.abs(ref["Ct"]).max()
     tol = (1e-12 + 16.0 * EPS * cond)[:, None, None] * ct_scale
-    assert cond.max() > 1e3                                       # the case is what it claims to be
+    assert cond.max() > (1e6 if hydro > 2.0 else 1e4)              # the case is what it claims to be
 
     got = {}
     for layout in ("full", "sym", "coef", "pack4"):
