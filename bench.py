@@ -1088,8 +1088,11 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
     sampler = fw_before = None
     tel = c.telemetry if rank == 0 else None
     if tel is not None:
-        fw_before = tel.metrics()
-        sampler = tel.Sampler(period_s=0.005)
+        try:   # context only: a telemetry failure must never cost the line
+            fw_before = tel.metrics()
+            sampler = tel.Sampler(period_s=0.005)
+        except Exception as exc:
+            fw_before, sampler = {"error": repr(exc)}, None
     # the box leaves its idle state: back-to-back launches for --settle-seconds, no host work in between (telemetry of the boxes
     # in profiles/r04_box_survey.jsonl: clocks do not move under this load and no launch but the very first after an idle gap
     # is slow -- the settling costs nothing and takes the question off the table)
@@ -1109,11 +1112,17 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         plastic_frac.append(st["n_plastic"] / n)
 
     # ---- the timed region: EXACTLY K steps between barrier + synchronize, every array where its first allocation put it -------
-    box_before = tel.fast_read(tel.my_card()) if (tel is not None and tel.my_card()) else None   # a few file reads
+    try:
+        box_before = tel.fast_read(tel.my_card()) if (tel is not None and tel.my_card()) else None   # a few file reads
+    except Exception:
+        box_before = None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     barrier()
     if sampler is not None:
-        sampler.start()
+        try:
+            sampler.start()
+        except Exception:
+            sampler = None
     t0 = time.perf_counter()
     for i in range(K):
         ev[i][0].record()
@@ -1122,17 +1131,25 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
     barrier()
     t1 = time.perf_counter()
     if sampler is not None:
-        sampler.stop()
+        try:
+            sampler.stop()
+        except Exception:
+            pass
     elapsed = t1 - t0
     per_launch = [a.elapsed_time(b) for a, b in ev]
     kern_ms = float(np.mean(per_launch))
     box_during = None
-    if sampler is not None:
-        fw_after = tel.metrics()
-        box_during = {"sysfs_samples": sampler.summary(), "firmware_counters": tel.metrics_delta(fw_before, fw_after), "clocks_at_start": box_before,
-                      "kernel_ms_min_median_max": [round(float(np.min(per_launch)), 4), round(float(np.median(per_launch)), 4), round(float(np.max(per_launch)), 4)],
-                      "note": "sysfs_samples: min / median / max of a 5 ms sampler thread across the K timed steps (20 steps are ~20 ms: a handful of samples); "
-                              "firmware_counters: gpu_metrics accumulators read before the settling launches and after the timed steps (settling + warm-up + timed steps + ~0.3 s of tool time)"}
+    if tel is not None:
+        try:
+            fw_after = tel.metrics()
+            box_during = {"sysfs_samples": sampler.summary() if sampler is not None else None, "firmware_counters": tel.metrics_delta(fw_before, fw_after),
+                          "clocks_at_start": box_before,
+                          "kernel_ms_min_median_max": [round(float(np.min(per_launch)), 4), round(float(np.median(per_launch)), 4), round(float(np.max(per_launch)), 4)],
+                          "note": "sysfs_samples: min / median / max of a 5 ms sampler thread across the K timed steps (20 steps are ~20 ms: a handful of samples); "
+                                  "firmware_counters: gpu_metrics accumulators read before the settling launches and after the timed steps (settling + warm-up + "
+                                  "timed steps + ~0.3 s of tool time)"}
+        except Exception as exc:   # context only
+            box_during = {"error": repr(exc)}
 
     # ---- context, after the timed region -----------------------------------------------------------------------------------
     # (1) the same kernel against two arithmetic-free streaming kernels that move its bytes, interleaved launch by launch on this

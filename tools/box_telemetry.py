@@ -23,6 +23,10 @@ import threading
 import time
 
 DRM = "/sys/class/drm"
+KFD = "/sys/class/kfd/kfd"
+DEV_DRI = "/dev/dri"
+ROCM_SMI = "/opt/rocm/bin/rocm-smi"
+AMD_SMI = "/opt/rocm/bin/amd-smi"
 
 
 def _read(path, limit=4096):
@@ -79,7 +83,7 @@ def my_card(pci=None):
     usable = []
     for d in devs:
         m = _render_minor(d)
-        if m is not None and os.access(f"/dev/dri/renderD{m}", os.R_OK | os.W_OK):
+        if m is not None and os.access(os.path.join(DEV_DRI, f"renderD{m}"), os.R_OK | os.W_OK):
             usable.append(d)
     if usable:
         return usable[0]
@@ -164,7 +168,7 @@ def snapshot(pci=None, tools=True, raw=False):
         return rec
     dev = my_card(pci)
     hw = _hwmon(dev)
-    rec["render_node_usable"] = bool(_render_minor(dev) is not None and os.access(f"/dev/dri/renderD{_render_minor(dev)}", os.R_OK | os.W_OK))
+    rec["render_node_usable"] = bool(_render_minor(dev) is not None and os.access(os.path.join(DEV_DRI, f"renderD{_render_minor(dev)}"), os.R_OK | os.W_OK))
     # the node's population: every GPU whose sysfs is visible, busy or not (other tenants' GPUs of a shared node)
     rec["node_gpus"] = [{"pci": os.path.basename(os.path.realpath(d)), "unique_id": _read(os.path.join(d, "unique_id")),
                          "gpu_busy": _num(_read(os.path.join(d, "gpu_busy_percent"))), "mem_busy": _num(_read(os.path.join(d, "mem_busy_percent"))),
@@ -213,7 +217,7 @@ def snapshot(pci=None, tools=True, raw=False):
     # KFD view: CU count, max engine clock, who else holds VRAM
     kfd = {}
     my_minor = _render_minor(dev)
-    for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*")):
+    for node in sorted(glob.glob(os.path.join(KFD, "topology", "nodes", "*"))):
         props = _read(os.path.join(node, "properties"), 8192)
         if not props or "simd_count 0" in props:
             continue
@@ -224,7 +228,7 @@ def snapshot(pci=None, tools=True, raw=False):
         kfd.setdefault("nodes", []).append({k: _num(p.get(k)) for k in ("simd_count", "cu_count", "array_count", "num_xcc", "max_engine_clk_fcompute",
                                                                           "local_mem_size", "gfx_target_version", "drm_render_minor", "num_sdma_engines",
                                                                           "num_sdma_xgmi_engines", "simd_per_cu", "max_waves_per_simd")})
-    procs = glob.glob("/sys/class/kfd/kfd/proc/[0-9]*")
+    procs = glob.glob(os.path.join(KFD, "proc", "[0-9]*"))
     kfd["processes_visible"] = len(procs)
     vram_by_proc = []
     for p in procs:
@@ -242,7 +246,7 @@ def snapshot(pci=None, tools=True, raw=False):
 
 
 def _rocm_smi(raw=False):
-    exe = "/opt/rocm/bin/rocm-smi"
+    exe = ROCM_SMI
     if not os.path.exists(exe):
         return {"error": "rocm-smi not found"}
     j = _json_tool([exe, "--showclocks", "--showpower", "--showmaxpower", "--showmemuse", "--showmeminfo", "vram", "--showcomputepartition",
@@ -252,7 +256,7 @@ def _rocm_smi(raw=False):
 
 
 def _amd_smi(raw=False):
-    exe = "/opt/rocm/bin/amd-smi"
+    exe = AMD_SMI
     if not os.path.exists(exe):
         return {"error": "amd-smi not found"}
     out = {}
@@ -272,7 +276,7 @@ METRIC_KEYS = ("accumulation_counter", "ppt_residency_acc", "prochot_residency_a
 def metrics():
     """The firmware's `gpu_metrics` table through `rocm-smi --showmetrics --json` (a child process; ~0.3 s): accumulated
     throttle residencies (power, thermal, HBM thermal), activity and energy accumulators, uclk.  Keys without the unit suffix."""
-    exe = "/opt/rocm/bin/rocm-smi"
+    exe = ROCM_SMI
     if not os.path.exists(exe):
         return {"error": "rocm-smi not found"}
     j = _json_tool([exe, "--showmetrics", "--json"], timeout=20)
