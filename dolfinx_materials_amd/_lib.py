@@ -133,7 +133,6 @@ EXPERIMENTAL_SYMBOLS = {
     "dxm_tune_placement": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dxm_time_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
-    "dxm_place_state": (C.c_int, [_h, C.c_int, C.c_uint64, C.c_uint64]),
     "dxm_mesh_set_weights": (C.c_int, [_h, C.c_void_p]),
     "dxm_mesh_internal_force_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dxm_mesh_tangent_apply_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -139,9 +139,6 @@ struct dxm_material {
   double rtol = 1e-14;
   double* state[2] = {nullptr, nullptr};  // [n_slots][ld] each
   double* state_base = nullptr;           // one allocation holds s0 and s1
-  // state built from individually created physical chunks (hipMemCreate / hipMemMap): dxm_place_state
-  std::vector<hipMemGenericAllocationHandle_t> vmm_chunks;
-  size_t vmm_chunk_bytes = 0, vmm_total = 0;
   size_t s1_skew = 0;
   bool s1_alias = false;  // after advance()/revert() s1 == s0 until the next integrate: no copy is made
   BlockStats* d_stats = nullptr;
@@ -205,14 +202,7 @@ static int sync_last(dxm_material* m);
 
 static void free_state(dxm_material* m) {
   if (!m->state_base) return;
-  if (!m->vmm_chunks.empty()) {
-    (void)hipMemUnmap(reinterpret_cast<hipDeviceptr_t>(m->state_base), m->vmm_total);
-    for (auto h : m->vmm_chunks) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(reinterpret_cast<hipDeviceptr_t>(m->state_base), m->vmm_total);
-    m->vmm_chunks.clear();
-  } else {
-    (void)hipFree(m->state_base);
-  }
+  (void)hipFree(m->state_base);
   m->state_base = nullptr;
 }
 
@@ -927,7 +917,6 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
   if (n_tried) *n_tried = 0;
   const LawDesc& d = kLaws[m->law];
   if (m->n == 0 || d.n_slots == 0 || max_candidates <= 0) return 0;   // nothing resident to place
-  if (!m->vmm_chunks.empty()) return 0;                                 // placed by dxm_place_state: leave it
   if (!grad_dev || !flux_dev || !ct_dev) return fail(-1, "null device pointer");
   DEVICE_GUARD(m);
   if (int rc = sync_last(m)) return rc;
@@ -1795,81 +1784,6 @@ const double* dxm_state_ptr(const dxm_material* m, int which, int field, int com
 }
 
 const char* dxm_kernel_name(const dxm_material* m) { return m ? kLaws[m->law].kernel : ""; }
-
-// Rebuild the resident state in memory assembled from separately created physical chunks that are mapped
-// into one virtual range in a permuted order (HIP virtual memory management), so that the seven read and
-// seven written state streams of the J2 kernel do not keep one fixed physical relation to the caller's
-// arrays for the whole launch.  mode 0: plain hipMalloc (fresh block); 1: chunks mapped in creation order;
-// 2: chunks mapped in a pseudo-random order (seed).  Copies s0 (and s1) over; the old block is freed.
-int dxm_place_state(dxm_material* m, int mode, uint64_t chunk_bytes, uint64_t seed) {
-  if (!m) return fail(-1, "null handle");
-  const LawDesc& d = kLaws[m->law];
-  if (d.n_slots == 0 || m->n == 0) return 0;
-  if (mode < 0 || mode > 2) return fail(-1, "unknown placement mode %d", mode);
-  DEVICE_GUARD(m);
-  if (int rc = sync_last(m)) return rc;
-  const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
-  const size_t need = 2 * bytes + m->s1_skew;
-  double* nb = nullptr;
-  std::vector<hipMemGenericAllocationHandle_t> chunks;
-  size_t chunk = 0, total = 0;
-  if (mode == 0) {
-    HIP_TRY(hipMalloc(&nb, need));
-  } else {
-    hipMemAllocationProp prop{};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = m->device;
-    size_t gran = 0;
-    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
-    if (gran == 0) gran = 4096;
-    chunk = ((std::max<size_t>(chunk_bytes, gran) + gran - 1) / gran) * gran;
-    const size_t nch = (need + chunk - 1) / chunk;
-    total = nch * chunk;
-    hipDeviceptr_t va = nullptr;
-    HIP_TRY(hipMemAddressReserve(&va, total, 0, nullptr, 0));
-    auto undo = [&]() {
-      for (auto h : chunks) (void)hipMemRelease(h);
-      (void)hipMemAddressFree(va, total);
-    };
-    for (size_t i = 0; i < nch; ++i) {
-      hipMemGenericAllocationHandle_t h;
-      hipError_t e = hipMemCreate(&h, chunk, &prop, 0);
-      if (e != hipSuccess) { undo(); return fail(-3, "hipMemCreate of chunk %zu failed: %s", i, hipGetErrorString(e)); }
-      chunks.push_back(h);
-    }
-    std::vector<size_t> order(nch);
-    for (size_t i = 0; i < nch; ++i) order[i] = i;
-    if (mode == 2) {   // Fisher-Yates with a splitmix64 stream
-      uint64_t x = seed + 0x9e3779b97f4a7c15ull;
-      auto next = [&x]() { uint64_t z = (x += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
-      for (size_t i = nch - 1; i > 0; --i) std::swap(order[i], order[next() % (i + 1)]);
-    }
-    for (size_t i = 0; i < nch; ++i) {
-      hipError_t e = hipMemMap(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<char*>(va) + i * chunk), chunk, 0, chunks[order[i]], 0);
-      if (e != hipSuccess) { (void)hipMemUnmap(va, i * chunk); undo(); return fail(-3, "hipMemMap failed: %s", hipGetErrorString(e)); }
-    }
-    hipMemAccessDesc acc{};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    hipError_t e = hipMemSetAccess(va, total, &acc, 1);
-    if (e != hipSuccess) { (void)hipMemUnmap(va, total); undo(); return fail(-3, "hipMemSetAccess failed: %s", hipGetErrorString(e)); }
-    nb = reinterpret_cast<double*>(va);
-  }
-  double* ns0 = nb;
-  double* ns1 = reinterpret_cast<double*>(reinterpret_cast<char*>(nb) + bytes + m->s1_skew);
-  HIP_TRY(hipMemcpy(ns0, m->state[0], bytes, hipMemcpyDeviceToDevice));
-  HIP_TRY(hipMemcpy(ns1, m->state[1], bytes, hipMemcpyDeviceToDevice));
-  free_state(m);
-  m->state_base = nb;
-  m->state[0] = ns0;
-  m->state[1] = ns1;
-  m->vmm_chunks = chunks;
-  m->vmm_chunk_bytes = chunk;
-  m->vmm_total = total;
-  ++m->epoch;
-  return 0;
-}
 
 int dxm_expand_tangent_device(const double* coef_dev, int64_t npoints, double* ct_dev, int device, void* hip_stream) {
   if (npoints < 0) return fail(-1, "negative point count");

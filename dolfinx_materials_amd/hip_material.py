@@ -1026,11 +1026,6 @@ class HIPMaterial:
             elif k == "tangent":
                 self._out_ct = None
 
-    def place_state(self, mode, chunk_bytes=2 << 20, seed=0):
-        """``dxm_place_state``: rebuild the resident state in a fresh block (0) or from physical chunks mapped in
-        order (1) / in a permuted order (2)."""
-        self._chk(self._lib.dxm_place_state(self._require(), int(mode), int(chunk_bytes), int(seed)))
-
     def isv_device(self, which, isv_ptr, stream=0):
         self._chk(self._lib.dxm_isv_device(self._require(), which, int(isv_ptr), int(stream) or None))
 

@@ -27,9 +27,6 @@ int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev
 /* `launches` updates with these device arrays on the handle's own stream (synchronous, two warm-up launches first): best launch
  * time in ms.  Acts like dxm_integrate_device otherwise. */
 int dxm_time_device(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev, int launches, double* best_ms);
-/* Rebuild the resident state (contents preserved) in mode 0 a fresh hipMalloc block, 1 physical chunks of chunk_bytes mapped in
- * creation order, 2 the same chunks in a pseudo-random order (hipMemCreate / hipMemMap).  A documented negative. */
-int dxm_place_state(dxm_material* m, int mode, uint64_t chunk_bytes, uint64_t seed);
 
 /* ---- assembly-side consumers on the device (hex8 meshes with 8 Gauss points per cell, small strain) --------------------------
  * What dolfinx assembly does with the quadrature Functions QuadratureMap.update filled -- `dot(sig, strain(v)) * dx` and its
