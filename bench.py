@@ -584,11 +584,13 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, blocks_per_cu=0):
     return out
 
 
-def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30):
+def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30, state=None):
     """The headline kernel interleaved, launch by launch, with two arithmetic-free kernels of tools/libstreammix.so that move
     its 496 B/point: `linear` = two perfectly linear 16 B-per-lane streams (104 B read, 392 B written with non-temporal
     stores), `j2_shape` = the kernel's own stream structure (strain AoS + 7 SoA slots in; stress AoS + 7 SoA slots + tangent
-    out), reading the bench's strain array and writing its flux / tangent arrays.  Medians over `reps` rounds after 5 untimed
+    out), reading the bench's strain array and the handle's own resident state (`state` = device addresses of s0, s1 and
+    their leading dimension: the SAME memory the kernel reads and writes, so that placement is common to both) and writing the
+    bench's flux / tangent arrays and s1.  Medians over `reps` rounds after 5 untimed
     ones.  Measurement infrastructure (never on the product path); what the box gives a streaming kernel of this mix NOW."""
     import ctypes as C
 
@@ -599,13 +601,18 @@ def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30):
     rb, wb, nblk = 104, 392, 2048
     rbuf = torch.randn(n64 * rb // 8, dtype=torch.float64, device=dev)
     wbuf = torch.empty(n64 * wb // 8, dtype=torch.float64, device=dev)
-    ld = n64 + 32
-    sa = torch.randn(7 * ld, dtype=torch.float64, device=dev)
-    sb = torch.empty(7 * ld, dtype=torch.float64, device=dev)
+    if state is not None:
+        s0_ptr, s1_ptr, ld = state
+        sa = sb = None
+    else:
+        ld = n64 + 32
+        sa = torch.randn(7 * ld, dtype=torch.float64, device=dev)
+        sb = torch.empty(7 * ld, dtype=torch.float64, device=dev)
+        s0_ptr, s1_ptr = sa.data_ptr(), sb.data_ptr()
     legs = {
         "kernel": kernel_launch,
         "linear": lambda: lib.stream_mix_nt_launch(rbuf.data_ptr(), wbuf.data_ptr(), n64, rb, wb, nblk, stream or None),
-        "j2_shape": lambda: lib.stream_mix_j2_shape_launch(eps.data_ptr(), sa.data_ptr(), sb.data_ptr(), ld, flux.data_ptr(), ct.data_ptr(), n64, nblk, stream or None),
+        "j2_shape": lambda: lib.stream_mix_j2_shape_launch(eps.data_ptr(), s0_ptr, s1_ptr, ld, flux.data_ptr(), ct.data_ptr(), n64, nblk, stream or None),
     }
     times = {k: [] for k in legs}
     for r in range(reps + 5):
@@ -623,8 +630,8 @@ def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30):
     out = {"kernel_ms": round(med["kernel"], 4), "linear_probe_ms": round(med["linear"], 4), "j2_shape_probe_ms": round(med["j2_shape"], 4),
            "linear_probe_GBs": round(496 * n64 / med["linear"] / 1e6, 1), "j2_shape_probe_GBs": round(496 * n64 / med["j2_shape"] / 1e6, 1),
            "kernel_over_linear_probe": round(med["linear"] / med["kernel"], 4), "kernel_over_j2_shape_probe": round(med["j2_shape"] / med["kernel"], 4),
-           "rounds": reps,
-           "note": "tools/stream_mix.hip: no arithmetic, the kernel's bytes; interleaved with the kernel in one process (each launch waited for), so all three "
+           "rounds": reps, "j2_shape_probe_on_the_kernels_own_arrays": state is not None,
+           "note": "tools/stream_mix.hip: no arithmetic, the kernel's bytes; the 17-stream probe reads and writes the kernel's own arrays (strain, resident state, flux, tangent): same placement; interleaved with the kernel in one process (each launch waited for), so all three "
                    "see the same box at the same time; > 1 means the kernel is faster than the probe"}
     del rbuf, wbuf, sa, sb
     torch.cuda.empty_cache()
@@ -1157,7 +1164,12 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
     stream_probe = None
     if rank == 0 and copy_probe and not share and not args.no_stream_probe:
         try:
-            stream_probe = stream_probes(torch, dev, n, stream, lambda: step(1), eps[2], flux, ct)
+            hm = mats[1]   # (step(1): the handle of increment 3, strain eps[2])
+            p0 = hm._lib.dxm_state_ptr(hm._handle, 0, 0, 0)
+            p1 = hm._lib.dxm_state_ptr(hm._handle, 1, 0, 0)
+            ld_b = (hm._lib.dxm_state_ptr(hm._handle, 0, 1, 0) or 0) - (p0 or 0)     # field 1 (epsp) starts one slot after field 0 (p)
+            own = (p0, p1, ld_b // 8) if (p0 and p1 and p0 != p1 and ld_b > 0 and ld_b % 8 == 0 and ld_b // 8 >= n) else None
+            stream_probe = stream_probes(torch, dev, n, stream, lambda: step(1), eps[2], flux, ct, state=own)
         except Exception as exc:   # context only
             stream_probe = {"error": repr(exc)}
 
