@@ -132,7 +132,7 @@ def main():
                     f"**{out['achieved_GBs_from_rocprof_avg']:.0f} GB/s** = {out['achieved_GBs_from_rocprof_avg']/8000:.3f} of the 8 TB/s HBM3E peak.\n")
         if timed:
             f.write(f"\nTimed region = the last {timed['dispatches']} of the {timed['of']} dispatches of this kernel in the trace (the earlier ones "
-                    f"are setup: load-step contexts, ~0.5 s of settling launches, warm-up): average "
+                    f"are set-up, settling and warm-up launches of the same kernel): average "
                     f"**{timed['avg_ns']/1e3:.1f} us** (min {timed['min_ns']/1e3:.1f}, max {timed['max_ns']/1e3:.1f}) = **{alg/timed['avg_ns']:.0f} GB/s** = "
                     f"{alg/timed['avg_ns']/8000:.3f} of peak; this is the figure `roofline.achieved` of the bench line corresponds to.\n")
         f.write("\n## PMC (mean per launch)\n\n| counter | value |\n|---|---|\n")
