@@ -35,12 +35,15 @@ def _fields(q):
             "epsp": q.internal_state_variables["epsp"].x.array}
 
 
+@pytest.mark.parametrize("isv_mode", [True, "lazy"])
 @pytest.mark.parametrize("case", ["full", "subset"])
-def test_field_map_reproduces_what_the_reference_class_left_in_its_functions(case):
+def test_field_map_reproduces_what_the_reference_class_left_in_its_functions(case, isv_mode):
     cells = GOLD["subset"] if case == "subset" else None
     now = {"k": 0}
     q = QuadratureFieldMap(NCELL, NQP, _material(), cells=cells)
-    q.isv_every_update = True   # the reference writes the internal state variables in every update (quadrature_map.py:332)
+    # True: the reference writes the internal state variables in every update (quadrature_map.py:332); "lazy" (the default): they are
+    # refreshed when `_fields` below looks at `q.internal_state_variables[...]` -- the same content either way
+    q.isv_every_update = isv_mode
     q.register_gradient("strain", lambda c: GOLD["strains"][now["k"]].reshape(NCELL, NQP * 6)[c])
     for i, (op, k) in enumerate(zip(GOLD["ops"], GOLD["strain_of_op"])):
         if op == "update":
@@ -53,8 +56,9 @@ def test_field_map_reproduces_what_the_reference_class_left_in_its_functions(cas
 
 
 @pytest.mark.skipif(not reference_available(), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("isv_mode", [True, "lazy"])
 @pytest.mark.parametrize("case,engine_like", [("full", False), ("subset", False), ("full", True), ("subset", True), ("subset", "rows"), ("full", "rows")])
-def test_accelerated_class_over_the_real_reference_class_equals_the_real_class(case, engine_like):
+def test_accelerated_class_over_the_real_reference_class_equals_the_real_class(case, engine_like, isv_mode):
     from oracle import dolfinx_doubles as dd
     from test_quadrature_map import EngineLikeMaterial, RowDeliveringMaterial
 
@@ -74,7 +78,7 @@ def test_accelerated_class_over_the_real_reference_class_equals_the_real_class(c
             q.register_gradient("strain", dd.PointwiseExpression(lambda c: GOLD["strains"][now["k"]].reshape(NCELL, NQP * 6)[c], 6))
             maps.append(q)
         ref, acc = maps
-        acc.isv_every_update = True
+        acc.isv_every_update = isv_mode   # "lazy": the reference's own `variables` / dict accesses trigger the refresh
         for i, (op, k) in enumerate(zip(GOLD["ops"], GOLD["strain_of_op"])):
             for q in maps:
                 if op == "update":
