@@ -609,8 +609,12 @@ def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30, 
         sa = torch.randn(7 * ld, dtype=torch.float64, device=dev)
         sb = torch.empty(7 * ld, dtype=torch.float64, device=dev)
         s0_ptr, s1_ptr = sa.data_ptr(), sb.data_ptr()
+    lib.stream_mix_launch.argtypes = lib.stream_mix_nt_launch.argtypes
+    big = torch.zeros(n64 * (rb + wb) // 8, dtype=torch.float64, device=dev)   # one direction only, the same bytes per launch
     legs = {
         "kernel": kernel_launch,
+        "read_only": lambda: lib.stream_mix_launch(big.data_ptr(), wbuf.data_ptr(), n64, rb + wb, 0, nblk, stream or None),
+        "write_only": lambda: lib.stream_mix_nt_launch(rbuf.data_ptr(), big.data_ptr(), n64, 0, rb + wb, nblk, stream or None),
         "linear": lambda: lib.stream_mix_nt_launch(rbuf.data_ptr(), wbuf.data_ptr(), n64, rb, wb, nblk, stream or None),
         "j2_shape": lambda: lib.stream_mix_j2_shape_launch(eps.data_ptr(), s0_ptr, s1_ptr, ld, flux.data_ptr(), ct.data_ptr(), n64, nblk, stream or None),
     }
@@ -630,10 +634,13 @@ def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30, 
     out = {"kernel_ms": round(med["kernel"], 4), "linear_probe_ms": round(med["linear"], 4), "j2_shape_probe_ms": round(med["j2_shape"], 4),
            "linear_probe_GBs": round(496 * n64 / med["linear"] / 1e6, 1), "j2_shape_probe_GBs": round(496 * n64 / med["j2_shape"] / 1e6, 1),
            "kernel_over_linear_probe": round(med["linear"] / med["kernel"], 4), "kernel_over_j2_shape_probe": round(med["j2_shape"] / med["kernel"], 4),
+           "read_only_probe_ms": round(med["read_only"], 4), "write_only_probe_ms": round(med["write_only"], 4),
+           "read_only_probe_GBs": round(496 * n64 / med["read_only"] / 1e6, 1), "write_only_probe_GBs": round(496 * n64 / med["write_only"] / 1e6, 1),
            "rounds": reps, "j2_shape_probe_on_the_kernels_own_arrays": state is not None,
-           "note": "tools/stream_mix.hip: no arithmetic, the kernel's bytes; the 17-stream probe reads and writes the kernel's own arrays (strain, resident state, flux, tangent): same placement; interleaved with the kernel in one process (each launch waited for), so all three "
-                   "see the same box at the same time; > 1 means the kernel is faster than the probe"}
-    del rbuf, wbuf, sa, sb
+           "note": "tools/stream_mix.hip: no arithmetic, the kernel's bytes; the 17-stream probe reads and writes the kernel's own arrays (strain, resident state, flux, tangent): same placement; interleaved with the kernel in one process (each launch waited for), so all "
+                   "see the same box at the same time; > 1 means the kernel is faster than the probe.  read_only / write_only: the same 4.96 GB per launch in "
+                   "one direction (profiles/r04_box_survey.md: reads run at 0.79-0.80 ms on every lease, writes at 0.80 on some GPUs and 0.86 on others)"}
+    del rbuf, wbuf, sa, sb, big
     torch.cuda.empty_cache()
     return out
 
