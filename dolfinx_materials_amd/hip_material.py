@@ -546,10 +546,11 @@ class HIPMaterial:
         held outside the material (or were looked at) keep what they show."""
         import sys
 
+        refcount = getattr(sys, "getrefcount", None)   # CPython; elsewhere every live view is kept (one download each)
         for kind in replaced:
             v = (self._grad, self._flux)[kind][0]
             # references of an unheld view: the mirror list, `v`, the argument of getrefcount
-            if type(v) is LazyInitialRows and not v._frozen and (v._seen == v._serial() or sys.getrefcount(v) > 3):
+            if type(v) is LazyInitialRows and not v._frozen and (v._seen == v._serial() or refcount is None or refcount(v) > 3):
                 v._freeze()
 
     def _advance(self):
