@@ -15,12 +15,11 @@ solve (reference solvers.py:72, quadrature_map.py:297-334).  Inputs and outputs 
 resident in the AoS layout of the dolfinx quadrature Functions.
 
 Setup (untimed): the three load-step contexts are built by integrating the earlier increments; every array stays where its
-FIRST allocation put it -- no placement search before the timed region.  Then ~0.5 s of back-to-back launches (the box leaves
+FIRST allocation put it (the library has no placement search: profiles/r05_placement_decision.md).  Then ~0.5 s of back-to-back launches (the box leaves
 its idle state), the W warm-up steps, and the K timed steps with a side thread sampling the GPU's sysfs telemetry (sclk, mclk,
 fclk, power, busy) every 5 ms.  `value`, `roofline.frac` and `roofline.kernel_ms` are of THAT configuration.  Afterwards, as
 context: the same kernel interleaved with two arithmetic-free streaming probes of its traffic mix on the same box
-(`roofline.frac_of_stream_probe`), and what a caller gets who searches placements (`roofline.after_placement_search`:
-dxm_tune_placement with its small budget + up to `--tangent-candidates` allocations of the tangent array; `--no-tune` skips it).
+(`roofline.frac_of_stream_probe`).
 
 The JSON line also carries
   roofline      achieved algorithmic HBM GB/s of the constitutive kernel (496 B/point x points
@@ -234,7 +233,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
 
     uploads, spread = [], []
 
-    def update_cadence(accelerated, reps, nqp=8):
+    def update_cadence(accelerated, reps, nqp=8, isv_mode=None):
         """One ``QuadratureMap.update()`` at n points (n / 8 hexahedra with 8 Gauss points), numpy stand-ins for the
         quadrature Functions (field_map.py): the reference's cadence around ``integrate`` (as_reference_update above)
         against ``quadrature_map.AcceleratedUpdate``.  The gradient "expression" hands out the precomputed strain rows."""
@@ -244,6 +243,8 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
         npts = ncell * nqp
         m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
         q = (QuadratureFieldMap if accelerated else FieldMapBase)(ncell, nqp, m)
+        if isv_mode is not None:
+            q.isv_every_update = isv_mode
         q.register_gradient("strain", None)
 
         class Ready:
@@ -386,7 +387,14 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
                 "note": "HIPMaterial.integrate_rows (dxm_integrate_rows): the threads that rebuild the tangent blocks store stress and block in the point's row"}
 
     def cadence_pair():
-        fast, f_fields, keep_f = update_cadence(True, reps)
+        fast, f_fields, keep_f = update_cadence(True, reps)                      # the default: ISV Functions written in every update, like the reference
+        lazy, l_fields, keep_l = update_cadence(True, reps, isv_mode="lazy")     # opt-in: ISVs cross PCIe when somebody looks, and at advance()
+        lazy_same = all(np.array_equal(f_fields[k], l_fields[k]) for k in f_fields)
+        keep_l[0].close()
+        keep_l[1].close()
+        del l_fields, keep_l
+        fast["with_isv_every_update_lazy"] = {"value": lazy["value"], "ms_per_update": lazy["ms_per_update"], "ms_per_advance": lazy["ms_per_advance"],
+                                              "same_fields_after_advance": bool(lazy_same)}
         try:
             slow, s_fields, keep_s = update_cadence(False, 2)
         except MemoryError as exc:
@@ -398,7 +406,8 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
             m_.close()
         fast["note"] = ("quadrature_map.AcceleratedUpdate (field_map.QuadratureFieldMap): flux / jacobian_flatten memory bound as the material's output arrays, "
                         "gradient evaluated into its page-locked Function memory and uploaded by DMA, NaN count from the kernel's status record, "
-                        "internal state variables downloaded at advance()")
+                        "internal state variables written into their Functions in every update like the reference (isv_every_update = True, the default: "
+                        "+56 B/point over PCIe); `with_isv_every_update_lazy`: the opt-in mode that downloads them when somebody looks and at advance()")
         slow["note"] = ("the reference's cadence around the same HIPMaterial.integrate: gradient scattered into its Function and gathered back, concatenate, three np.isnan "
                         "passes (the ISV one downloads 56 B/point), flux / ISVs / tangent scattered through a per-call np.add.outer index "
                         "(quadrature_map.py:304-334, utils.py:136-143)")
@@ -555,7 +564,7 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, blocks_per_cu=0):
         m.integrate_device(g0.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()
         # a newly allocated array needs 10-20 launches to reach its steady time (the FeFp kernel: 1.70 -> 1.63 ms over the first
-        # fifteen, profiles/r03_fefp_v2_kernel_stats.csv): twenty untimed launches, then the median of `reps`
+        # fifteen, profiles/archive/r03_fefp_v2_kernel_stats.csv): twenty untimed launches, then the median of `reps`
         for _ in range(20):
             m.integrate_device(g1.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -798,7 +807,40 @@ def launch_ranks(args, argv):
     return rc
 
 
+def hbm_plan(law, n, world, gather, copy_probe, coefficient_gather=True):
+    """Device bytes one rank of `run_workload(law, n)` holds at its peak, by purpose (fp64; J2: 7 doubles of resident state per
+    point and side).  Printed per rank at N > 1 and checked against the free HBM before anything is allocated."""
+    state = 3 * 2 * 7 * 8 * n                                   # three load-step handles, s0 + s1 each
+    plan = {"strain_increments_x4": 4 * 48 * n, "resident_state_3_handles": state, "local_stress_and_tangent": (48 + 288) * n}
+    if copy_probe:                                              # rank 0 of the headline: 1 GiB source + four 1 GiB destinations, two probe arrays
+        plan["copy_and_stream_probes"] = 5 * (1 << 30) + 2 * 392 * n
+    if gather:
+        plan["gathered_stress_and_tangent"] = (48 + 288) * n * world
+        if coefficient_gather:
+            plan["coefficient_gather_leg"] = state + 32 * n + 32 * n * world
+    plan["total"] = sum(plan.values())
+    return plan
+
+
+def check_hbm_budget(torch, dev, rank, world, blocks):
+    """`blocks`: name -> hbm_plan(...) of the workloads this rank will run one after the other (each releases its arrays on return).
+    One line per rank on stderr; SystemExit with a message when the largest exceeds 0.9 x the free HBM of this rank's GPU -- the
+    first lease of a multi-GPU node should not be spent on an allocation failure 40 s into the run."""
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    need = max(p["total"] for p in blocks.values())
+    line = {"rank": rank, "world": world, "device": str(dev), "hbm_free_GB": round(free_b / 1e9, 2), "hbm_total_GB": round(total_b / 1e9, 2),
+            "largest_block_GB": round(need / 1e9, 2), "blocks_GB": {k: {kk: round(vv / 1e9, 3) for kk, vv in p.items()} for k, p in blocks.items()}}
+    print("[bench.py hbm budget] " + json.dumps(line), file=sys.stderr, flush=True)
+    if need > 0.9 * free_b:
+        raise SystemExit(f"bench.py rank {rank}: the run would allocate {need / 1e9:.1f} GB on {dev} but only {free_b / 1e9:.1f} GB of HBM are free "
+                         f"(limit 0.9 x free); lower --points / --cfg3-points or pass --no-gather / --no-cfg3")
+    return line
+
+
 def main():
+    # Every rank, whoever started it (this file's launch_ranks, torch.distributed.run, a test): the hosts of this pool support
+    # dmabuf IPC only; without the variable RCCL's hipIpcGetMemHandle fails with "invalid argument".  Before torch is imported.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -819,16 +861,10 @@ def main():
                     help="debug, --gpus 1 only: join an RCCL process group of one rank and run the gather legs through it "
                          "(the device-tensor collectives of the N > 1 path on a 1-GPU box; never for reported numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tune", action="store_true",
-                    help="skip the context leg `roofline.after_placement_search` (the timed region never uses a placement search)")
     ap.add_argument("--settle-seconds", type=float, default=0.5, help="back-to-back launches before the warm-up steps (the box leaves its idle state)")
     ap.add_argument("--no-stream-probe", action="store_true", help="skip the context leg `roofline.stream_probe` (the kernel interleaved with two arithmetic-free streaming kernels)")
     ap.add_argument("--no-telemetry", action="store_true", help="skip the box block (sysfs / rocm-smi reads around and during the timed steps)")
-    ap.add_argument("--tune-candidates", type=int, default=4, help="state allocations dxm_tune_placement may measure per handle (context leg after the timed region)")
-    ap.add_argument("--tune-skip-gib", type=float, default=2.0, help="skip blocks dxm_tune_placement may hold, GiB")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="option blocks_per_cu for every handle of the run (0: the library's default per law)")
-    ap.add_argument("--tangent-candidates", type=int, default=4,
-                    help="allocations of the caller's tangent array the context leg `roofline.after_placement_search` tries; 1 = keep the first")
     ap.add_argument("--no-other-laws", action="store_true", help="skip the per-law context numbers")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -914,13 +950,22 @@ def main():
     n = args.points
     K, W = args.steps, args.warmup
     seed = 1234 + rank
+    run_cfg3 = world > 1 and not args.no_cfg3 and args.law == "j2_linear"
+    # (the debug share mode keeps all ranks on one GPU and gathers through gloo on the host: never the full size there)
+    n3 = args.cfg3_points if args.cfg3_points else (min(n, 50_000, 100_000_000 // world) if share else 100_000_000 // world)
+    if world > 1:
+        blocks = {"headline": hbm_plan(args.law, n, 1 if share else world, grouped and not args.no_gather and not share, rank == 0 and not share)}
+        if run_cfg3:
+            blocks["cfg3"] = hbm_plan("j2_voce", n3, 1 if share else world, not args.no_gather and not share, False)
+        if share:   # all ranks of the debug mode allocate on GPU 0
+            for b in blocks.values():
+                b["total"] *= world
+        check_hbm_budget(torch, dev, rank, world, blocks)
     head = run_workload(c, args.law, n, K, W, max(1, args.gather_steps), gather=grouped and not args.no_gather, copy_probe=True)
     # N > 1: cfg 3 of SURVEY.md 8(d) beside the weak-scaling headline -- J2 + Voce, 1e8 points sharded over the ranks,
     # compute-only and the three reassembly schedules
     cfg3 = None
-    if world > 1 and not args.no_cfg3 and args.law == "j2_linear":
-        # (the debug share mode keeps all ranks on one GPU and gathers through gloo on the host: never the full size there)
-        n3 = args.cfg3_points if args.cfg3_points else (min(n, 50_000, 100_000_000 // world) if share else 100_000_000 // world)
+    if run_cfg3:
         try:
             cfg3 = run_workload(c, "j2_voce", n3, max(10, min(K, 50)), min(W, 5), max(10, args.gather_steps), gather=not args.no_gather)
         except Exception as exc:   # context block: never lose the headline line
@@ -968,7 +1013,7 @@ def main():
                 "plastic_fraction_inc2_3_4": head["plastic_fraction"],
                 "layout": "AoS (N,6)/(N,36) boundary arrays in HBM, SoA resident state",
                 "sharding": "independent contiguous point blocks, no data-path collective",
-                "placement": "every array where its first allocation put it (no placement search before or inside the timed region)",
+                "placement": "every array where its first allocation put it",
                 "settle_launches_before_warmup": head["settle_launches"],
             },
             "roofline": {
@@ -985,7 +1030,6 @@ def main():
                 "kernel_ms": round(kern_ms, 4),
                 "frac_of_stream_probe": (probe or {}).get("kernel_over_j2_shape_probe"),
                 "stream_probe": probe,
-                "after_placement_search": head.get("searched"),
                 "algorithmic_bytes_per_point": ALG_BYTES,
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                 "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
@@ -1015,7 +1059,7 @@ def main():
                     "value": round(n3_ * world * k3 / e3 / 1e6, 3), "unit": "Mpoints/s", "steps": k3, "ms_per_step": round(e3 / k3 * 1e3, 4),
                     "kernel": cfg3["kernel"], "kernel_ms": round(cfg3["kernel_ms"], 4),
                     "frac": round(ALG_BYTES * n3_ / (cfg3["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "plastic_fraction_inc2_3_4": cfg3["plastic_fraction"], "after_placement_search": cfg3.get("searched"),
+                    "plastic_fraction_inc2_3_4": cfg3["plastic_fraction"],
                     "gather_inclusive": cfg3["gather"],
                     "note": "SURVEY.md 8(d) cfg 3: compute-only (`value`, no data-path collective) and, in `gather_inclusive`, stress + tangent reassembled "
                             "on every rank by the RCCL all-gather, by the point-to-point schedule and as coefficients rebuilt locally",
@@ -1045,7 +1089,7 @@ def workload_name(law, n):
 
 
 def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
-    """One law at n points per rank: set-up (three load-step contexts, placement search), W warm-up steps, K timed steps
+    """One law at n points per rank: set-up (three load-step contexts), W warm-up steps, K timed steps
     bracketed by barrier + synchronize (max over ranks), then -- in a process group -- the same steps followed by the
     reassembly of stress and tangent on every rank, three ways.  Everything it allocated is released on return."""
     torch, dist, jm, JAXMaterial, args = c.torch, c.dist, c.jm, c.JAXMaterial, c.args
@@ -1180,39 +1224,6 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         except Exception as exc:   # context only
             stream_probe = {"error": repr(exc)}
 
-    # (2) what a caller gets who searches: dxm_tune_placement per handle (small budget) and a few allocations of the tangent array
-    searched = None
-    if not args.no_tune and not share:
-        try:
-            events_ms(3)
-            before_ms = events_ms(12)
-            tuning = []
-            for j, m in enumerate(mats):
-                m.set_option("tune_max_skip_bytes", args.tune_skip_gib * 2**30)
-                info = m.tune_placement(eps[j + 1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=args.tune_candidates)
-                tuning.append({"ms_before": round(info["ms_before"], 4), "ms_after": round(info["ms_after"], 4), "candidates_tried": info["candidates_tried"]})
-            events_ms(3)
-            times, cands = [events_ms(12)], [ct]
-            for _ in range(max(0, args.tangent_candidates - 1)):
-                ct = torch.empty((n, 36), dtype=torch.float64, device=dev)   # (events_ms / step read `ct` of this scope)
-                cands.append(ct)
-                events_ms(15)   # a newly allocated array needs 10-20 launches to reach its steady time
-                times.append(events_ms(12))
-            kept = int(np.argmin(times))
-            ct = cands[kept]
-            del cands
-            torch.cuda.empty_cache()
-            events_ms(5)
-            after_ms = events_ms(20)
-            searched = {"kernel_ms": round(after_ms, 4), "frac": round(ALG_BYTES * n / (after_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "kernel_ms_before_the_search": round(before_ms, 4), "state_placement": tuning,
-                        "tangent_allocations_ms": [round(t, 4) for t in times], "tangent_allocation_kept": kept,
-                        "note": "context, never `value`: dxm_tune_placement (dxmat_experimental.h; 4 state allocations, <= 2 GiB of skip blocks) per handle, then "
-                                "the fastest of a few allocations of the caller's tangent array; the kernel time has two levels in where these "
-                                "arrays sit physically (profiles/NOTES.md, placement)"}
-        except Exception as exc:   # context only
-            searched = {"error": repr(exc)}
-
     # device-copy bandwidth of THIS box (read + write bytes of a 1 GiB fp64 copy): the practical
     # ceiling a streaming kernel sees here.  The rate depends on which physical regions the two
     # buffers come from (5.2 vs 4.65 TB/s), so the best of four destinations
@@ -1249,7 +1260,8 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         group_info = {"backend": dist.get_backend(), "ranks_in_group": dist.get_world_size(),
                       "ranks_counted_by_all_reduce": int(seen.item()),
                       "launcher": os.environ.get("DXM_BENCH_LAUNCHER", "torch.distributed.run"),
-                      "share_gpu_debug_mode": bool(share)}
+                      "share_gpu_debug_mode": bool(share),
+                      "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}   # set by main() when the launcher did not
     if grouped and gather:
         # gather-inclusive variant: reassemble stress and tangent on every rank over xGMI.  Context
         # for cfg 3 only: a failure here (e.g. not enough HBM for the gathered buffers when the GPUs
@@ -1351,7 +1363,7 @@ def run_workload(c, law, n, K, W, G, gather, copy_probe=False):
         m.close()
     del eps, flux, ct
     torch.cuda.empty_cache()
-    return {"elapsed": elapsed, "kernel_ms": kern_ms, "searched": searched, "stream_probe": stream_probe, "box_during": box_during, "settle_launches": n_settle,
+    return {"elapsed": elapsed, "kernel_ms": kern_ms, "stream_probe": stream_probe, "box_during": box_during, "settle_launches": n_settle,
             "plastic_fraction": [round(x, 4) for x in plastic_frac],
             "copy_gbs": copy_gbs, "gather": gather_out, "group_info": group_info, "kernel": kernel, "steps": K, "points": n}
 

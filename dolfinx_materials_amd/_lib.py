@@ -128,17 +128,6 @@ SYMBOLS = {
     ),
 }
 
-#: every symbol include/dxmat_experimental.h declares (measurement helpers, assembly-side research kernels)
-EXPERIMENTAL_SYMBOLS = {
-    "dxm_tune_placement": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double),
-                                     C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "dxm_time_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
-    "dxm_mesh_set_weights": (C.c_int, [_h, C.c_void_p]),
-    "dxm_mesh_internal_force_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "dxm_mesh_tangent_apply_device": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "dxm_mesh_tangent_diagonal_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
-}
-
 _lib = None
 
 
@@ -187,7 +176,7 @@ def load() -> C.CDLL:
 
 
 def _bind(lib: C.CDLL, strict: bool = True) -> C.CDLL:
-    for name, (res, args) in {**SYMBOLS, **EXPERIMENTAL_SYMBOLS}.items():
+    for name, (res, args) in SYMBOLS.items():
         try:
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         except AttributeError:
@@ -262,7 +251,7 @@ def load_custom(expr_R: str, expr_dR: str) -> C.CDLL:
     if key in _custom_libs:
         return _custom_libs[key]
     srcs = [os.path.join(CSRC_DIR, f) for f in sorted(os.listdir(CSRC_DIR)) if f.endswith((".hip", ".hpp"))]
-    srcs += [os.path.join(os.path.dirname(_HERE), "include", h) for h in ("dxmat.h", "dxmat_experimental.h")]
+    srcs += [os.path.join(os.path.dirname(_HERE), "include", h) for h in ("dxmat.h",)]
     h = hashlib.sha1()
     h.update(expr_R.encode() + b"\0" + expr_dR.encode())
     for f in srcs:

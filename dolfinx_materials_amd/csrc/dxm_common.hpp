@@ -149,7 +149,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 //   bit 2 = non-temporal loads of the gradient            bit 3 = of the old state
 // Shipped: 1.  Flux and tangent (336 of the 496 B/point of J2) are not read again on the GPU, so
 // their lines need not displace the gradient and the state in L2 / Infinity Cache: same-process A/B
-// (tools/ab_inproc.py, profiles/r01_nt_ab.jsonl) -26 % kernel time at 1e6 points, -9 % at 1e5,
+// (tools/ab_inproc.py, profiles/archive/r01_nt_ab.jsonl) -26 % kernel time at 1e6 points, -9 % at 1e5,
 // -2 % at 1e7, never slower.  The new state IS read back by the next update (advance), and a
 // non-temporal state store costs +18 % at 3e5 points; non-temporal loads only lose where the
 // gradient was just written by the displacement-gradient kernel.  So bits 1-3 stay off.

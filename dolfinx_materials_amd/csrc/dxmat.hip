@@ -24,7 +24,6 @@
 #include <vector>
 
 #include "../../include/dxmat.h"
-#include "../../include/dxmat_experimental.h"
 #include "dxm_common.hpp"
 #include "fefp.hpp"
 #include "gradient.hpp"
@@ -162,13 +161,12 @@ struct dxm_material {
                                           // on the host; 2 (small strain) only (c1, c2, c3, w), the direction rebuilt from the stress
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
   bool opt_staged_gradient = true;        // hex8 gradient kernel: nodal data through LDS
-  bool opt_tune_verbose = false;
+  bool opt_verbose = false;
   dxm_host::UploadChooser up;             // option register_input (host path, pageable gradient array): 2 page-lock it for the call (DMA upload), 0 stage it, 1 measure and keep the faster
   int last_upload = DXM_UPLOAD_NONE;      // dxm_stats.upload of the last host-buffer call
   int opt_host_threads = 16;
   int opt_pageable_dma = 0;   // 1: hand pageable host arrays to the runtime (faster uploads; see upload_from_host)
   int64_t opt_packed_min_points = 32768;   // below: waking the workers costs what the bytes save (r02_hostpath_v2.jsonl)
-  size_t opt_tune_max_skip = (size_t)2 << 30;   // dxm_tune_placement: bytes of skip blocks it may hold
   int opt_max_chunks = DXM_MAX_CHUNKS;
   HostPool* pool = nullptr;
   double* h_coef = nullptr;               // page-locked (n, 9) landing area of the tangent coefficients
@@ -376,7 +374,7 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   // SoA leading dimension: N rounded up to 256 plus 32 doubles.  With a slot stride that is a
   // multiple of 2 KiB the s0 read streams and s1 write streams of all slots stay congruent and the
   // kernel falls into a slow mode (0.91 vs 0.83 ms at 1e7 points, bimodal by allocation address);
-  // a 256 B stagger per slot removes it (profiles/r01_tune_state_stride.txt).
+  // a 256 B stagger per slot removes it (profiles/archive/r01_tune_state_stride.txt).
   m->ld = ((npoints + 255) / 256) * 256 + 32;
   auto bail = [&](void) -> dxm_material* { dxm_destroy(m); return nullptr; };
   if (build_params(m, params, n_params) != 0) return bail();
@@ -403,7 +401,7 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
   // grid).  Small strain: 32 = 8 x the resident 4: a grid of exactly-resident workgroups starts all
   // waves together and keeps them in lockstep (everybody loads, then everybody stores); workgroups
   // that are dispatched as others retire spread those phases, 3-6 % faster at 1e7 points in the fast
-  // placement mode and 10 % in the slow one (tools/grid_sweep.py, profiles/r01_grid_sweep.jsonl).
+  // placement mode and 10 % in the slow one (tools/grid_sweep.py, profiles/archive/r01_grid_sweep.jsonl).
   {
     int occ = 0;
     const void* fn = nullptr;
@@ -430,7 +428,7 @@ dxm_material* dxm_create(int law, const double* params, int n_params, int64_t np
     if (law == DXM_LAW_ELASTIC_ISO || law == DXM_LAW_J2_LINEAR) m->blocks_per_cu = 32;
     // The laws with a local Newton iteration (Voce or traced hardening, FeFp) do a point-dependent amount of work per tile: a
     // grid of one workgroup per 256 points (up to 256 per CU, the cap; a grid-stride loop beyond) lets the dispatcher balance
-    // it -- Voce +3 %, FeFp +2.5 % over the persistent grids above at 1e7 points (profiles/r03_grid_size_by_law.txt); the
+    // it -- Voce +3 %, FeFp +2.5 % over the persistent grids above at 1e7 points (profiles/archive/r03_grid_size_by_law.txt); the
     // linear-hardening kernel, whose tiles all cost the same, loses 2.5 % with it and keeps 32.
     if (law == DXM_LAW_J2_VOCE || law == DXM_LAW_FEFP_J2_VOCE || law == DXM_LAW_FEFP_J2_LINEAR) m->blocks_per_cu = 256;
   }
@@ -779,7 +777,7 @@ static void launch_small_strain(dxm_material* m, int grid, hipStream_t st, int64
   // J2 kernels: 2.25 KiB of unused dynamic LDS on top of the static 30.1 KiB keep FOUR workgroups (16 waves) per CU.  The
   // linear-hardening kernel needs 95 VGPRs since the flow direction of the tangent comes from the stress (it was 103):
   // a fifth wave per SIMD would fit and costs 0.65 % (0.8169 vs 0.8116 / 0.8123 ms per 1e7 points in one process,
-  // profiles/r03_j2_ab_pack4.jsonl); the elastic kernel keeps its five.
+  // profiles/archive/r03_j2_ab_pack4.jsonl); the elastic kernel keeps its five.
   constexpr int dyn_lds = LAW == LAW_ELASTIC ? 0 : 2304;
 #define DXM_LAUNCH_SS(TL, G)                                                                              \
   hipLaunchKernelGGL((small_strain_kernel<LAW, TL, G>), dim3(grid), dim3(BLOCK), dyn_lds, st, m->prm, cnt, grad, s0, s1, \
@@ -864,138 +862,6 @@ int dxm_integrate_device(dxm_material* m, const double* grad_dev, double dt, dou
   if (m->n > 0 && (!grad_dev || !flux_dev || !ct_dev)) return fail(-1, "null device pointer");
   DEVICE_GUARD(m);
   return launch(m, grad_dev, flux_dev, ct_dev, (hipStream_t)hip_stream);
-}
-
-// ---- placement tuning ----------------------------------------------------------------------
-// The kernel time is bimodal (+13 % at 1e7 J2 points) in WHERE the resident state sits relative to
-// the caller's gradient / flux / tangent arrays: physical placement, invisible to and not steerable
-// from user space (profiles/r01_placement_*.jsonl).  What can be done is to
-// measure: try a few fresh state allocations with the caller's real buffers and keep the fastest.
-struct StateBlock { double* base; double* s[2]; };
-
-static int time_launches(dxm_material* m, const double* grad, double* flux, double* ct, int reps,
-                         hipEvent_t e0, hipEvent_t e1, float* best_ms) {
-  float best = 1e30f;
-  for (int r = 0; r < reps; ++r) {
-    HIP_TRY(hipEventRecord(e0, m->own_stream));
-    if (int rc = launch(m, grad, flux, ct, m->own_stream)) return rc;
-    HIP_TRY(hipEventRecord(e1, m->own_stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (ms < best) best = ms;
-  }
-  *best_ms = best;
-  return 0;
-}
-
-int dxm_time_device(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev, int launches, double* best_ms) {
-  if (!m) return fail(-1, "null handle");
-  if (best_ms) *best_ms = 0.0;
-  if (m->n == 0 || launches <= 0) return 0;
-  if (!grad_dev || !flux_dev || !ct_dev) return fail(-1, "null device pointer");
-  DEVICE_GUARD(m);
-  if (int rc = sync_last(m)) return rc;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(hipEventCreate(&e0));
-  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(-3, "hipEventCreate failed"); }
-  float t = 0.f;
-  int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 2, e0, e1, &t);   // two untimed-in-effect launches first: caches, clocks
-  if (!rc) rc = time_launches(m, grad_dev, flux_dev, ct_dev, launches, e0, e1, &t);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  if (rc) return rc;
-  if (best_ms) *best_ms = t;
-  return 0;
-}
-
-int dxm_tune_placement(dxm_material* m, const double* grad_dev, double* flux_dev, double* ct_dev,
-                       int max_candidates, double* ms_before, double* ms_after, int* n_tried) {
-  if (!m) return fail(-1, "null handle");
-  if (ms_before) *ms_before = 0.0;
-  if (ms_after) *ms_after = 0.0;
-  if (n_tried) *n_tried = 0;
-  const LawDesc& d = kLaws[m->law];
-  if (m->n == 0 || d.n_slots == 0 || max_candidates <= 0) return 0;   // nothing resident to place
-  if (!grad_dev || !flux_dev || !ct_dev) return fail(-1, "null device pointer");
-  DEVICE_GUARD(m);
-  if (int rc = sync_last(m)) return rc;
-  const size_t bytes = (size_t)d.n_slots * m->ld * sizeof(double);
-  const size_t block = 2 * bytes + m->s1_skew;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  std::vector<void*> held;   // losers stay allocated until the end, so that the allocator keeps
-                             // handing out NEW physical ranges
-  auto cleanup = [&]() {
-    for (void* p : held) (void)hipFree(p);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-  };
-  float t = 0.f;
-  if (int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 2, e0, e1, &t)) { cleanup(); return rc; }   // warm
-  const int reps = t > 0.f ? std::min(50, std::max(3, (int)(2.0f / t))) : 3;
-  if (int rc = time_launches(m, grad_dev, flux_dev, ct_dev, reps, e0, e1, &t)) { cleanup(); return rc; }
-  if (ms_before) *ms_before = t;
-  StateBlock best{m->state_base, {m->state[0], m->state[1]}};
-  float t_best = t, t_max = t;
-  size_t free_b = 0, total_b = 0;
-  (void)hipMemGetInfo(&free_b, &total_b);
-  size_t budget = free_b / 2;
-  int tried = 0, after_contrast = 0;
-  size_t skipped = 0;
-  const bool verbose = m->opt_tune_verbose;
-  ++m->epoch;   // the state moves: graphs captured before are stale
-  if (verbose) fprintf(stderr, "[dxm_tune_placement] initial %p: %.4f ms\n", (void*)m->state_base, t);
-  for (int c = 0; c < max_candidates; ++c) {
-    if (budget < block) break;
-    // First half of the candidates: consecutive allocations (the mode usually flips within a few GB of
-    // allocated memory).  Second half: jump ahead by skip blocks of 1, 2, 4 ... GiB first; all skip blocks
-    // together stay below max_skip_bytes (2 GiB unless the caller raised it with dxm_set_option).
-    if (c >= (max_candidates + 1) / 2) {
-      size_t skip = std::min<size_t>((size_t)1 << (30 + std::min(c - (max_candidates + 1) / 2, 4)), budget / 4);
-      skip = std::min(skip, m->opt_tune_max_skip > skipped ? m->opt_tune_max_skip - skipped : 0);
-      void* sp = nullptr;
-      if (skip >= ((size_t)256 << 20) && budget >= skip + block) {
-        if (hipMalloc(&sp, skip) == hipSuccess) { held.push_back(sp); budget -= skip; skipped += skip; } else (void)hipGetLastError();
-      }
-    }
-    double* nb = nullptr;
-    if (hipMalloc(&nb, block) != hipSuccess) { (void)hipGetLastError(); break; }
-    budget -= block;
-    StateBlock cand{nb, {nb, reinterpret_cast<double*>(reinterpret_cast<char*>(nb) + bytes + m->s1_skew)}};
-    hipError_t ce = hipMemcpyAsync(cand.s[0], m->state[0], bytes, hipMemcpyDeviceToDevice, m->own_stream);
-    if (ce != hipSuccess) { held.push_back(nb); cleanup(); return fail(-2, "state copy failed: %s", hipGetErrorString(ce)); }
-    const StateBlock cur{m->state_base, {m->state[0], m->state[1]}};
-    m->state_base = cand.base; m->state[0] = cand.s[0]; m->state[1] = cand.s[1];
-    int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 1, e0, e1, &t);
-    if (!rc) rc = time_launches(m, grad_dev, flux_dev, ct_dev, reps, e0, e1, &t);
-    if (rc) {   // keep the handle usable: back to the previous block
-      m->state_base = cur.base; m->state[0] = cur.s[0]; m->state[1] = cur.s[1];
-      held.push_back(nb); cleanup(); return rc;
-    }
-    ++tried;
-    if (verbose) fprintf(stderr, "[dxm_tune_placement] candidate %d %p: %.4f ms\n", c, (void*)nb, t);
-    if (t > t_max) t_max = t;
-    if (t < t_best) {
-      held.push_back(best.base);   // the former best becomes a loser
-      best = cand; t_best = t;
-    } else {
-      held.push_back(cand.base);
-    }
-    // state[0] of `best` always holds s0: every candidate received a copy and the kernel never writes it
-    m->state_base = best.base; m->state[0] = best.s[0]; m->state[1] = best.s[1];
-    // both modes seen: the best is a fast placement.  Fast placements still differ by 2-3 % among
-    // themselves, so a few more candidates are measured before stopping.
-    if (t_best <= 0.95f * t_max && ++after_contrast > 6) break;
-  }
-  // one more launch on the chosen block so that s1, flux, tangent and the stats are those of `best`
-  int rc = time_launches(m, grad_dev, flux_dev, ct_dev, 1, e0, e1, &t);
-  cleanup();
-  if (rc) return rc;
-  if (ms_after) *ms_after = t_best;
-  if (n_tried) *n_tried = tried;
-  return 0;
 }
 
 int dxm_get_stats(dxm_material* m, dxm_stats* stats) {
@@ -1171,7 +1037,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                         sizeof(double) * ((n - o) < csize ? (n - o) : csize) * d.n_grad, p);
     return 0;
   };
-  double ms_wait_copy = 0.0, ms_first_copy = 0.0;   // tune_verbose: time the issue loop spent waiting for staging copies
+  double ms_wait_copy = 0.0, ms_first_copy = 0.0;   // option verbose: time the issue loop spent waiting for staging copies
   const int ahead = m->opt_stage_ahead;
   for (int p = 0; p < ahead; ++p) if (int rc = stage_chunk(p)) return rc;
   for (int c = 0; c < nchunks; ++c) {
@@ -1196,7 +1062,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       const int64_t n16 = cnt * d.n_grad / 2;      // cnt is a multiple of 256 except in the last chunk; n_grad 6 or 9:
       const int64_t tail = cnt * d.n_grad - 2 * n16;   // an odd count leaves one double for a plain copy
       // (on the chunk's own stream: a third stream carrying all uploads ahead of the kernels was measured at 46-62 ms per
-      // 1e7 points against 31-33, profiles/r03_hostpath_fresh_array.md)
+      // 1e7 points against 31-33, profiles/archive/r03_hostpath_fresh_array.md)
       hipLaunchKernelGGL(ring_upload_kernel, dim3(32), dim3(256), 0, st, reinterpret_cast<const double2_t*>(dst),
                          reinterpret_cast<double2_t*>(m->d_grad + off * d.n_grad), n16);
       if (tail) HIP_TRY(hipMemcpyAsync(m->d_grad + off * d.n_grad + 2 * n16, dst + 2 * n16, sizeof(double), hipMemcpyHostToDevice, st));
@@ -1249,7 +1115,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   for (int c = 0; c < issued; ++c) {
     HIP_TRY(hipEventSynchronize(m->chunk_done[c]));
-    if (m->opt_tune_verbose && (c % 8 == 7 || c == 0)) fprintf(stderr, "[dxm host path] chunk %d landed at +%.2f ms after issue (issue loop took %.2f ms)\n", c, ms_since(t_issued), std::chrono::duration<double, std::milli>(t_issued - t_enter).count());
+    if (m->opt_verbose && (c % 8 == 7 || c == 0)) fprintf(stderr, "[dxm host path] chunk %d landed at +%.2f ms after issue (issue loop took %.2f ms)\n", c, ms_since(t_issued), std::chrono::duration<double, std::milli>(t_issued - t_enter).count());
     if (packed && (!constant || rowmode) && c >= submitted) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
@@ -1270,14 +1136,14 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   m->last_event_recorded = true;
   const auto t_landed = std::chrono::steady_clock::now();
   if (packed) m->pool->wait();
-  if (m->opt_tune_verbose && host_grad) fprintf(stderr, "[dxm host path] %d chunks of %lld points; issue loop waited %.2f ms for staging copies (first chunk %.2f ms)\n", nchunks, (long long)csize, ms_wait_copy, ms_first_copy);
-  if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] all landed at +%.2f ms, workers done %.2f ms later\n", std::chrono::duration<double, std::milli>(t_landed - t_issued).count(), ms_since(t_landed));
+  if (m->opt_verbose && host_grad) fprintf(stderr, "[dxm host path] %d chunks of %lld points; issue loop waited %.2f ms for staging copies (first chunk %.2f ms)\n", nchunks, (long long)csize, ms_wait_copy, ms_first_copy);
+  if (m->opt_verbose) fprintf(stderr, "[dxm host path] all landed at +%.2f ms, workers done %.2f ms later\n", std::chrono::duration<double, std::milli>(t_landed - t_issued).count(), ms_since(t_landed));
   inflight.completed = true;
   m->io1_valid = (fused ? 0 : 1) | 2;   // d_grad (unless the strain never existed as an array) and d_flux are those of s1
   const auto t_stats = std::chrono::steady_clock::now();
   const int rc_stats = dxm_get_stats(m, stats);
   if (stats) stats->upload = host_grad ? DXM_UPLOAD_STAGED : m->last_upload;
-  if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] status records summed in %.3f ms; %.2f ms since entry\n", ms_since(t_stats), ms_since(t_enter));
+  if (m->opt_verbose) fprintf(stderr, "[dxm host path] status records summed in %.3f ms; %.2f ms since entry\n", ms_since(t_stats), ms_since(t_enter));
   return rc_stats;
 }
 
@@ -1294,7 +1160,7 @@ static int integrate_host_impl(dxm_material* m, const double* grad_aos, double* 
   const auto t_in = std::chrono::steady_clock::now();
   bool locked_in = m->opt_pageable_dma || page_locked(grad_aos, sizeof(double) * n * d.n_grad);
   // An array in ordinary memory is page-locked HERE, for the duration of this call, and uploaded by DMA like a page-locked
-  // one: registering a 480 MB array takes ~1 ms (profiles/r03_hostpath_register.md) where staging it through the ring
+  // one: registering a 480 MB array takes ~1 ms (profiles/archive/r03_hostpath_register.md) where staging it through the ring
   // costs the worker threads 5-10 ms of a 24 ms call.  This is not the runtime's implicit path for pageable memory (whose
   // cache of on-the-fly mappings outlives the caller's array: DESIGN.md section 1): the range is unregistered before this
   // function returns, error paths included, while the caller still owns the array.  A refusal (a range that overlaps a
@@ -1309,7 +1175,7 @@ static int integrate_host_impl(dxm_material* m, const double* grad_aos, double* 
       (void)hipHostUnregister(p);
       (void)hipGetLastError();
       m->unregister_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] releasing the page-lock of the gradient array took %.3f ms\n", m->unregister_ms);
+      if (m->opt_verbose) fprintf(stderr, "[dxm host path] releasing the page-lock of the gradient array took %.3f ms\n", m->unregister_ms);
     }
   } temp;
   temp.m = m;
@@ -1328,7 +1194,7 @@ static int integrate_host_impl(dxm_material* m, const double* grad_aos, double* 
         // 0.9 ms per 480 MB on transparent huge pages (what numpy asks for), 7-17 ms on 4 KiB pages, where the whole call
         // then takes 43 instead of 28 ms: such arrays go through the staging ring for the next 20 calls, then one more try
         const double ms_lock = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (m->opt_tune_verbose) fprintf(stderr, "[dxm host path] page-locking the gradient array took %.3f ms (releasing it after the previous call: %.3f ms)\n", ms_lock, m->unregister_ms);
+        if (m->opt_verbose) fprintf(stderr, "[dxm host path] page-locking the gradient array took %.3f ms (releasing it after the previous call: %.3f ms)\n", ms_lock, m->unregister_ms);
         m->up.registered(ms_lock + m->unregister_ms, bytes);   // what the previous call paid to release its range counts too
       } else {
         (void)hipGetLastError();
@@ -1341,7 +1207,7 @@ static int integrate_host_impl(dxm_material* m, const double* grad_aos, double* 
   const auto t_q = std::chrono::steady_clock::now();
   if (int rc = ensure_host_path_buffers(m)) return rc;
   if (int rc = sync_last(m)) return rc;
-  if (m->opt_tune_verbose)
+  if (m->opt_verbose)
     fprintf(stderr, "[dxm host path] classifying the gradient pointer took %.3f ms, buffers + wait for the previous call %.3f ms\n",
             std::chrono::duration<double, std::milli>(t_q - t_in).count(),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q).count());
@@ -1370,7 +1236,7 @@ static int integrate_host(dxm_material* m, const double* grad_aos, double* flux_
   // the adaptive choice between page-locking the caller's gradient array for the call and staging it (see above)
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   const bool changed = m->up.record(way, ms);
-  if (m->opt_tune_verbose && way && m->up.opt == 1 && (changed || m->up.calls == 5))
+  if (m->opt_verbose && way && m->up.opt == 1 && (changed || m->up.calls == 5))
     fprintf(stderr, "[dxm host path] gradient upload: page-locked for the call %.2f ms, staged %.2f ms per call -> %s\n",
             m->up.ms[1], m->up.ms[2], m->up.pref == 1 ? "page-locking" : "staging");
   return rc;
@@ -1428,11 +1294,6 @@ struct dxm_mesh {
   int64_t n_dofs = 0;
   int32_t* d_dofmap = nullptr;
   double* d_dphi = nullptr;
-  // assembly-side consumers (hex8 x 8 points): quadrature weights, element scratch, node -> (cell, corner) table
-  double w[27];
-  double* d_fe = nullptr;
-  int64_t* d_node_ptr = nullptr;
-  int32_t* d_node_adj = nullptr;
 };
 
 static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, const int32_t* conn,
@@ -1455,7 +1316,6 @@ static dxm_mesh* mesh_create(int npc, const double* coords, int64_t n_nodes, con
   mesh->n_cells = n_cells;
   mesh->u_len = 3 * n_nodes;
   mesh->qp.nqp = nqp;
-  for (int q = 0; q < 27; ++q) mesh->w[q] = 1.0;   // 2x2x2 Gauss-Legendre on [-1,1]^3; dxm_mesh_set_weights otherwise
   if (qpoints)
     for (int q = 0; q < nqp; ++q)
       for (int d = 0; d < 3; ++d) mesh->qp.xi[q][d] = qpoints[3 * q + d];
@@ -1551,9 +1411,6 @@ int dxm_mesh_destroy(dxm_mesh* mesh) {
   if (mesh->d_u) (void)hipFree(mesh->d_u);
   if (mesh->d_dofmap) (void)hipFree(mesh->d_dofmap);
   if (mesh->d_dphi) (void)hipFree(mesh->d_dphi);
-  if (mesh->d_fe) (void)hipFree(mesh->d_fe);
-  if (mesh->d_node_ptr) (void)hipFree(mesh->d_node_ptr);
-  if (mesh->d_node_adj) (void)hipFree(mesh->d_node_adj);
   if (mesh->grad_done) (void)hipEventDestroy(mesh->grad_done);
   delete mesh;
   return 0;
@@ -1599,97 +1456,6 @@ int dxm_mesh_gradient_device(dxm_mesh* mesh, const double* u_dev, int kind, doub
   }
   HIP_TRY(hipGetLastError());
   return 0;
-}
-
-// ---- assembly-side consumers on the device (gradient.hpp: hex8_element_kernel + node_gather_kernel) ------------
-int dxm_mesh_set_weights(dxm_mesh* mesh, const double* weights) {
-  if (!mesh || !weights) return fail(-1, "null argument");
-  if (mesh->nodes_per_cell != 8) return fail(-1, "quadrature weights are used by the hex8 operators only");
-  for (int q = 0; q < mesh->qp.nqp; ++q) mesh->w[q] = weights[q];
-  return 0;
-}
-
-// scratch for the element values and the node -> (cell, corner) table (counting sort of the connectivity), on first use
-static int ensure_operator_buffers(dxm_mesh* mesh) {
-  if (mesh->nodes_per_cell != 8 || mesh->qp.nqp != 8)
-    return fail(-1, "the device operators need a hex8 mesh with 8 Gauss points per cell");
-  if (mesh->d_fe) return 0;
-  const int64_t ne = mesh->n_cells * 8;
-  if (ne > INT32_MAX) return fail(-1, "too many cells for the 32-bit (cell, corner) table");
-  // (through page-locked memory: see download_to_host)
-  int32_t* conn = nullptr;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&conn), sizeof(int32_t) * ne, hipHostMallocDefault));
-  struct Unpin { void* p; ~Unpin() { (void)hipHostFree(p); } } unpin{conn};
-  HIP_TRY(hipMemcpy(conn, mesh->d_conn, sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
-  std::vector<int64_t> ptr((size_t)mesh->n_nodes + 1, 0);
-  for (int64_t k = 0; k < ne; ++k) ++ptr[(size_t)conn[k] + 1];
-  for (int64_t v = 0; v < mesh->n_nodes; ++v) ptr[v + 1] += ptr[v];
-  std::vector<int32_t> adj((size_t)ne);
-  {
-    // element values are stored corner-major (gradient.hpp): entry = corner * n_cells + cell, ascending per node
-    std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
-    for (int c = 0; c < 8; ++c)
-      for (int64_t cell = 0; cell < mesh->n_cells; ++cell)
-        adj[(size_t)fill[conn[cell * 8 + c]]++] = (int32_t)((int64_t)c * mesh->n_cells + cell);
-  }
-  // all three or none: d_fe != nullptr is the "ready" mark
-  int64_t* d_ptr = nullptr;
-  int32_t* d_adj = nullptr;
-  double* d_fe = nullptr;
-  bool ok = hipMalloc(&d_ptr, sizeof(int64_t) * (mesh->n_nodes + 1)) == hipSuccess;
-  ok = ok && hipMalloc(&d_adj, sizeof(int32_t) * ne) == hipSuccess;
-  ok = ok && hipMalloc(&d_fe, sizeof(double) * ne * 3) == hipSuccess;
-  ok = ok && upload_from_host(d_ptr, ptr.data(), sizeof(int64_t) * (mesh->n_nodes + 1), nullptr) == 0;
-  ok = ok && upload_from_host(d_adj, adj.data(), sizeof(int32_t) * ne, nullptr) == 0;
-  if (!ok) {
-    (void)hipGetLastError();
-    if (d_ptr) (void)hipFree(d_ptr);
-    if (d_adj) (void)hipFree(d_adj);
-    if (d_fe) (void)hipFree(d_fe);
-    return fail(-3, "device allocation for the mesh operators failed");
-  }
-  mesh->d_node_ptr = d_ptr; mesh->d_node_adj = d_adj; mesh->d_fe = d_fe;
-  return 0;
-}
-
-static int run_operator(int op, dxm_mesh* mesh, const double* field, int layout, const double* x, double* y, hipStream_t st) {
-  if (int rc = ensure_operator_buffers(mesh)) return rc;
-  HexOperatorArgs a{};
-  a.coords = mesh->d_coords; a.conn = mesh->d_conn; a.x = x; a.field = field; a.ncells = mesh->n_cells; a.layout = layout;
-  for (int q = 0; q < 8; ++q) {
-    for (int d = 0; d < 3; ++d) a.xi[q][d] = mesh->qp.xi[q][d];
-    a.w[q] = mesh->w[q];
-  }
-  const int blocks = (int)((mesh->n_cells + HEX_OP_CELLS - 1) / HEX_OP_CELLS);
-  if (op == OP_FORCE) hipLaunchKernelGGL(hex8_element_kernel<OP_FORCE>, dim3(blocks), dim3(256), 0, st, a, mesh->d_fe);
-  else if (op == OP_APPLY) hipLaunchKernelGGL(hex8_element_kernel<OP_APPLY>, dim3(blocks), dim3(256), 0, st, a, mesh->d_fe);
-  else hipLaunchKernelGGL(hex8_element_kernel<OP_DIAGONAL>, dim3(blocks), dim3(256), 0, st, a, mesh->d_fe);
-  hipLaunchKernelGGL(node_gather_kernel, dim3((int)((mesh->n_nodes + 255) / 256)), dim3(256), 0, st, mesh->n_nodes,
-                     mesh->d_node_ptr, mesh->d_node_adj, mesh->d_fe, y);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int dxm_mesh_internal_force_device(dxm_mesh* mesh, const double* flux_dev, double* f_dev, void* hip_stream) {
-  if (!mesh || !flux_dev || !f_dev) return fail(-1, "null argument");
-  DEVICE_GUARD(mesh);
-  return run_operator(OP_FORCE, mesh, flux_dev, 0, nullptr, f_dev, (hipStream_t)hip_stream);
-}
-
-int dxm_mesh_tangent_apply_device(dxm_mesh* mesh, const double* ct_dev, int layout, const double* x_dev, double* y_dev,
-                                  void* hip_stream) {
-  if (!mesh || !ct_dev || !x_dev || !y_dev) return fail(-1, "null argument");
-  if (layout != DXM_TANGENT_FULL && layout != DXM_TANGENT_COEF)
-    return fail(-1, "tangent layout must be DXM_TANGENT_FULL or DXM_TANGENT_COEF");
-  if (x_dev == y_dev) return fail(-1, "x and y must not alias");
-  DEVICE_GUARD(mesh);
-  return run_operator(OP_APPLY, mesh, ct_dev, layout, x_dev, y_dev, (hipStream_t)hip_stream);
-}
-
-int dxm_mesh_tangent_diagonal_device(dxm_mesh* mesh, const double* coef_dev, double* d_dev, void* hip_stream) {
-  if (!mesh || !coef_dev || !d_dev) return fail(-1, "null argument");
-  DEVICE_GUARD(mesh);
-  return run_operator(OP_DIAGONAL, mesh, coef_dev, DXM_TANGENT_COEF, nullptr, d_dev, (hipStream_t)hip_stream);
 }
 
 // kind of in-kernel gradient evaluation this mesh allows: 1 hex8 x 8 points, 2 tet4, 3 Lagrange simplex, 0 none
@@ -1836,7 +1602,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
     m->opt_packed_transfer = (int)value;
   }
   else if (k == "fused_gradient") m->opt_fused_gradient = on;
-  else if (k == "tune_verbose") m->opt_tune_verbose = on;
+  else if (k == "verbose") m->opt_verbose = on;
   else if (k == "stage_ahead") {
     if (!(value >= 1 && value <= DXM_RING - 2)) return fail(-1, "stage_ahead must be in [1, %d]", DXM_RING - 2);
     m->opt_stage_ahead = (int)value;
@@ -1858,9 +1624,6 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   } else if (k == "max_chunks") {
     if (!(value >= 1 && value <= DXM_MAX_CHUNKS)) return fail(-1, "max_chunks must be in [1, %d]", DXM_MAX_CHUNKS);
     m->opt_max_chunks = (int)value;
-  } else if (k == "tune_max_skip_bytes") {
-    if (!(value >= 0)) return fail(-1, "tune_max_skip_bytes must be >= 0");
-    m->opt_tune_max_skip = (size_t)value;
   } else if (k == "blocks_per_cu") {
     if (!(value >= 1 && value <= 256)) return fail(-1, "blocks_per_cu must be in [1, 256]");
     m->blocks_per_cu = (int)value;

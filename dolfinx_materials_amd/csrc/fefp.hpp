@@ -37,7 +37,7 @@ constexpr int F2_REC = 73;   // record stride: 54 staged doubles per point, padd
 // store covers whole lines.  With 14 points per round (the mapping's natural 2 x 7 point slots) the rounds started 112 /
 // 96 / 80 / 64 B past a line and every store instruction straddled two partial lines: an arithmetic-free kernel with this
 // kernel's streams, occupancy and compute gaps runs 1.63 ms per 1e7 points with 16-point rounds against 1.77 with 14
-// (tools/fefp_shape_probe.py, profiles/r03_fefp_shape_probe.md).  The price is a third, mostly idle, step per round
+// (tools/fefp_shape_probe.py, profiles/archive/r03_fefp_shape_probe.md).  The price is a third, mostly idle, step per round
 // (7 + 7 + 2 point slots): 12 instead of 10 tangent steps per tile.
 // (A/B knobs of the residency study, profiles/r04_fefp_third_wave_and_subwave.md: 8-point rounds cost 9 %, a 168-register budget
 // spills 78 VGPRs and costs 80 %; the defaults are what ships)
@@ -115,7 +115,7 @@ __device__ __forceinline__ void hardening(const LawParams& prm, double p, double
 //       displacement vector of a hex8 mesh with 8 Gauss points per cell / of a tet4 mesh / of a straight-sided
 //       simplex mesh with a Lagrange displacement of any order (`src`, see small_strain.hpp)
 //
-// What was measured for this kernel in round 2 (profiles/r02_fefp_ab_*.jsonl; builds side by side in one process,
+// What was measured for this kernel in round 2 (profiles/archive/r02_fefp_ab_*.jsonl; builds side by side in one process,
 // five handles each, every handle with its state placement searched: the kernel is placement-sensitive like the J2
 // one and comparisons of single un-tuned handles are dominated by that):
 //   * register diet (symmetric storage, Q = h M form of the tangent coefficients, per-tile re-derivation of the

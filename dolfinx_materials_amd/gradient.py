@@ -116,26 +116,6 @@ class Hex8Mesh(_DeviceMesh):
             raise _lib.DxmError(f"dxm_mesh_create_hex8 failed: {_lib.last_error()}")
         self._handle = h
 
-    # ---- assembly-side consumers on the device (8 Gauss points per cell; include/dxmat.h) ----------------------
-    def set_weights(self, weights):
-        w = np.ascontiguousarray(weights, dtype=np.float64)
-        if w.size != self.nqp:
-            raise ValueError(f"{self.nqp} quadrature weights expected")
-        _lib.check(self._lib.dxm_mesh_set_weights(self._handle, w.ctypes.data))
-
-    def internal_force_device(self, flux_ptr, f_ptr, stream=0):
-        """``f = sum_q w detJ B_q^T sigma_q``: stress ``(npoints, 6)`` -> nodal vector ``(n_nodes * 3)``; device pointers."""
-        _lib.check(self._lib.dxm_mesh_internal_force_device(self._handle, int(flux_ptr), int(f_ptr), int(stream) or None))
-
-    def tangent_apply_device(self, ct_ptr, x_ptr, y_ptr, layout="coef", stream=0):
-        """``y = sum_q w detJ B_q^T Ct_q B_q x`` with the tangent in the ``"coef"`` (N,9) or ``"full"`` (N,36) layout."""
-        _lib.check(self._lib.dxm_mesh_tangent_apply_device(self._handle, int(ct_ptr), {"full": 0, "coef": 2}[layout], int(x_ptr),
-                                                           int(y_ptr), int(stream) or None))
-
-    def tangent_diagonal_device(self, coef_ptr, d_ptr, stream=0):
-        """Diagonal of the operator of :meth:`tangent_apply_device` (coefficient layout)."""
-        _lib.check(self._lib.dxm_mesh_tangent_diagonal_device(self._handle, int(coef_ptr), int(d_ptr), int(stream) or None))
-
     @classmethod
     def from_dolfinx(cls, V, quadrature_degree, device=0, cells=None):
         """From a dolfinx P1 vector function space on hexahedra (``cells``: those of one ``QuadratureMap`` instead of all).  The Gauss points are basix's for

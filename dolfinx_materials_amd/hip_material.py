@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import warnings
+import weakref
 
 import numpy as np
 
@@ -49,7 +50,7 @@ class _Reaper:
     PREVIOUS call dies inside the next ``integrate`` -- and ``QuadratureMap.update`` builds a new one per call
     (``quadrature_map.py:304-313``): freeing 480 MB (1e7 points) is a 17 ms ``munmap`` (28 ms without transparent huge
     pages) on the calling thread, more than half of what the whole PCIe-bound call takes
-    (``profiles/r03_hostpath_fresh_array.md``).  The array is handed to this thread when the call that replaced it
+    (``profiles/archive/r03_hostpath_fresh_array.md``).  The array is handed to this thread when the call that replaced it
     returns: the free then runs beside whatever the caller does next (a ``munmap`` running beside the chunk pipeline
     itself slows that by 10-15 ms: it was tried)."""
 
@@ -149,16 +150,47 @@ class LazyInitialRows(LazyISV):
     ``generic.py:194-198`` -- kept on the device by ``dxm_advance`` (option ``keep_initial_io``) and downloaded when
     first looked at.  Used when the host array that held the accepted state is a bound Function that the next update
     overwrites: accepting an increment then costs a pointer swap instead of a 480 MB host copy per array (1e7 points).
-    It stands for ONE initial state: when that state is replaced (``advance`` with a new state, ``set_initial_state_dict``) a view
-    that somebody still holds or has looked at keeps its content (it is downloaded at that moment if need be), like the arrays the
-    reference hands out, which ``DataManager.update`` rebinds rather than overwrites (``generic.py:212-213``); a view nobody
-    holds is simply dropped."""
+
+    It stands for ONE initial state.  The material keeps one such object per field as its s0 mirror and never gives it away:
+    the state dictionaries hand out *views* of it (:meth:`_view`; same class, ``_parent`` set), which the mirror knows through
+    weak references.  When that state is replaced (``advance`` with a new state, ``set_initial_state_dict``) and a view is still
+    alive -- in a local, a container, a closure: whoever holds it -- the mirror downloads its rows at that moment and all its
+    views keep showing them, like the arrays the reference hands out, which are copies (``generic.py:212-213, :237-240, :265-277``);
+    with no view alive nothing is downloaded.  No reference counting is involved: the only question asked is whether a view
+    object still exists (an interpreter without prompt finalisation answers "yes" for longer: one download more, same values)."""
 
     _which = 0
 
-    def __init__(self, material, shape, kind):
+    def __init__(self, material, shape, kind, parent=None):
         super().__init__(material, shape)
         self._kind = kind
+        self._parent = parent
+        self._views = [] if parent is None else None     # weak references to the views handed out (identity only: `==` on a view is an array operation)
+
+    def _view(self):
+        """A new view of this mirror for a caller (what the state dictionaries contain)."""
+        v = type(self)(self._m, self.shape, self._kind, parent=self)
+        self._views = [r for r in self._views if r() is not None]
+        self._views.append(weakref.ref(v))
+        return v
+
+    def _handed_out(self):
+        """Whether a view given to a caller still exists."""
+        return any(r() is not None for r in self._views)
+
+    def _get(self):
+        return super()._get() if self._parent is None else self._parent._get()
+
+    def _freeze(self):
+        if self._parent is None:
+            super()._freeze()
+        else:
+            self._parent._freeze()
+
+    @property
+    def fetched(self):
+        top = self if self._parent is None else self._parent
+        return top._frozen or top._seen == top._serial()
 
     def _serial(self):
         return self._m._serial0
@@ -467,7 +499,7 @@ class HIPMaterial:
         return [p[0] for p in self._parts]
 
     def _require(self):
-        """THE handle: for the calls that belong to one GPU (device pointers, streams, graphs, placement)."""
+        """THE handle: for the calls that belong to one GPU (device pointers, streams, graphs)."""
         hs = self._handles()
         if len(hs) > 1:
             raise DxmError("this call addresses one GPU: not available for a material spread over several devices (devices=[...])")
@@ -498,13 +530,29 @@ class HIPMaterial:
             out[name] = a
         return out
 
+    def _hand_out(self, mirror):
+        """What a state dictionary shows for a gradient / flux mirror.  The reference's dictionaries hold copies
+        (``generic.py:265-277``: fancy-indexed rows of the state manager), so what goes out must not change under the caller:
+        a lazy s0 mirror goes out as a view it can count (:class:`LazyInitialRows`: downloaded only if still alive when s0 is
+        replaced); an array that a later update writes again (the material's two alternating page-locked flux buffers, a bound
+        flux or gradient array, i.e. a Function's memory) goes out as a copy; everything else -- the array the caller passed to
+        ``integrate`` (kept by reference, theirs to change), snapshots, placeholders, s1 views (which follow s1 by contract) --
+        as it is."""
+        if type(mirror) is LazyInitialRows:
+            return mirror._view()
+        if isinstance(mirror, np.ndarray) and mirror.size and mirror.strides[0] != 0:
+            bound = self._bound.get("gradient")
+            if any(mirror is b for b in self._flux_buf) or (bound is not None and np.may_share_memory(mirror, bound)):
+                return self._snapshot(mirror)
+        return mirror
+
     def get_initial_state_dict(self):
         self._handles()
-        return {self._gname: self._grad[0], self._fname: self._flux[0], **self._isv_dict(S0)}
+        return {self._gname: self._hand_out(self._grad[0]), self._fname: self._hand_out(self._flux[0]), **self._isv_dict(S0)}
 
     def get_final_state_dict(self):
-        self._handles()
-        return {self._gname: self._grad[1], self._fname: self._flux[1], **self._isv_dict(S1)}
+        self._handles()   # (after revert() the s1 mirrors ARE the s0 mirrors)
+        return {self._gname: self._hand_out(self._grad[1]), self._fname: self._hand_out(self._flux[1]), **self._isv_dict(S1)}
 
     def set_initial_state_dict(self, state):
         """``generic.py:200-201`` / ``quadrature_map.py:279,294``: any subset of the fields."""
@@ -542,21 +590,26 @@ class HIPMaterial:
                 self._chk(self._lib.dxm_set_state(h, S0, field, ptrs[0]))
 
     def _retire_initial_views(self, replaced):
-        """s0 is about to be replaced in the fields named by `replaced` (0 gradient, 1 flux): lazy views of the OLD s0 that are
-        held outside the material (or were looked at) keep what they show."""
-        import sys
-
-        refcount = getattr(sys, "getrefcount", None)   # CPython; elsewhere every live view is kept (one download each)
+        """s0 is about to be replaced in the fields named by `replaced` (0 gradient, 1 flux): if a view of the OLD s0 that a state
+        dictionary handed out is still alive, the mirror takes its rows off the device now and its views keep showing them."""
         for kind in replaced:
             v = (self._grad, self._flux)[kind][0]
-            # references of an unheld view: the mirror list, `v`, the argument of getrefcount
-            if type(v) is LazyInitialRows and not v._frozen and (v._seen == v._serial() or refcount is None or refcount(v) > 3):
+            if type(v) is LazyInitialRows and not v._frozen and v._handed_out():
                 v._freeze()
 
     def _advance(self):
         self._handles()
-        if self._serial != self.__dict__.get("_serial_of_s0"):   # an update came since the last advance / revert: s0 is replaced
-            self._retire_initial_views((0, 1))
+        # every s0 mirror that is about to be replaced settles with the views handed out of it while the device still holds its
+        # rows (after revert() the s1 mirror IS the s0 mirror and stays: nothing to settle)
+        self._retire_initial_views([kind for kind, pair in enumerate((self._grad, self._flux)) if pair[1] is not pair[0]])
+        # An s1 mirror that IS the s0 mirror stays -- but the device may be about to drop the rows it stands for: after
+        # revert() + set_initial_state_dict(...) s1 has its own storage again and brings no copies along, so dxm_advance leaves s0
+        # without any.  The mirror takes them off the device first (rare; one download).
+        for kind, pair in enumerate((self._grad, self._flux)):
+            v = pair[0]
+            if pair[1] is v and type(v) is LazyInitialRows and not v._frozen:
+                if not all(max(0, int(self._lib.dxm_io_held(h, S1))) & (1 << kind) for h, lo, hi, _dev in self._parts if hi > lo):
+                    v._freeze()
         held = 3
         for h, lo, hi, _dev in self._parts:
             self._chk(self._lib.dxm_advance(h))
@@ -564,8 +617,8 @@ class HIPMaterial:
                 held &= max(0, int(self._lib.dxm_io_held(h, S0)))
         # A bound gradient / flux array is overwritten by the next update, so the s0 mirror cannot be that array.  When
         # every handle kept its device copy (bind_* set option keep_initial_io; bit 0 gradient, bit 1 flux) the mirror is
-        # a lazy view of it, else a snapshot of the array.  Mirrors that are already such views stay (advance twice,
-        # advance after revert: s0 did not change).
+        # a lazy view of it, else a snapshot of the array.  An s1 mirror that is the s0 mirror stays (advance after revert: s0
+        # did not change).
         old = (self._grad[0], self._flux[0])
         new = []
         for kind, (cur, key) in enumerate(((self._grad[1], "gradient"), (self._flux[1], "flux"))):
@@ -583,7 +636,6 @@ class HIPMaterial:
                 new.append(self._snapshot(cur))
         self._grad[0], self._flux[0] = new
         self._serial0 += 1
-        self._serial_of_s0 = self._serial
         for a in old:   # the mirrors of the increment before: freed off this thread
             if isinstance(a, np.ndarray) and a is not self._grad[0] and a is not self._flux[0] and not any(a is b for b in self._flux_buf):
                 _reaper.drop(a)
@@ -592,10 +644,7 @@ class HIPMaterial:
     def _fetch_io_rows(self, which, kind):
         """Download the gradient (0) / flux (1) of s0 / s1 from the device copies of the last host-buffer call
         (:class:`LazyInitialRows`, :class:`LazyFinalRows`)."""
-        mirror = (self._grad, self._flux)[kind][which]
-        if not isinstance(mirror, LazyInitialRows):   # a view that outlived its state: the mirror is an ordinary array again
-            return mirror
-        out = np.empty(mirror.shape)
+        out = np.empty((self._n, int(self._info.n_flux if kind else self._info.n_grad)))
         self._run([lambda h=h, ptr=ptrs[0]: self._chk(self._lib.dxm_get_io(h, which, kind, ptr))
                    for h, lo, hi, ptrs in self._blocks(out) if hi > lo])
         return out
@@ -614,7 +663,6 @@ class HIPMaterial:
         self._grad[1] = self._grad[0]
         self._flux[1] = self._flux[0]
         self._serial += 1   # s1 changed: lazy ISV views refetch
-        self._serial_of_s0 = self._serial
 
     # ---- protocol: the hot path -----------------------------------------------------------------
     def integrate(self, gradients, dt=0):
@@ -841,59 +889,12 @@ class HIPMaterial:
         self._chk(self._lib.dxm_integrate_displacement_device(
             self._require(), mesh._handle, int(u_ptr), float(dt), int(flux_ptr), int(ct_ptr), int(stream) or None))
 
-    def tune_placement(self, grad_ptr, flux_ptr, ct_ptr, max_candidates=4):
-        """Optional, synchronous: measure the update on up to ``max_candidates`` (default 4; at most four state
-        blocks and 2 GiB of skip blocks are held meanwhile) fresh allocations of
-        the resident state with the caller's real device arrays and keep the fastest (the kernel time
-        is bimodal, up to 13 %, in where the state sits relative to those arrays: DESIGN.md section 3).
-        Acts like ``integrate_device(grad_ptr, flux_ptr, ct_ptr)``: the initial state is preserved,
-        the final state / flux / tangent are those of that update.  Returns the kernel times."""
-        before, after, tried = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
-        self._host_mirrors_left_behind()
-        self._chk(self._lib.dxm_tune_placement(self._require(), int(grad_ptr), int(flux_ptr), int(ct_ptr),
-                                               int(max_candidates), C.byref(before), C.byref(after), C.byref(tried)))
-        return {"ms_before": before.value, "ms_after": after.value, "candidates_tried": tried.value}
-
-    def time_device(self, grad_ptr, flux_ptr, ct_ptr, launches=12):
-        """Best launch time (ms) of ``launches`` updates with these device arrays (``dxm_time_device``; synchronous, acts like
-        :meth:`integrate_device`)."""
-        self._host_mirrors_left_behind()
-        ms = C.c_double(0.0)
-        self._chk(self._lib.dxm_time_device(self._require(), int(grad_ptr), int(flux_ptr), int(ct_ptr), int(launches), C.byref(ms)))
-        return ms.value
-
-    def fastest_tangent_array(self, alloc, grad_ptr, flux_ptr, candidates=8, launches=12, contrast=0.985, patience=2, tune_state=True):
-        """The caller's side of :meth:`tune_placement`: where the caller's tangent array sits decides between levels of the
-        kernels 3 % (J2), 12 % (FeFp) or 17 % (elastic) apart.  ``alloc()`` returns a newly allocated
-        device array with a ``data_ptr()`` (``lambda: torch.empty((n, 36), dtype=torch.float64, device=dev)``); up to
-        ``candidates`` are measured -- all kept alive meanwhile, so that the allocator hands out new ranges.  The level is a
-        property of the PAIRING of the resident state with the caller's arrays, so with ``tune_state`` (default) every
-        candidate is measured with the state placed for it (``tune_placement`` with its recommended budget), and the state
-        ends up placed for the array returned.  The search stops early once a contrast has been seen (best <= ``contrast`` x
-        worst) and ``patience`` candidates in a row have not improved the best by 0.5 %.  Returns ``(array, [ms, ...], index)``."""
-        stateful = tune_state and self._info.n_isv_total > 0
-        arrays, times, stale = [], [], 0
-        for _ in range(max(1, int(candidates))):
-            arrays.append(alloc())
-            ptr = arrays[-1].data_ptr()
-            if stateful:
-                self.tune_placement(grad_ptr, flux_ptr, ptr)
-            t = self.time_device(grad_ptr, flux_ptr, ptr, launches)
-            stale = 0 if (not times or t < 0.995 * min(times)) else stale + 1
-            times.append(t)
-            if stale >= patience and min(times) <= contrast * max(times):
-                break
-        k = int(np.argmin(times))
-        if stateful and k != len(arrays) - 1:
-            self.tune_placement(grad_ptr, flux_ptr, arrays[k].data_ptr())
-        return arrays[k], times, k
-
     @property
     def launch_generation(self):
         """``dxm_launch_generation``: a HIP graph that captured ``integrate_device`` /
         ``integrate_displacement_device`` of this material may be replayed only while this value equals the
         one read at capture time (``data_manager.update()`` swaps the state buffers, parameter / option
-        changes and ``tune_placement`` re-configure the launch)."""
+        changes re-configure the launch)."""
         return int(self._lib.dxm_launch_generation(self._require()))
 
     def notify_replay(self):

@@ -23,11 +23,12 @@ same job with what the engine offers:
   (``HIPMaterial.integrate_rows``); rows of other arrays are moved on several threads (``scatter_rows``);
 * NaNs are taken from the kernel's status record (``material.last_stats["n_nan"]``: stress, state AND tangent, like the
   three asserts of ``quadrature_map.py:322-324``) instead of three host passes;
-* internal state variables cross PCIe when somebody looks at them: ``isv_every_update = "lazy"`` (default) refreshes the
-  Functions on the first access to ``qmap.internal_state_variables`` / ``qmap.variables`` / ``qmap.project_on`` after an
-  ``update()`` and at ``advance()``; ``True`` writes them in every ``update()`` exactly like the reference (``:332``); ``False``
-  only at ``advance()``.  The one thing the lazy mode cannot see is a Function object taken out of the dict EARLIER and read
-  directly between ``update()`` and ``advance()`` -- such callers set ``isv_every_update = True``;
+* internal state variables: ``isv_every_update = True`` (default) writes their Functions in every ``update()`` exactly like the
+  reference (``:332``; +56 B/point over PCIe per update for J2).  Callers that read them between ``update()`` and ``advance()``
+  only through the map opt in to ``"lazy"``: the Functions are refreshed on the first access to
+  ``qmap.internal_state_variables`` / ``qmap.variables`` / ``qmap.project_on`` after an ``update()`` and at ``advance()`` -- what that
+  mode cannot see is a Function object taken out of the dict EARLIER (or captured in a compiled form) and read directly in
+  between, which is why it is not the default; ``False`` writes them at ``advance()`` only;
 * the four phases carry the reference's timer names (``"dx_mat: ..."``, ``quadrature_map.py:302-331``), so ``list_timings`` keeps
   its rows;
 * optionally the gradient is evaluated on the GPU from the displacement vector (``register_device_gradient``).
@@ -130,9 +131,10 @@ class _Plan:
 class AcceleratedUpdate:
     """Mixin: ``update / advance / initialize_state`` of ``QuadratureMap`` around a batched engine."""
 
-    #: when the internal state variables reach their Functions: ``"lazy"`` on the first access after an ``update()`` (and at
-    #: ``advance()``), ``True`` in every ``update()`` like the reference (``quadrature_map.py:332``), ``False`` at ``advance()`` only
-    isv_every_update = "lazy"
+    #: when the internal state variables reach their Functions: ``True`` (default) in every ``update()`` like the reference
+    #: (``quadrature_map.py:332``); opt-in ``"lazy"``: on the first access through the map after an ``update()`` and at ``advance()``;
+    #: ``False``: at ``advance()`` only
+    isv_every_update = True
 
     # ---- set-up, once ------------------------------------------------------------------------------------------
     def _accel_plan(self):

@@ -7,13 +7,14 @@ derivative, a PETSc SNES Newton loop with a Krylov solver (``solvers.py:31-96, :
 config 5: per Newton iteration
 
     displacement (device) --dxm_integrate_displacement_device--> stress (N,6) + tangent COEFFICIENTS (N,9)   [the hot path]
-    residual  r = sum_q w detJ B^T sigma                                                [dxm_mesh_internal_force_device]
-    K du = -r  by preconditioned conjugate gradients, K p = sum_q w detJ B^T Ct B p     [dxm_mesh_tangent_apply_device]
+    residual  r = sum_q w detJ B^T sigma                                                [libdxmfem: internal force]
+    K du = -r  by preconditioned conjugate gradients, K p = sum_q w detJ B^T Ct B p     [libdxmfem: tangent apply]
 
 so that no (N,6,6) array exists anywhere and nothing but scalars crosses PCIe.  Preconditioner: the diagonal of K
-(``dxm_mesh_tangent_diagonal_device``) or a geometric multigrid V-cycle whose coarse operators are the same matrix-free
+(``Hex8Operators.tangent_diagonal_device``) or a geometric multigrid V-cycle whose coarse operators are the same matrix-free
 kernels on coarser meshes with cell-averaged tangents (``Multigrid`` below).  Vectors are torch tensors; torch is
-plumbing (axpy, dot), the operators are the library's kernels.
+plumbing (axpy, dot); the assembly-side operators are the kernels of ``examples/csrc/dxmfem.hip`` (``fem_operators.py``), built
+beside this file -- they are not part of ``libdxmat.so``, whose scope ends with the constitutive update.
 
 Not part of the product package and not a re-implementation of dolfinx / PETSc.
 """
@@ -56,11 +57,13 @@ class Level:
     """One mesh of the hierarchy: the device mesh, its free-dof mask and the tangent it applies."""
 
     def __init__(self, n, device):
-        from dolfinx_materials_amd.gradient import Hex8Mesh
+        from fem_operators import Hex8Operators
 
         self.n = n
         coords, conn = structured_hex_mesh(n)
-        self.mesh = Hex8Mesh(coords, conn, device=device.index or 0)
+        self._coords_conn = (coords, conn)
+        self._mesh = None
+        self.ops = Hex8Operators(coords, conn, device=device.index or 0)      # examples/libdxmfem.so: the assembly-side kernels
         self.ndof = 3 * len(coords)
         self.free, _ = uniaxial_masks(n, device)
         self.device = device
@@ -69,11 +72,20 @@ class Level:
         self.wdinv = None        # damped inverse diagonal of the masked operator
         self.applies = 0
 
+    @property
+    def mesh(self):
+        """The library's mesh handle (gradient evaluation inside the update kernel): only the finest level needs one."""
+        if self._mesh is None:
+            from dolfinx_materials_amd.gradient import Hex8Mesh
+
+            self._mesh = Hex8Mesh(*self._coords_conn, device=self.device.index or 0)
+        return self._mesh
+
     def apply(self, x, out=None):
         """y = M K M x + (1 - M) x for the level's tangent (x is expected to vanish on the constrained dofs)."""
         y = torch.empty_like(x) if out is None else out
         st = torch.cuda.current_stream().cuda_stream
-        self.mesh.tangent_apply_device(self.tangent.data_ptr(), x.data_ptr(), y.data_ptr(), layout=self.layout, stream=st)
+        self.ops.tangent_apply_device(self.tangent.data_ptr(), x.data_ptr(), y.data_ptr(), layout=self.layout, stream=st)
         self.applies += 1
         y.mul_(self.free)
         return y
@@ -126,7 +138,7 @@ class Multigrid:
         for lvl in self.levels:
             d = torch.empty(lvl.ndof, dtype=torch.float64, device=self.device)
             if lvl.layout == "coef":
-                lvl.mesh.tangent_diagonal_device(lvl.tangent.data_ptr(), d.data_ptr(), st)
+                lvl.ops.tangent_diagonal_device(lvl.tangent.data_ptr(), d.data_ptr(), st)
             else:   # diagonal of a full-layout operator: probe-free, from its action on the coordinate colouring
                 d = _diagonal_by_colouring(lvl)
             d = d * lvl.free + (1.0 - lvl.free)
@@ -214,7 +226,7 @@ def _diagonal_by_colouring(lvl):
                 for comp in range(3):
                     x.zero_()
                     x[a::3, b::3, c::3, comp] = 1.0
-                    lvl.mesh.tangent_apply_device(lvl.tangent.data_ptr(), x.data_ptr(), y.data_ptr(), layout=lvl.layout, stream=st)
+                    lvl.ops.tangent_apply_device(lvl.tangent.data_ptr(), x.data_ptr(), y.data_ptr(), layout=lvl.layout, stream=st)
                     d[a::3, b::3, c::3, comp] = y.reshape(m, m, m, 3)[a::3, b::3, c::3, comp]
     return d.reshape(-1)
 
@@ -289,7 +301,7 @@ class DeviceProblem:
 
     def residual(self):
         st = torch.cuda.current_stream().cuda_stream
-        self.mesh.internal_force_device(self.flux.data_ptr(), self.r.data_ptr(), st)
+        self.fine.ops.internal_force_device(self.flux.data_ptr(), self.r.data_ptr(), st)
         self.r.mul_(self.free)
         return float(torch.linalg.vector_norm(self.r))
 
@@ -301,7 +313,7 @@ class DeviceProblem:
         def setup():
             self.fine.tangent, self.fine.layout = self.coef, "coef"
             d = torch.empty(self.ndof, dtype=torch.float64, device=self.device)
-            self.mesh.tangent_diagonal_device(self.coef.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            self.fine.ops.tangent_diagonal_device(self.coef.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream)
             return self.free / (d * self.free + (1.0 - self.free))
         return self._timed("preconditioner_setup", setup)
 

@@ -34,8 +34,9 @@
  *     and revert() only swap pointers on the host);
  *   - there is NO CPU fallback: every entry point that computes fails with a negative code when no
  *     HIP device is usable;
- *   - measurement and research entry points (placement tuning, launch timing, matrix-free assembly kernels) are declared in
- *     dxmat_experimental.h: exported by the same library, not part of this contract.
+ *   - the library exports what this header declares and nothing else (tests/test_abi.py).  The placement search and launch
+ *     timing of ABI 3-5 are gone (profiles/r05_placement_decision.md: a search rescued 4 of 12 slow leases); the matrix-free
+ *     assembly kernels of the stand-in FE loop are examples/csrc/dxmfem.hip (examples/libdxmfem.so), not product.
  */
 #ifndef DXMAT_H
 #define DXMAT_H
@@ -46,8 +47,8 @@
 extern "C" {
 #endif
 
-#define DXM_ABI_VERSION 5   /* 5: dxm_host_index_range; n_nan covers the tangent; placement tuning, launch timing and the
-                             *    assembly-side kernels moved to dxmat_experimental.h */
+#define DXM_ABI_VERSION 6   /* 6: dxm_tune_placement, dxm_time_device, the dxm_mesh_* assembly operators and the options "tune_verbose" /
+                             *    "tune_max_skip_bytes" removed (there is no dxmat_experimental.h any more); option "verbose" */
 
 /* Constitutive laws (what `behavior.constitutive_update` is in jaxmat.py:163). */
 enum {
@@ -254,7 +255,7 @@ int dxm_notify_replay(dxm_material* m);
  *                            allows (default 1)
  *   "blocks_per_cu"  1..256  grid size of the update kernel in workgroups per CU (default 32 small strain,
  *                            the resident 2 for FeFp)
- *   (dxmat_experimental.h adds "tune_verbose" and "tune_max_skip_bytes") */
+ *   "verbose"        0 | 1   host-buffer form: log the chunk timeline, page-locking and upload-mode decisions to stderr (default 0) */
 int dxm_set_option(dxm_material* m, const char* name, double value);
 /* get_initial_state_dict / get_final_state_dict without a device array of the caller: packs the
  * user-visible ISVs of state `which` and downloads them into host memory (npoints, n_isv_total).  This is

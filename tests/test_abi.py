@@ -22,28 +22,31 @@ def test_header_and_binding_declare_the_same_symbols():
     syms = header_symbols()
     assert len(syms) >= 20
     assert syms == sorted(_lib.SYMBOLS)
-    exp = header_symbols("dxmat_experimental.h")
-    assert exp == sorted(_lib.EXPERIMENTAL_SYMBOLS) and not set(exp) & set(syms)
-    # the contract does not mention the lab equipment
-    core_text = open(os.path.join(ROOT, "include", "dxmat.h")).read()
-    for name in exp:
-        assert name not in core_text, name
+    # one header, one contract: the "experimental" side door of ABI 3-5 (placement search, launch timing, assembly kernels) is gone
+    assert os.listdir(os.path.join(ROOT, "include")) == ["dxmat.h"] and not hasattr(_lib, "EXPERIMENTAL_SYMBOLS")
 
 
 def test_library_exports_every_header_symbol():
     lib = _lib.load()
-    for s in header_symbols() + header_symbols("dxmat_experimental.h"):
+    for s in header_symbols():
         assert hasattr(lib, s), s
-    assert lib.dxm_abi_version() == 5
+    assert lib.dxm_abi_version() == 6
 
 
-def test_library_exports_nothing_else():
-    """Every dxm_* symbol the shared object exports is declared in one of the two headers."""
+def test_library_exports_the_header_and_nothing_else():
+    """`nm -D libdxmat.so` = the list of include/dxmat.h: no assembly kernels (FEM
+    assembly stays on the host; the stand-in loop's operators are examples/libdxmfem.so), no measurement helpers."""
     import subprocess
 
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "dolfinx_materials_amd", "libdxmat.so")], capture_output=True, text=True).stdout
     exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r"\sT\s+dxm_", ln)})
-    assert exported == sorted(header_symbols() + header_symbols("dxmat_experimental.h"))
+    assert exported == header_symbols()
+    for gone in ("dxm_tune_placement", "dxm_time_device", "dxm_mesh_internal_force_device", "dxm_mesh_tangent_apply_device",
+                 "dxm_mesh_tangent_diagonal_device", "dxm_mesh_set_weights"):
+        assert gone not in exported
+    # nothing else with C linkage slips out either: every defined text symbol is a dxm_* entry point or C++-mangled / runtime glue
+    other = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r"\sT\s+(?!dxm_|_Z|_init|_fini|__)", ln)})
+    assert other == [], other
 
 
 def test_law_table():

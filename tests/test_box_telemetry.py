@@ -5,6 +5,7 @@ The module sits on bench.py's critical path: nothing it does may raise."""
 import json
 import os
 import stat
+import subprocess
 import sys
 import time
 
@@ -132,3 +133,45 @@ def test_nothing_raises_where_nothing_exists(tmp_path, monkeypatch):
     s.stop()
     assert s.summary()["samples"] == 0
     assert bt.fast_read(str(tmp_path / "nothing"))["sclk"] is None
+
+
+def test_smi_tools_are_never_started_under_a_profiler_and_never_through_env(tmp_path, monkeypatch):
+    """`rocm-smi` is a `#!/usr/bin/env python3` script.  Under `rocprofv3 --pmc -- python3 bench.py` a child
+    would inherit the profiler's preload, initialise the GPU inside `env`, and `env` would exec python3 -- the exec that takes a
+    box of this pool down.  `_tool` refuses under a profiler, strips the profiler's variables otherwise, and starts a script with
+    this interpreter on its real path (no `env` hop)."""
+    import box_telemetry as bt
+
+    script = tmp_path / "fake-smi"
+    script.write_text("#!/usr/bin/env python3\nimport json, os, sys\n"
+                      "print(json.dumps({'argv0': sys.argv[0], 'exe': sys.executable, 'args': sys.argv[1:],\n"
+                      "                  'leaked': sorted(k for k in os.environ if k.startswith(('ROCP', 'HSA_TOOLS')))}))\n")
+    script.chmod(0o755)
+    link = tmp_path / "smi-link"
+    link.symlink_to(script)
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
+        monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    monkeypatch.setenv("HSA_TOOLS_LIB", "librocprofiler-sdk-tool.so")      # what a profiler leaves for its children
+    seen = {}
+    real_run = subprocess.run
+
+    def spy(argv, **kw):
+        seen["argv"], seen["env"] = list(argv), kw.get("env")
+        return real_run(argv, **kw)
+
+    monkeypatch.setattr(bt.subprocess, "run", spy)
+    rc, out, err = bt._tool([str(link), "--showmetrics"])
+    assert rc == 0, err
+    rec = json.loads(out)
+    assert seen["argv"][:2] == [sys.executable, str(script)] and rec["args"] == ["--showmetrics"]    # interpreter + real path: no env, no shebang
+    assert rec["leaked"] == [] and "HSA_TOOLS_LIB" not in seen["env"]
+    for var, val in (("ROCPROFILER_LIBRARY", "x"), ("ROCP_TOOL_LIBRARIES", "x"), ("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")):
+        monkeypatch.setenv(var, val)
+        seen.clear()
+        assert bt.under_profiler()
+        rc, out, err = bt._tool([str(link), "--showmetrics"])
+        assert rc is None and out == "" and "profiler" in err and not seen       # nothing was started
+        assert "error" in bt._json_tool([str(link)]) and "error" in (bt.metrics() if os.path.exists(bt.ROCM_SMI) else {"error": 1})
+        monkeypatch.delenv(var)
+    assert not bt.under_profiler()

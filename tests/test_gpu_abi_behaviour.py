@@ -180,67 +180,6 @@ def test_several_handles_side_by_side():
         m.close()
 
 
-def test_tune_placement_preserves_state_and_results():
-    """dxm_tune_placement moves the resident state to another allocation: results before and after
-    must be bit-identical, s0 preserved, and it acts like one integrate_device."""
-    torch = pytest.importorskip("torch")
-    from helpers import E, NU, SIG0_V, SIGU_V, B_V, j2_history
-
-    dev = torch.device("cuda:0")
-    n = 200_003
-    h = j2_history(n, sig0=SIG0_V)
-    mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V)))
-    mat.set_data_manager(n)
-    st = torch.cuda.current_stream().cuda_stream
-    g = [to_device(x) for x in h[:3]]
-    flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
-    ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
-    mat.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
-    mat.data_manager.update()
-    mat.integrate_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
-    torch.cuda.synchronize()
-    ref_flux, ref_ct = flux.clone(), ct.clone()
-    s0_before = mat.get_initial_state_dict()
-    s1_before = mat.get_final_state_dict()
-    flux.zero_()
-    ct.zero_()
-    free_before = torch.cuda.mem_get_info()[0]
-    info = mat.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=3)
-    assert info["candidates_tried"] >= 1 and info["ms_after"] <= info["ms_before"] * 1.0001
-    assert abs(torch.cuda.mem_get_info()[0] - free_before) <= (4 << 20)   # losers and the replaced block are freed
-    torch.cuda.synchronize()
-    assert torch.equal(flux, ref_flux) and torch.equal(ct, ref_ct)       # acts like integrate_device
-    s0_after, s1_after = mat.get_initial_state_dict(), mat.get_final_state_dict()
-    for k in s0_before:   # (gradient / flux mirrors of a device-pointer state are NaN placeholders)
-        assert np.array_equal(s0_before[k], s0_after[k], equal_nan=True)
-    for k in s1_before:
-        assert np.array_equal(s1_before[k], s1_after[k], equal_nan=True)
-    rc, stats = mat.stats()
-    assert rc == 0 and stats["n_plastic"] > 0
-    # the handle keeps working on the new block: advance + next increment against the oracle-free identity
-    mat.data_manager.update()
-    mat.integrate_device(g[2].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
-    torch.cuda.synchronize()
-    other = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V)))
-    other.set_data_manager(n)
-    f2, c2 = torch.empty_like(flux), torch.empty_like(ct)
-    for k in range(3):
-        other.integrate_device(g[k].data_ptr(), f2.data_ptr(), c2.data_ptr(), st)
-        if k < 2:
-            other.data_manager.update()
-    torch.cuda.synchronize()
-    assert torch.equal(flux, f2) and torch.equal(ct, c2)
-    with pytest.raises(_lib.DxmError):
-        mat.tune_placement(0, flux.data_ptr(), ct.data_ptr())          # null gradient pointer
-    with pytest.raises(_lib.DxmError):
-        mat.tune_placement(g[1].data_ptr() + 8, flux.data_ptr(), ct.data_ptr())   # not 16-byte aligned
-    assert mat.tune_placement(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), max_candidates=0)["candidates_tried"] == 0
-    # no state, nothing to place
-    el = JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU)))
-    el.set_data_manager(1000)
-    assert el.tune_placement(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr())["candidates_tried"] == 0
-
-
 def test_plain_c_host_runs():
     """examples/c_host/j2_batch.c: the constitutive update driven from C through include/dxmat.h only; exits 0 when
     four load steps match the closed-form radial return to 1e-10."""
@@ -284,38 +223,3 @@ def test_pageable_output_arrays_are_filled_through_the_staging_path(law, n):
     assert lib.dxm_get_state(b._handle, 1, 0, p.ctypes.data) == 0 and np.array_equal(p[:, 0], isv[:, 0])
 
 
-def test_time_device_and_the_tangent_array_search_act_like_an_update():
-    """`dxm_time_device` / `HIPMaterial.fastest_tangent_array`: the caller's side of the placement search.  They run the update
-    with the candidate arrays (s0 preserved, results those of the update) and hand back one of the arrays they were given."""
-    torch = pytest.importorskip("torch")
-    from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
-
-    dev = torch.device("cuda:0")
-    n = 300_001
-    h = j2_history(n)
-    mat = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)))
-    mat.set_data_manager(n)
-    st = torch.cuda.current_stream().cuda_stream
-    g = [to_device(x) for x in h[:2]]
-    flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
-    ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
-    mat.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
-    mat.data_manager.update()
-    mat.integrate_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
-    torch.cuda.synchronize()
-    ref_flux, ref_ct, s0 = flux.clone(), ct.clone(), mat.get_initial_state_dict()
-    ms = mat.time_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), launches=5)
-    assert 0.0 < ms < 50.0
-    made = []
-
-    def alloc():
-        made.append(torch.zeros((n, 36), dtype=torch.float64, device=dev))
-        return made[-1]
-
-    best, times, k = mat.fastest_tangent_array(alloc, g[1].data_ptr(), flux.data_ptr(), candidates=4, launches=4)
-    assert 1 <= len(times) <= 4 and len(made) == len(times) and best is made[k] and times[k] == min(times)
-    assert torch.equal(best, ref_ct) and torch.equal(flux, ref_flux)          # every candidate received the update's tangent
-    for name, a in mat.get_initial_state_dict().items():
-        assert np.array_equal(np.asarray(a), np.asarray(s0[name]), equal_nan=True), name
-    assert mat._lib.dxm_time_device(mat._handles()[0], None, None, None, 3, None) < 0
-    mat.close()

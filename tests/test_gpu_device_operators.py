@@ -1,7 +1,7 @@
-"""GPU: the assembly-side consumers on the device (dxm_mesh_internal_force_device / _tangent_apply_device /
-_tangent_diagonal_device; what dolfinx assembly does with the quadrature Functions, tests/uniaxial_tension.py:62-67,
-quadrature_map.py:132-158) against a numpy evaluation on distorted hex8 meshes and against the block-CSR matrix of the
-stand-in host FE loop."""
+"""GPU: the assembly-side consumers on the device of the stand-in FE loop (examples/libdxmfem.so through
+examples/fem_operators.py: internal force / tangent apply / tangent diagonal; what dolfinx assembly does with the quadrature
+Functions, tests/uniaxial_tension.py:62-67, quadrature_map.py:132-158) against a numpy evaluation on distorted hex8 meshes and
+against the block-CSR matrix of the stand-in host FE loop.  Example code, not product: libdxmat.so holds none of it."""
 import os
 import sys
 
@@ -9,12 +9,14 @@ import numpy as np
 import pytest
 
 from dolfinx_materials_amd.conventions import tangent_from_coefficients
-from dolfinx_materials_amd.gradient import Hex8Mesh, gauss_points_hex
+from dolfinx_materials_amd.gradient import gauss_points_hex
 
 pytestmark = pytest.mark.gpu
 from helpers import to_device, to_host  # noqa: E402,F401
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+from fem_operators import Hex8Operators  # noqa: E402
+
 S = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
 R2 = np.sqrt(2.0)
 
@@ -84,7 +86,7 @@ def test_force_apply_and_diagonal_match_numpy_on_a_distorted_mesh(n):
     m, coords, conn, coef, rng = _case(n, seed=n)
     g, wdet = shape_gradients(coords, conn, gauss_points_hex(2))
     nn = len(coords)
-    mesh = Hex8Mesh(coords, conn)
+    mesh = Hex8Operators(coords, conn)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     sig = rng.standard_normal((len(conn) * 8, 6))
@@ -127,7 +129,7 @@ def test_apply_equals_the_assembled_block_csr_matrix_of_the_host_loop():
     sig = rng.standard_normal((m.num_cells * 8, 6))
     r, K = m.assemble(sig, coef, m.B_eps, "coef")
     x = rng.standard_normal(m.ndof)
-    mesh = Hex8Mesh(m.coords, m.conn.astype(np.int32))
+    mesh = Hex8Operators(m.coords, m.conn.astype(np.int32))
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     d_sig, d_x, d_coef = (to_device(a) for a in (sig, x, coef))
@@ -144,11 +146,25 @@ def test_apply_equals_the_assembled_block_csr_matrix_of_the_host_loop():
     assert np.abs(to_host(y) - K.diagonal()).max() < 1e-12 * K.diagonal().max()
 
 
-def test_operators_need_eight_points_per_cell():
-    from dolfinx_materials_amd import _lib
+def test_operators_need_eight_points_per_cell_and_real_arrays():
     from hex_fem import HexMesh
 
     m = HexMesh(2)
-    mesh = Hex8Mesh(m.coords, m.conn.astype(np.int32), qpoints=gauss_points_hex(4))
-    with pytest.raises(_lib.DxmError, match="8 Gauss points"):
-        mesh.internal_force_device(8, 8)
+    with pytest.raises(ValueError, match="8 Gauss points"):
+        Hex8Operators(m.coords, m.conn.astype(np.int32), qpoints=gauss_points_hex(4))
+    ops = Hex8Operators(m.coords, m.conn.astype(np.int32))
+    with pytest.raises(RuntimeError, match="null argument"):
+        ops.internal_force_device(0, 0)
+    with pytest.raises(RuntimeError, match="must not alias"):
+        ops.tangent_apply_device(8, 16, 16)
+    with pytest.raises(ValueError, match="out of range"):
+        Hex8Operators(m.coords, m.conn.astype(np.int32) + 1000)
+
+
+def test_the_product_library_exports_no_assembly_kernels():
+    """assembly stays on the host; what runs on the device in examples/ comes from examples/libdxmfem.so."""
+    from dolfinx_materials_amd import _lib
+
+    lib = _lib.load()
+    for name in ("dxm_mesh_internal_force_device", "dxm_mesh_tangent_apply_device", "dxm_mesh_tangent_diagonal_device", "dxm_mesh_set_weights"):
+        assert not hasattr(lib, name), name

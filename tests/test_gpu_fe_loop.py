@@ -99,3 +99,65 @@ def test_two_materials_on_disjoint_cells_in_the_newton_loop(device_gradient):
         if len(n_) >= 3 and n_[-2] < 1e-2 * n_[0]:
             assert n_[-1] < 1e-3 * n_[-2]          # the consistent tangent from both maps: quadratic tail
     assert two["history"][-1]["sxx_inclusion"] > 1.5 * two["history"][-1]["sxx_matrix"] and two["history"][-1]["p_max"] > 0
+
+
+# ---- BASELINE.json configs[4] at the sizes it names (the stand-in FE loops of examples/; dolfinx itself is not in this image) ----------
+def _closed_form(out_E, sig0, H, exx):
+    """Homogeneous uniaxial stress: elastic E eps below yield, then sigma_xx = (sig0 + H eps) / (1 + H / E)."""
+    return min(out_E * exx, (sig0 + H * exx) / (1 + H / out_E))
+
+
+def _check_host_loop(out, max_iters=3):
+    for step in out["history"]:
+        expect = _closed_form(out["E"], out["sig0"], out["H"], step["exx"])
+        assert abs(step["sxx"] - expect) < 1e-9 * expect, step
+        assert step["sxx_spread"] < 1e-6 and 1 <= step["iters"] <= max_iters and step["norms"][-1] < 1e-8, step
+        assert abs(step["p"] - (step["exx"] - expect / out["E"])) < 1e-11
+    return sum(step["iters"] for step in out["history"])
+
+
+def test_cfg5_host_assembly_loop_at_32_cubed():
+    """`tests/uniaxial_tension.py:11-118` in 3-D with HOST assembly (examples/hex_fem.py: block-CSR tangent from the nine tangent
+    coefficients, multigrid-CG) and the GPU constitutive update with the strain evaluated on the device: 32^3 hexahedra =
+    262 144 Gauss points, 8 load steps; closed form to 1e-9 at every step, at most 3 Newton iterations per step."""
+    from uniaxial_tension_3d import run
+
+    out = run(n=32, steps=8, law="j2_linear", verbose=False, solver="krylov", layout="coef", device_gradient=True)
+    assert out["points"] == 32 ** 3 * 8 and out["ndof"] == 3 * 33 ** 3
+    total = _check_host_loop(out)
+    assert 8 <= total <= 20
+
+
+@pytest.mark.skipif(os.environ.get("DXM_TEST_CFG5_HOST_64") != "1", reason="opt-in (DXM_TEST_CFG5_HOST_64=1): 64^3 host assembly takes ~3 minutes")
+def test_cfg5_host_assembly_loop_at_64_cubed():
+    from uniaxial_tension_3d import run
+
+    out = run(n=64, steps=8, law="j2_linear", verbose=False, solver="krylov", layout="coef", device_gradient=True)
+    assert out["points"] == 64 ** 3 * 8
+    _check_host_loop(out)
+
+
+def test_cfg5_device_resident_loop_at_its_stated_size_200_cubed():
+    """BASELINE.json configs[4] names a 200^3 hex mesh with quad_degree 2: 8e6 cells, 6.4e7 Gauss points, 2.44e7 dofs.  The
+    device-resident stand-in loop (examples/device_fem.py: constitutive update by libdxmat.so from the displacement vector,
+    matrix-free residual / tangent operator of examples/libdxmfem.so, multigrid-preconditioned CG) runs it in ~10 s and ~31 GB of
+    HBM: 8 load steps to eps_xx = 2 %, closed form to 1e-9, every Gauss point plastic from step 2 on, at most 3 Newton iterations
+    per step (the linear predictor is exact for the homogeneous solution)."""
+    import torch
+
+    from uniaxial_tension_3d_device import run
+
+    free_b, _total = torch.cuda.mem_get_info(0)
+    if free_b < 40e9:
+        pytest.skip(f"needs ~31 GB of HBM, {free_b / 1e9:.0f} GB free")
+    out = run(n=200, steps=8, preconditioner="mg", verbose=False)
+    assert out["points"] == 64_000_000 and out["ndof"] == 3 * 201 ** 3 and out["levels"] >= 3
+    assert out["rel_err"] < 1e-9 and out["sxx_spread"] < 1e-4 and out["other_components_max"] < 1e-4
+    E, sig0, H = 70e3, 250.0, 5e3
+    for step in out["history"]:
+        expect = _closed_form(E, sig0, H, step["exx"])
+        assert abs(step["sxx"] - expect) < 1e-9 * expect, step
+        assert 1 <= step["iters"] <= 3 and step["norms"][-1] < 1e-7, step
+    assert 8 <= out["newton_iterations"] <= 16
+    assert out["constitutive_share_of_iteration"] < 0.05       # the update is not what such a loop waits for
+    assert 20 < out["hbm_GiB_allocated_peak"] < 60

@@ -74,7 +74,28 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     ey = SIG0_V / (2 * mu) * np.sqrt(2.0 / 3.0)
     eps = np.zeros((n, 6))
     held = None           # (isv object of an earlier integrate, what it must show when looked at)
-    ops = rng.choice(["integrate", "integrate", "integrate", "update", "revert", "get", "set", "look", "device", "tune", "prop"], size=48)
+    ops = rng.choice(["integrate", "integrate", "integrate", "update", "update", "revert", "get", "set", "look", "device", "device", "prop",
+                      "hold", "hold", "drop"], size=64)
+    # state dictionaries taken at random steps and KEPT (in a list, in a dict under their id(), inside a closure): each must go on
+    # showing the state it was taken from whatever happens to the material afterwards (the reference's dictionaries are copies,
+    # generic.py:265-277) -- hip_material.LazyInitialRows views, copies of the alternating flux buffers
+    handouts, by_id, closures = [], {}, []
+
+    def keep(got, want, how):
+        if how == 0:
+            handouts.append((got, want))
+        elif how == 1:
+            by_id[id(got)] = (got, want)
+        else:
+            closures.append(lambda got=got, want=want: (got, want))
+
+    def kept():
+        return handouts + list(by_id.values()) + [c() for c in closures]
+
+    def check_kept():
+        for got, want in kept():
+            for name, ref_rows in want.items():
+                assert np.array_equal(np.asarray(got[name]).reshape(ref_rows.shape), ref_rows), name
     known = {"initial": False, "final": False}   # whether the host-side stress mirror of s0 / s1 is meaningful
     import torch
 
@@ -103,17 +124,13 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
             assert m.last_stats["n_plastic"] == ref["n_plastic"] and m.last_stats["n_nan"] == 0
             held = isv
             known["final"] = True
-        elif op in ("device", "tune"):
-            # device-pointer forms: asynchronous launch on torch's stream / the placement search (which acts like one
-            # integrate_device and may move the resident state to another allocation)
+        elif op == "device":
+            # device-pointer form: asynchronous launch on torch's stream
             d = rng.standard_normal((n, 6))
             eps = 0.6 * eps + d * (rng.uniform(0, 3.0, n) * ey / np.linalg.norm(d, axis=1))[:, None]
             d_eps = to_device(eps)
             st = torch.cuda.current_stream().cuda_stream
-            if op == "device":
-                m.integrate_device(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr(), st)
-            else:
-                m.tune_placement(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr(), max_candidates=3)
+            m.integrate_device(d_eps.data_ptr(), d_flux.data_ptr(), d_ct.data_ptr(), st)
             torch.cuda.synchronize()
             ref = model.integrate(eps)
             scale = max(np.abs(ref["sig"]).max(), SIG0_V)
@@ -150,12 +167,34 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
             ep[:, :3] -= ep[:, :3].mean(axis=1, keepdims=True)
             m.set_initial_state_dict({"p": p, "epsp": ep})
             model.s0["p"], model.s0["epsp"] = p.copy(), ep.copy()
+        elif op == "hold":
+            which = "initial" if rng.random() < 0.7 else "final"
+            getter = m.get_initial_state_dict if which == "initial" else m.get_final_state_dict
+            names = ["p", "epsp"] + (["stress", "strain"] if known[which] else [])
+            got, twin = getter(), getter()          # two dictionaries of one state: one kept, one looked at now and thrown away
+            want = {k: np.array(np.asarray(twin[k])) for k in names}
+            del twin
+            st = model.s0 if which == "initial" else model.s1
+            for k in names:
+                assert close(want[k], st[k].reshape(want[k].shape), max(np.abs(st[k]).max(), SIG0_V if k == "stress" else 1e-300) + 1e-30), (which, k)
+            if rng.random() < 0.5:                  # some kept dictionaries are looked at when taken, some only later
+                assert all(np.array_equal(np.asarray(got[k]), want[k]) for k in names)
+            keep({k: got[k] for k in names}, want, int(rng.integers(0, 3)))
+        elif op == "drop":
+            for bag in (handouts, closures):
+                if bag and rng.random() < 0.5:
+                    bag.pop(int(rng.integers(0, len(bag))))
+            if by_id and rng.random() < 0.5:
+                by_id.pop(next(iter(by_id)))
         elif op == "look" and held is not None and lazy:
             # a lazy ISV array is a VIEW of s1 as it is NOW (hip_material.LazyISV); the eager one is a snapshot
             a = np.asarray(held)
             assert a.shape == (n, 7)
             assert close(a[:, 0], model.s1["p"], max(model.s1["p"].max(), 1e-300) + 1e-30)
             assert close(a[:, 1:], model.s1["epsp"], max(np.abs(model.s1["epsp"]).max(), 1e-300) + 1e-30)
+        if op in ("update", "integrate", "set", "revert"):
+            check_kept()
+    check_kept()
     m.close()
 
 

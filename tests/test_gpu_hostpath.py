@@ -186,6 +186,94 @@ def test_bound_arrays_keep_the_initial_gradient_and_flux_on_the_device():
     m.close()
 
 
+def test_views_of_the_initial_state_keep_their_content_however_they_are_held():
+    """A state dictionary's lazy strain / stress keeps showing the state it was taken from across later `update(); advance()`
+    cycles -- held in a local, in a list, in a closure, in a dict under its id() -- like the copies the reference's dictionaries
+    hold (generic.py:212-213, :237-240, :265-277).  Whether a view is still held is asked of weak references, not of reference
+    counts; a dictionary nobody kept costs no download when its state is replaced."""
+    import gc
+    import weakref
+
+    from dolfinx_materials_amd.hip_material import LazyInitialRows
+
+    n = 50_001
+    m = _j2()
+    m.set_data_manager(n)
+    flux_fn, jac_fn, grad_fn = np.zeros(n * 6), np.zeros(n * 36), np.zeros(n * 6)
+    m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+    m.bind_inputs(gradient=grad_fn)
+    rows = grad_fn.reshape(n, 6)
+    h = j2_history(n, seed=33)
+    downloads = []
+    fetch = m._fetch_io_rows
+    m._fetch_io_rows = lambda which, kind: (downloads.append((which, kind)), fetch(which, kind))[1]
+
+    def cycle(k):
+        rows[...] = h[k]
+        f = np.array(m.integrate(rows)[0])
+        m.data_manager.update()
+        return f
+
+    f0 = cycle(0)
+    local = m.get_initial_state_dict()["stress"]                      # (i) a local
+    bag = [m.get_initial_state_dict()["stress"]]                      # (ii) a list
+
+    def closed_over():
+        v = m.get_initial_state_dict()["stress"]
+        return lambda: v
+
+    inside = closed_over()                                            # (iii) a closure
+    v = m.get_initial_state_dict()["strain"]
+    book = {id(v): v}                                                 # (iv) known to the caller by its id() only
+    del v
+    gone = weakref.ref(m.get_initial_state_dict()["stress"])          # (v) a weak reference holds nothing
+    gc.collect()
+    assert all(isinstance(x, LazyInitialRows) and not x.fetched for x in (local, bag[0], inside(), *book.values())) and not downloads
+    f1 = cycle(1)                                                     # s0 replaced: the views above settle now ...
+    assert sorted(downloads) == [(0, 0), (0, 1)]                      # ... with ONE download per field, shared by its views
+    f2 = cycle(2)
+    assert len(downloads) == 2 and gone() is None
+    for x in (local, bag[0], inside()):
+        assert np.array_equal(np.asarray(x), f0) and x.fetched
+    assert np.array_equal(np.asarray(next(iter(book.values()))), h[0])
+    assert np.array_equal(np.asarray(m.get_initial_state_dict()["stress"]), f2) and not np.array_equal(f0, f2) and not np.array_equal(f1, f2)
+    # dictionaries that were looked at and dropped, or never kept: nothing is downloaded when their state goes
+    n_before = len(downloads)
+    assert np.array_equal(np.asarray(m.get_initial_state_dict()["strain"]), h[2])
+    m.get_initial_state_dict()
+    gc.collect()
+    n_looked = len(downloads)
+    assert n_looked == n_before + 1
+    f3 = cycle(3)
+    assert len(downloads) == n_looked
+    # after revert the final state shows the initial one: its dictionary entries are views of the same kind
+    rows[...] = h[0]
+    m.integrate(rows)
+    m.data_manager.revert()
+    fin = m.get_final_state_dict()["stress"]
+    assert isinstance(fin, LazyInitialRows) and np.array_equal(np.asarray(fin), f3)
+    # set_initial_state_dict replaces s0 as well: a held view of the state before keeps it
+    keep = m.get_initial_state_dict()["strain"]
+    m.set_initial_state_dict({"strain": np.full((n, 6), 2.0)})
+    assert np.array_equal(np.asarray(m.get_initial_state_dict()["strain"]), np.full((n, 6), 2.0))
+    rows[...] = h[1]
+    m.integrate(rows)                         # overwrites the bound arrays
+    m.data_manager.update()
+    assert np.array_equal(np.asarray(keep), h[3]) and np.array_equal(np.asarray(fin), f3)
+    # the unbound form: the material's two alternating flux buffers go out as copies
+    m2 = _j2()
+    m2.set_data_manager(n)
+    g0 = np.array(m2.integrate(h[0])[0])
+    m2.data_manager.update()
+    kept_s0, kept_s1 = m2.get_initial_state_dict()["stress"], m2.get_final_state_dict()["stress"]
+    for k in (1, 2, 3):
+        m2.integrate(h[k])
+        m2.data_manager.update()
+    assert np.array_equal(kept_s0, g0) and np.array_equal(kept_s1, g0)
+    m2.close()
+    m.close()
+
+
 @pytest.mark.parametrize("kind,n,total,devices", [("linear", 300_007, 700_000, None), ("voce", 70_001, 70_001, None), ("linear", 1, 5, None),
                                                   ("linear", 150_003, 200_000, [0, 0, 0])])
 def test_integrate_rows_delivers_every_point_into_its_row(kind, n, total, devices):
@@ -324,7 +412,7 @@ def test_options_replace_environment_variables():
     m.set_data_manager(1000)
     g0 = m.launch_generation
     for name, value in (("pipeline", 0), ("packed_transfer", 0), ("host_threads", 2), ("max_chunks", 4), ("fused_gradient", 0),
-                        ("blocks_per_cu", 8), ("tune_verbose", 0)):
+                        ("blocks_per_cu", 8), ("verbose", 0)):
         m.set_option(name, value)
     assert m.launch_generation > g0
     sig = m.integrate(j2_history(1000)[2])[0].copy()

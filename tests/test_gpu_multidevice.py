@@ -108,7 +108,7 @@ def test_field_map_on_a_multi_device_material_binds_and_matches():
 def test_calls_that_belong_to_one_gpu_say_so():
     m = JAXMaterial(_beh("linear"), devices=[0, 0])
     m.set_data_manager(100)
-    for call in (lambda: m.integrate_device(0, 0, 0), lambda: m.tune_placement(0, 0, 0), lambda: m.launch_generation,
+    for call in (lambda: m.integrate_device(0, 0, 0), lambda: m.launch_generation,
                  lambda: m.stats(), lambda: m.isv_device(1, 0)):
         with pytest.raises(DxmError, match="one GPU"):
             call()

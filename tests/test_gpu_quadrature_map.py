@@ -106,6 +106,7 @@ def test_bound_map_delivers_into_the_fields_memory_and_fetches_isvs_when_looked_
     now = {"g": hist[1]}
     m = JAXMaterial(_behavior("j2_linear"))
     q = QuadratureFieldMap(ncell, nqp, m)
+    q.isv_every_update = "lazy"   # opt-in (the default writes the ISV Functions in every update like the reference)
     q.register_gradient("strain", lambda c: now["g"].reshape(ncell, nqp, 6)[c].reshape(-1, 6))
     q.update()
     assert q._bound and set(m._bound) == {"flux", "tangent", "gradient", "isv:p", "isv:epsp"}

@@ -160,8 +160,9 @@ def test_bench_under_the_drivers_launcher(gpu_available):
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-    env.update(DXM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (HSA_ENABLE_IPC_MODE_LEGACY is taken OUT of the environment: the driver's launcher will not set it; bench.py::main does, for every rank)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    env.update(DXM_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
                         "--points", "200000", "--cfg3-points", "20000", "--cpu-sample", "100000", "--gather-steps", "1", "--settle-seconds", "0.1"],
@@ -173,6 +174,11 @@ def test_bench_under_the_drivers_launcher(gpu_available):
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["value"] > 0
     pg = out["process_group"]
     assert pg["ranks_counted_by_all_reduce"] == 2 and pg["launcher"] == "torch.distributed.run" and pg["share_gpu_debug_mode"]
+    assert pg["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # one HBM budget line per rank on stderr, before anything is allocated (headline + cfg3 block)
+    budget = [json.loads(l.split("] ", 1)[1]) for l in r.stderr.splitlines() if l.startswith("[bench.py hbm budget] ")]
+    assert sorted(b["rank"] for b in budget) == [0, 1] and all(set(b["blocks_GB"]) == {"headline", "cfg3"} for b in budget)
+    assert all(0 < b["largest_block_GB"] < 0.9 * b["hbm_free_GB"] for b in budget)
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0 and "error" not in out["cfg3"]
 
 
@@ -258,8 +264,8 @@ def test_gather_legs_run_through_rccl_itself_in_a_group_of_one(gpu_available):
     in a process group of one rank -- what a 1-GPU box can verify of the N > 1 data path before an 8-GPU node runs it."""
     if not gpu_available:
         pytest.skip("no GPU")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "DXM_BENCH_SHARE_GPU")}
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "DXM_BENCH_SHARE_GPU",
+                                                            "HSA_ENABLE_IPC_MODE_LEGACY")}   # (bench.py::main sets it itself)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-rank-group", "--points", "300000",
                         "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-other-laws", "--no-host-path", "--no-live-traffic",
                         "--gather-steps", "2"], env=env, capture_output=True, text=True, timeout=900)
@@ -267,6 +273,7 @@ def test_gather_legs_run_through_rccl_itself_in_a_group_of_one(gpu_available):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     pg, g = out["process_group"], out["gather_inclusive"]
     assert pg["backend"] == "nccl" and pg["ranks_in_group"] == 1 and pg["ranks_counted_by_all_reduce"] == 1
+    assert pg["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert "error" not in g and g["value"] > 0
     assert "error" not in g["p2p_schedule"] and g["p2p_schedule"]["value"] > 0
     assert "error" not in g["coefficient_gather"] and g["coefficient_gather"]["value"] > 0

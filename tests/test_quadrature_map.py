@@ -128,8 +128,9 @@ def test_accelerated_update_equals_the_reference_cadence(material, subset):
 
 
 def test_internal_state_variables_follow_isv_every_update():
-    """"lazy" (default): the Functions are refreshed by the first access to the dict after an update; False: at advance only
-    (the held Function object stays stale until then); True: in every update (quadrature_map.py:332)."""
+    """True (default): in every update, like the reference (quadrature_map.py:332) -- also a Function object taken out of the dict
+    earlier is current after update(); "lazy" (opt-in): the Functions are refreshed by the first access to the dict after an update;
+    False: at advance only (the held Function object stays stale until then)."""
     ncell, nqp = 5, 4
     hist = j2_history(ncell * nqp, seed=9)
     now = {"eps": hist[1]}
@@ -145,6 +146,13 @@ def test_internal_state_variables_follow_isv_every_update():
     ref.update()
     p_ref = ref.internal_state_variables["p"].x.array.copy()
     assert p_ref.any()
+
+    default = QuadratureFieldMap(ncell, nqp, OracleJ2Material(E, NU, _hard()))
+    assert default.isv_every_update is True      # drop-in parity first; "lazy" is for callers that opt in
+    default.register_gradient("strain", lambda c: now["eps"].reshape(ncell, nqp, 6)[c].reshape(-1, 6))
+    held_default = default._isv_functions()["p"]
+    default.update()
+    assert np.array_equal(held_default.x.array, p_ref)
 
     lazy = make("lazy")
     held = lazy._isv_functions()["p"]            # a Function object taken out earlier
@@ -216,6 +224,8 @@ def test_map_over_all_cells_binds_the_functions_memory_and_scatters_nothing():
     assert np.array_equal(q.gradients["strain"].function.values, eps)   # evaluated straight into the Function
     q.update()
     assert m.calls.count("bind_outputs") == 1 and m.calls.count("bind_inputs") == 1   # once per map, not per call
+    assert [c for c in m.calls if c.startswith("read:")] == ["read:p", "read:epsp"] * 2   # every update writes the ISV Functions (default)
+    del m.calls[:]
     q.advance()
     assert [c for c in m.calls if c.startswith("read:")] == ["read:stress", "read:p", "read:epsp"]
     q.close()   # gives back exactly what the map bound, key by key

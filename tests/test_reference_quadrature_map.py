@@ -41,7 +41,7 @@ def test_field_map_reproduces_what_the_reference_class_left_in_its_functions(cas
     cells = GOLD["subset"] if case == "subset" else None
     now = {"k": 0}
     q = QuadratureFieldMap(NCELL, NQP, _material(), cells=cells)
-    # True: the reference writes the internal state variables in every update (quadrature_map.py:332); "lazy" (the default): they are
+    # True: the reference writes the internal state variables in every update (quadrature_map.py:332); "lazy" (opt-in): they are
     # refreshed when `_fields` below looks at `q.internal_state_variables[...]` -- the same content either way
     q.isv_every_update = isv_mode
     q.register_gradient("strain", lambda c: GOLD["strains"][now["k"]].reshape(NCELL, NQP * 6)[c])

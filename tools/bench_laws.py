@@ -61,8 +61,6 @@ def main():
     ap.add_argument("--laws", nargs="+", default=["elastic", "j2_linear", "j2_voce", "fefp"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="also time the plain-C oracle on this many points")
     ap.add_argument("--sym", action="store_true", help="symmetric-packed tangent (small-strain laws)")
-    ap.add_argument("--tangent-search", action="store_true",
-                    help="place the state (tune_placement) and try several allocations of the tangent array (fastest_tangent_array) first")
     a = ap.parse_args()
     import torch
 
@@ -97,12 +95,6 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         m.integrate_device(g[0].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         m.data_manager.update()  # s0 = state after the first increment
-        search = None
-        if a.tangent_search and not sym:
-            nfg = nf * ng
-            ct, t_search, k_best = m.fastest_tangent_array(lambda: torch.empty((n, nfg), dtype=torch.float64, device=dev), g[1].data_ptr(), flux.data_ptr())
-            search = {"best_launch_per_allocation_ms": [round(t, 4) for t in t_search], "kept": k_best}
-            torch.cuda.empty_cache()
         for _ in range(a.warmup):
             m.integrate_device(g[1].data_ptr(), flux.data_ptr(), ct.data_ptr(), st)
         rc, stats = m.stats()
@@ -120,8 +112,6 @@ def main():
             "plastic_fraction": round(stats["n_plastic"] / n, 4), "max_local_iters": stats["max_local_iters"],
             "not_converged": stats["n_not_converged"], "rc": rc,
         }
-        if search:
-            r["tangent_array_search"] = search
         if a.cpu_sample:
             r["cpu_port"] = cpu_port(law, a.cpu_sample)
         print(json.dumps(r), flush=True)

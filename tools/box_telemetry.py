@@ -2,7 +2,7 @@
 """What the BOX looks like from its own side: clocks, power, partition modes, VRAM co-tenancy, RAS.
 
 Pure sysfs / `rocm-smi` / `amd-smi` reads from an ordinary user process: no HIP call, no exec of a GPU program, never under
-rocprofv3.  Three entry points:
+rocprofv3 (`_tool` refuses to start a tool when a profiler is loaded).  Three entry points:
 
     snapshot(pci=None)       one dict of everything readable now (static identity + current clocks / power / memory)
     Sampler(pci, period_s)   a side thread that reads the cheap sysfs files (sclk, mclk, fclk, power, busy) every few ms
@@ -132,9 +132,31 @@ def fast_read(dev, hw=None):
     return rec
 
 
+def under_profiler(env=None):
+    """Whether this process runs under rocprofv3 / rocprofiler-sdk (the same test bench.py::live_traffic uses)."""
+    env = os.environ if env is None else env
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in env) or "rocprofiler" in env.get("LD_PRELOAD", "")
+
+
 def _tool(cmd, timeout=20):
+    """Run one of the SMI tools as a child.  Never under a profiler: a preloaded profiler library initialises the GPU in the
+    first process of the child's chain, and `rocm-smi` is a `#!/usr/bin/env python3` script, i.e. env -> exec python3 with an
+    initialised GPU, the exec that takes a box of this pool down.  So: refused when a profiler is around; the profiler's
+    variables are stripped from the child's environment all the same; a script is started as [this interpreter, real path]
+    (no `env` hop, no shebang)."""
+    if under_profiler():
+        return None, "", "under a profiler: SMI tools are not started"
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        exe = os.path.realpath(cmd[0])
+        argv = list(cmd)
+        with open(exe, "rb") as f:
+            head = f.read(64)
+        if head.startswith(b"#!") and b"python" in head.split(b"\n", 1)[0]:
+            argv = [sys.executable, exe] + argv[1:]
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS"))}
+        if "rocprof" in env.get("LD_PRELOAD", ""):
+            env.pop("LD_PRELOAD")
+        r = subprocess.run(argv, capture_output=True, text=True, timeout=timeout, env=env)
         return r.returncode, r.stdout, r.stderr[-300:]
     except Exception as exc:
         return None, "", repr(exc)

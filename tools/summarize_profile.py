@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--alg-bytes", type=int, default=496)
     ap.add_argument("--no-traffic-json", action="store_true")
     ap.add_argument("--command-text", default="`bash tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around\n"
-                    "`python3 bench.py --no-cpu-baseline --no-other-laws --no-host-path --no-live-traffic --no-tune --no-stream-probe --no-telemetry` (the default bench command: 200 steps, 10 warm-up, every array where its first allocation put it, without the context legs).")
+                    "`python3 bench.py --no-cpu-baseline --no-other-laws --no-host-path --no-live-traffic --no-stream-probe --no-telemetry` (the default bench command: 200 steps, 10 warm-up, every array where its first allocation put it, without the context legs).")
     ap.add_argument("--steps", type=int, default=200, help="timed steps of the bench command = the LAST dispatches of the kernel")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.prefix) or ".", exist_ok=True)

@@ -5,7 +5,7 @@ reference cannot travel to the GPU box): LinearElasticIsotropic through generic.
 Also times the same J2 law used for the protocol golden (a per-point Python law through the same
 machinery) and the build's numpy / C oracles on the same inputs, for scale.
 
-    python tools/time_reference_cpu.py > profiles/r01_reference_cpu_container.json
+    python tools/time_reference_cpu.py > profiles/archive/r01_reference_cpu_container.json
 """
 import json
 import os
