@@ -100,6 +100,7 @@ SYMBOLS = {
     "dxm_notify_replay": (C.c_int, [_h]),
     "dxm_set_option": (C.c_int, [_h, C.c_char_p, C.c_double]),
     "dxm_isv_host": (C.c_int, [_h, C.c_int, C.c_void_p]),
+    "dxm_bind_isv_output": (C.c_int, [_h, C.c_int, C.c_void_p]),
     "dxm_host_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "dxm_host_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     "dxm_host_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),

@@ -186,6 +186,7 @@ struct dxm_material {
   int io0_valid = 0;          // the same for d_grad0 / d_flux0 and s0
   int opt_keep_initial_io = 0;
   double* d_isv = nullptr;
+  double* isv_out[DXM_MAX_STATE_FIELDS] = {};   // dxm_bind_isv_output: host rows the host-buffer forms deliver each field of s1 into
   double* d_ct = nullptr;
   double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
   // host-buffer form, strain in ordinary memory: page-locked ring the kernels read the chunks from (zero-copy)
@@ -712,9 +713,10 @@ int dxm_advance(dxm_material* m) {
     m->parity ^= 1;   // launches now read / write the other buffer: dxm_launch_generation changes
     // Gradient and flux of the accepted state stay on the device as those of s0 (option keep_initial_io): the buffers the
     // last host-buffer call filled become d_grad0 / d_flux0 and the next call fills the other pair -- no copy.  Without a
-    // new state in between (advance twice, advance after revert) s0 keeps what it has; so it does when the state came
-    // from a form of call that has no host arrays (device pointers, a fused displacement for the gradient): like the
-    // caller's own host arrays, the copies follow the host-buffer calls only.
+    // new state in between (advance twice, advance after revert: s1 is served from s0 and this branch is not entered) s0
+    // keeps what it has.  A state that came from a form of call without host arrays (device pointers; a fused displacement
+    // for the gradient) or that got its own storage back after revert (dxm_set_state: materialize_s1) brings NO copies
+    // along, and s0 then holds none (io0_valid below): the Python layer's lazy s0 mirrors are settled before this call.
     if (m->opt_keep_initial_io && m->io1_valid) {
       if (m->io1_valid & 1) { double* g = m->d_grad0; m->d_grad0 = m->d_grad; m->d_grad = g; }
       if (m->io1_valid & 2) { double* f = m->d_flux0; m->d_flux0 = m->d_flux; m->d_flux = f; }
@@ -904,6 +906,28 @@ static int pack_isv_range(dxm_material* m, int which, int64_t off, int64_t cnt, 
   return 0;
 }
 
+// one user-visible field of s1 for the point range [off, off + cnt): AoS (cnt, dim) at dst_dev
+static int pack_isv_field_range(dxm_material* m, int field, int64_t off, int64_t cnt, double* dst_dev, hipStream_t st) {
+  const LawDesc& d = kLaws[m->law];
+  PackMap map{};
+  map.n = d.isv_dim[field];
+  for (int c = 0; c < map.n; ++c) map.slot[c] = d.isv_slot[field] + c;
+  const int blocks = (int)((cnt * map.n + 255) / 256);
+  hipLaunchKernelGGL(pack_isv_kernel, dim3(blocks), dim3(256), 0, st, m->state[1] + off, m->ld, cnt, dst_dev, map);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dxm_bind_isv_output(dxm_material* m, int field, double* host_aos) {
+  if (!m) return fail(-1, "null handle");
+  const LawDesc& d = kLaws[m->law];
+  if (field < 0 || field >= d.n_isv_fields) return fail(-1, "state field %d out of range", field);
+  if (host_aos && m->n > 0 && !page_locked(host_aos, sizeof(double) * m->n * d.isv_dim[field]))
+    return fail(-1, "the array must be page-locked (dxm_host_alloc / dxm_host_register): it is written by DMA inside the chunk pipeline");
+  m->isv_out[field] = host_aos;
+  return 0;
+}
+
 int dxm_isv_device(dxm_material* m, int which, double* isv_aos_dev, void* hip_stream) {
   if (!m) return fail(-1, "null handle");
   if (which != DXM_S0 && which != DXM_S1) return fail(-1, "state selector must be DXM_S0 or DXM_S1");
@@ -1089,6 +1113,14 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       if (isv_locked)
         HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
                                hipMemcpyDeviceToHost, st));
+    }
+    // fields of the final state bound to host rows (dxm_bind_isv_output: the x.array of the ISV Functions): the (N, total)
+    // device scratch holds them field after field, [n * sum of the dims before f] + off * dim_f
+    for (int f = 0, before = 0; f < d.n_isv_fields; before += d.isv_dim[f], ++f) {
+      if (!m->isv_out[f]) continue;
+      double* dev = m->d_isv + n * before + off * d.isv_dim[f];
+      if (int rc = pack_isv_field_range(m, f, off, cnt, dev, st)) return rc;
+      HIP_TRY(hipMemcpyAsync(m->isv_out[f] + off * d.isv_dim[f], dev, sizeof(double) * cnt * d.isv_dim[f], hipMemcpyDeviceToHost, st));
     }
     if (ct_aos && !constant && (packed || ct_locked)) {
       double* dst = packed ? m->h_coef + off * np : ct_aos + off * nt;

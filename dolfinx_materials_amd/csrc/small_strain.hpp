@@ -270,8 +270,10 @@ small_strain_kernel(const LawParams prm, const int64_t n, const double* __restri
           wn = rho > 0.0 ? 1.5 * iseq / rho : 0.0;   // (a division: with the 5-instruction reciprocal the fused tet4 Voce variant spills 2 registers)
           // rho = R(p) / seq of the returned state: <= 0 only for a yield stress that is not positive there (a softening law
           // driven to zero, an overshooting iterate).  The direction is then undefined (wn = 0 drops the n x n term): reported
-          // as a point that did not converge, never silently
+          // as a point that did not converge, never silently.  Linear hardening can get there with H < 0 only: one scalar
+          // compare on the kernel's parameters keeps the per-lane test out of the H >= 0 launches (the headline)
           if constexpr (LAW != LAW_J2_LINEAR) { if (valid && !(rho > 0.0)) ++c_notconv; }
+          else if (prm.h1 < 0.0) { if (valid && !(rho > 0.0)) ++c_notconv; }
         }
         const double gamma = 1.0 / (hardening_dR<LAW>(prm, p_n + dp) + 3.0 * mu);
         // Dt = lambda IxI + 2mu Id - 4mu^2 [beta (M - n^n) + gamma n^n]      mfront:66-69

@@ -202,7 +202,9 @@ class LazyInitialRows(LazyISV):
 class LazyFinalRows(LazyInitialRows):
     """The flux of the FINAL state s1 after :meth:`HIPMaterial.integrate_rows`, whose results went to scattered rows of the
     caller's arrays: the contiguous ``(N, nf)`` array exists on the device only and is downloaded when somebody asks
-    (``get_final_state_dict()["Stress"]``)."""
+    (``get_final_state_dict()["Stress"]``).  Same hand-out rule as :class:`LazyInitialRows`: the material keeps the mirror, the
+    dictionaries hold views of it, and a view that is still alive when the next update (or ``revert``) replaces s1 keeps the rows
+    of ITS state."""
 
     _which = 1
 
@@ -273,6 +275,7 @@ class HIPMaterial:
         self._serial = 0
         self._serial0 = 0     # counts the changes of s0 (advance, set_initial_state_dict)
         self._bound = {}
+        self._delivered = set()    # ISV names that host-buffer calls write into bound arrays (bind_state_outputs(deliver=True))
         self.tangent_layout = tangent_layout
         self.behavior = behavior
         self.devices = [int(d) for d in devices] if devices is not None else [int(device)]
@@ -533,12 +536,11 @@ class HIPMaterial:
     def _hand_out(self, mirror):
         """What a state dictionary shows for a gradient / flux mirror.  The reference's dictionaries hold copies
         (``generic.py:265-277``: fancy-indexed rows of the state manager), so what goes out must not change under the caller:
-        a lazy s0 mirror goes out as a view it can count (:class:`LazyInitialRows`: downloaded only if still alive when s0 is
-        replaced); an array that a later update writes again (the material's two alternating page-locked flux buffers, a bound
+        a lazy mirror goes out as a view it can count (:class:`LazyInitialRows`, :class:`LazyFinalRows`: downloaded only if
+        still alive when the state it stands for is replaced); an array that a later update writes again (the material's two alternating page-locked flux buffers, a bound
         flux or gradient array, i.e. a Function's memory) goes out as a copy; everything else -- the array the caller passed to
-        ``integrate`` (kept by reference, theirs to change), snapshots, placeholders, s1 views (which follow s1 by contract) --
-        as it is."""
-        if type(mirror) is LazyInitialRows:
+        ``integrate`` (kept by reference, theirs to change), snapshots, placeholders -- as it is."""
+        if type(mirror) in (LazyInitialRows, LazyFinalRows):
             return mirror._view()
         if isinstance(mirror, np.ndarray) and mirror.size and mirror.strides[0] != 0:
             bound = self._bound.get("gradient")
@@ -574,6 +576,7 @@ class HIPMaterial:
             elif key == "be_bar" and self._info.n_grad == 9:
                 continue  # handled below together with F
             else:
+                self._retire_final_views(materializing=True)   # dxm_set_state gives s1 its own storage back: its device copies go
                 self._set_state(isv_names.index(key), a)
         if self._info.n_grad == 9 and ("be_bar" in state or self._gname in state):
             # the kernel's state is the isochoric Cp^-1 (hidden field 2), rebuilt from (F_n, be_bar_n)
@@ -581,6 +584,7 @@ class HIPMaterial:
 
             be = _as_c(state["be_bar"], (self._n, 6)) if "be_bar" in state else self._isv_dict(S0)["be_bar"]
             cpi, be = cp_bar_inv_from_be_bar(self._grad[0], be)
+            self._retire_final_views(materializing=True)
             self._set_state(1, _as_c(be))
             self._set_state(2, _as_c(cpi))
 
@@ -596,6 +600,17 @@ class HIPMaterial:
             v = (self._grad, self._flux)[kind][0]
             if type(v) is LazyInitialRows and not v._frozen and v._handed_out():
                 v._freeze()
+
+    def _retire_final_views(self, materializing=False):
+        """s1 is about to be replaced (an update of any form, ``revert``): a lazy s1 flux mirror takes its rows off the device
+        first if a view of it is still alive -- the launch invalidates the device copy.  ``materializing``
+        (``set_initial_state_dict`` of an internal state variable): s1 stays, but an s1 that is served from s0 gets its own
+        storage back and the device drops the copies it showed; lazy s1 mirrors then settle whether or not a view is alive."""
+        drop_all = materializing and self.__dict__.get("_s1_from_s0", False)
+        for v in (self._grad[1], self._flux[1]) if getattr(self, "_flux", None) is not None else ():
+            if type(v) in (LazyFinalRows, LazyInitialRows) and not v._frozen and (drop_all or (type(v) is LazyFinalRows and v._handed_out())):
+                v._freeze()
+        self._s1_from_s0 = False   # written in full by the caller's launch, or materialised by dxm_set_state
 
     def _advance(self):
         self._handles()
@@ -622,8 +637,11 @@ class HIPMaterial:
         old = (self._grad[0], self._flux[0])
         new = []
         for kind, (cur, key) in enumerate(((self._grad[1], "gradient"), (self._flux[1], "flux"))):
-            if isinstance(cur, LazyFinalRows):     # results of integrate_rows: the device copy became that of s0
-                new.append(LazyInitialRows(self, cur.shape, kind))
+            if isinstance(cur, LazyFinalRows):     # results of integrate_rows: the device copy became that of s0 ...
+                if cur._frozen or not held & (1 << kind):   # ... unless the device dropped it (settled on the host beforehand)
+                    new.append(np.asarray(cur))
+                else:
+                    new.append(LazyInitialRows(self, cur.shape, kind))
             elif isinstance(cur, LazyInitialRows):
                 new.append(cur)
             elif isinstance(cur, np.ndarray) and cur.size and cur.strides[0] == 0:   # the "unknown" placeholder of a device-pointer call
@@ -636,6 +654,7 @@ class HIPMaterial:
                 new.append(self._snapshot(cur))
         self._grad[0], self._flux[0] = new
         self._serial0 += 1
+        self._s1_from_s0 = True
         for a in old:   # the mirrors of the increment before: freed off this thread
             if isinstance(a, np.ndarray) and a is not self._grad[0] and a is not self._flux[0] and not any(a is b for b in self._flux_buf):
                 _reaper.drop(a)
@@ -658,11 +677,14 @@ class HIPMaterial:
         return out
 
     def _revert(self):
+        self._handles()
+        self._retire_final_views()
         for h in self._handles():
             self._chk(self._lib.dxm_revert(h))
         self._grad[1] = self._grad[0]
         self._flux[1] = self._flux[0]
         self._serial += 1   # s1 changed: lazy ISV views refetch
+        self._s1_from_s0 = True
 
     # ---- protocol: the hot path -----------------------------------------------------------------
     def integrate(self, gradients, dt=0):
@@ -686,6 +708,7 @@ class HIPMaterial:
                 raise ValueError(f"gradients must have shape {(self._n, ng)}, got {g.shape}")
             eager = not self.lazy_isv
             self._ensure_outputs(isv=eager)
+            self._retire_final_views()
             flux = self._next_flux_buffer()
             old = self._grad[1]
             self._grad[1] = g
@@ -811,6 +834,7 @@ class HIPMaterial:
         if g.shape != (self._n, self._info.n_grad):
             raise ValueError(f"gradients must have shape {(self._n, self._info.n_grad)}, got {g.shape}")
         self._check_rows(rows, flux, tangent)
+        self._retire_final_views()
         old = self._grad[1]
         self._grad[1] = g
         recs = [Stats() for _ in self._parts]
@@ -833,6 +857,7 @@ class HIPMaterial:
         if u.size != mesh.displacement_size:
             raise ValueError(f"u must have {mesh.displacement_size} entries, got {u.size}")
         self._check_rows(rows, flux, tangent)
+        self._retire_final_views()
         st = Stats()
         rc = self._lib.dxm_integrate_displacement_rows(h, mesh._handle, _ptr(u), float(dt), _ptr(flux), _ptr(tangent), rows.ctypes.data, C.byref(st))
         return self._after_rows(self._finish_blocks([rc], [st]))
@@ -850,6 +875,7 @@ class HIPMaterial:
             raise ValueError(f"u must have {mesh.displacement_size} entries, got {u.size}")
         eager = not self.lazy_isv
         self._ensure_outputs(isv=eager)
+        self._retire_final_views()
         flux = self._next_flux_buffer()
         rc = self._integrate_blocks(self._lib.dxm_integrate_displacement, mesh._handle, u, float(dt), flux, self._out_isv if eager else None)
         if rc > 0:
@@ -865,6 +891,7 @@ class HIPMaterial:
         holds no device copy for such a state either (``dxm_io_held`` is 0 after ``dxm_advance``)."""
         if getattr(self, "_grad", None) is None:
             return
+        self._retire_final_views()
         self._grad[1] = np.broadcast_to(np.nan, (self._n, int(self._info.n_grad)))
         self._flux[1] = np.broadcast_to(np.nan, (self._n, int(self._info.n_flux)))
         self._serial += 1
@@ -906,7 +933,7 @@ class HIPMaterial:
     def set_option(self, name, value):
         """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"packed_transfer"``, ``"packed_min_points"``,
         ``"register_input"``, ``"stage_ahead"``, ``"keep_initial_io"``, ``"pageable_dma"``, ``"host_threads"``, ``"max_chunks"``,
-        ``"fused_gradient"``, ``"blocks_per_cu"``, ``"tune_max_skip_bytes"``, ``"tune_verbose"``; process-wide:
+        ``"fused_gradient"``, ``"blocks_per_cu"``, ``"verbose"``; process-wide:
         ``"query_foreign_pointers"``)."""
         for h in self._handles():
             self._chk(self._lib.dxm_set_option(h, name.encode(), float(value)))
@@ -952,10 +979,13 @@ class HIPMaterial:
         self._bound["gradient"] = gradient
         self.set_option("keep_initial_io", 1)
 
-    def bind_state_outputs(self, arrays):
-        """Page-lock in place the caller-owned arrays that receive internal state variables at ``advance`` -- the
-        ``x.array`` of the ISV quadrature Functions (``read_final_state(name, out)`` into such memory is one DMA
-        transfer instead of a staged copy).  ``arrays``: name -> C-contiguous fp64 array of ``N * dim`` entries."""
+    def bind_state_outputs(self, arrays, deliver=False):
+        """Page-lock in place the caller-owned arrays that receive internal state variables -- the ``x.array`` of the ISV
+        quadrature Functions (``read_final_state(name, out)`` into such memory is one DMA transfer instead of a staged copy).
+        ``arrays``: name -> C-contiguous fp64 array of ``N * dim`` entries.  ``deliver=True``: every host-buffer ``integrate``
+        writes these fields of the final state into the arrays inside its transfer pipeline (``dxm_bind_isv_output``) -- what
+        ``QuadratureMap.update`` does after each ``integrate`` (``quadrature_map.py:332, :343-348``) without a second pass;
+        :attr:`delivers_state_outputs` then names the fields."""
         self._handles()
         for name, arr in arrays.items():
             if name not in self.internal_state_variables:
@@ -968,6 +998,19 @@ class HIPMaterial:
             if arr.nbytes:
                 self._chk(self._lib.dxm_host_register(_ptr(arr), arr.nbytes))
             self._bound[key] = arr
+            if deliver:
+                f = self.internal_state_variable_names.index(name)
+                dim = max(1, self.internal_state_variables[name])
+                rows = arr.reshape(self._n, dim)
+                for h, lo, hi, ptrs in self._blocks(rows):
+                    self._chk(self._lib.dxm_bind_isv_output(h, f, ptrs[0] if hi > lo else None))
+                self._delivered.add(name)
+
+    @property
+    def delivers_state_outputs(self):
+        """Names of the internal state variables that every host-buffer ``integrate`` writes into bound arrays
+        (``bind_state_outputs(..., deliver=True)``)."""
+        return frozenset(self.__dict__.get("_delivered", ()))
 
     def scatter_rows(self, dst, rows, src):
         """``dst[rows] = src`` for ``(*, w)`` fp64 arrays on several threads (``dxm_host_scatter_rows``): what a map over a
@@ -1020,6 +1063,11 @@ class HIPMaterial:
             arr = self._bound.pop(k, None)
             if arr is None:
                 continue
+            if k.startswith("isv:") and k[4:] in self.__dict__.get("_delivered", ()):   # stop the deliveries before the page-lock goes
+                f = self.internal_state_variable_names.index(k[4:])
+                for h, *_ in getattr(self, "_parts", []):
+                    self._lib.dxm_bind_isv_output(h, f, None)
+                self._delivered.discard(k[4:])
             if arr.nbytes:
                 self._lib.dxm_host_unregister(_ptr(arr))
             # back to the material's own buffers (allocated when next needed)

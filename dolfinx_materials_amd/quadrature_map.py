@@ -187,6 +187,26 @@ class AcceleratedUpdate:
         self.__dict__["_accel"] = plan
         return plan
 
+    def _accel_deliveries(self, plan, want):
+        """``isv_every_update = True`` with the ISV Functions bound: let the engine write them inside every ``integrate`` (its
+        transfer pipeline carries the 56 B/point along: ``HIPMaterial.bind_state_outputs(deliver=True)``) instead of a second
+        pass over the state after it.  Switched when the mode changes; returns whether the Functions are written by the call."""
+        m = self.material
+        names = tuple(k[4:] for k in plan.bound_keys if k.startswith("isv:"))
+        if not names or not hasattr(m, "delivers_state_outputs") or set(names) != set(m.internal_state_variables):
+            return False
+        on = set(names) <= set(m.delivers_state_outputs)
+        if bool(want) != on:
+            fields = self._isv_functions()
+            try:
+                m.bind_state_outputs({name: fields[name].x.array for name in names}, deliver=bool(want))
+            except Exception as exc:   # page-locking refused on the re-bind: the second pass keeps working through staged copies
+                _slow_path_warning("the internal-state Functions", exc)
+                plan.bound_keys = tuple(k for k in plan.bound_keys if not k.startswith("isv:"))
+                return False
+            on = bool(want)
+        return on
+
     def _isv_functions(self):
         """name -> Function of the internal state variables, without triggering a lazy refresh."""
         d = self.internal_state_variables
@@ -341,6 +361,7 @@ class AcceleratedUpdate:
         if rotate and grad is not None:   # in place, on the rows (quadrature_map.py:315-318); a bound gradient Function is re-evaluated next call
             m.rotate_gradients(grad.ravel(), self.rotation_func.x.array)
         flux = tangent = None
+        delivered = plan.bound and self._accel_deliveries(plan, self.isv_every_update is True and not rows_mode)
         with _Timer("dx_mat: Material integration"):
             if rows_mode:
                 # a map over a subset of the cells: the engine stores each point's stress and tangent block in its row of the
@@ -373,8 +394,8 @@ class AcceleratedUpdate:
                 self._put_columns(self.fluxes, m.fluxes, flux)
                 self._put(self.jacobian_flatten, self._jacobian_width(), tangent)
             self._last_isv = isv
-            self.__dict__["_accel_isv_stale"] = bool(m.internal_state_variables)
-            if self.isv_every_update is True:
+            self.__dict__["_accel_isv_stale"] = bool(m.internal_state_variables) and not delivered
+            if self.isv_every_update is True and not delivered:
                 self.refresh_internal_state_variables()
 
     def refresh_internal_state_variables(self):

@@ -261,6 +261,13 @@ int dxm_set_option(dxm_material* m, const char* name, double value);
  * user-visible ISVs of state `which` and downloads them into host memory (npoints, n_isv_total).  This is
  * how the Python layer serves the `isv` array of integrate() on first access (jaxmat.py:227-229). */
 int dxm_isv_host(dxm_material* m, int which, double* isv_aos);
+/* QuadratureMap.update writes every internal state variable into its quadrature Function after each integrate
+ * (quadrature_map.py:332, :343-348: `_update_vals(isv, isv_vals[:, buff:buff+dim], cells)`).  Bind the memory of such a Function --
+ * C-contiguous (npoints, dim) rows of field `field`, page-locked by dxm_host_alloc / dxm_host_register -- and the host-buffer
+ * forms (dxm_integrate, dxm_integrate_displacement, ..._rows) deliver that field of the final state into it chunk by chunk inside
+ * their transfer pipeline: the caller finds the Functions written when the call returns, without a second pass over the state.
+ * NULL unbinds (do so before un-page-locking the array).  The device-pointer forms do not deliver. */
+int dxm_bind_isv_output(dxm_material* m, int field, double* host_aos);
 
 /* ---- pinned host memory for the host-buffer form --------------------------------------------
  * integrate() returns arrays owned by the material (the reference returns views of its state

@@ -223,3 +223,43 @@ def test_pageable_output_arrays_are_filled_through_the_staging_path(law, n):
     assert lib.dxm_get_state(b._handle, 1, 0, p.ctypes.data) == 0 and np.array_equal(p[:, 0], isv[:, 0])
 
 
+
+
+def test_isv_outputs_bound_at_the_c_level_are_written_by_the_host_buffer_call():
+    """`dxm_bind_isv_output`: page-locked (npoints, dim) rows per field receive that field of the final state inside
+    `dxm_integrate`'s chunk pipeline -- bit-identical to `dxm_get_state` afterwards, for a chunked batch and a single-chunk one;
+    pageable memory is refused (the rows are written by DMA); NULL unbinds."""
+    from helpers import E, NU, j2_history
+
+    lib = _lib.load()
+    for n in (300_007, 1000):
+        prm = (C.c_double * 5)(E, NU, 350.0, 500.0, 1e3)
+        h = lib.dxm_create(_lib.LAW_J2_VOCE, prm, 5, n, 0)
+        assert h
+        hist = j2_history(n, seed=1, sig0=350.0)
+        bufs = {name: _lib.PinnedArray(shape) for name, shape in (("g", (n, 6)), ("f", (n, 6)), ("c", (n, 36)), ("p", (n, 1)), ("ep", (n, 6)))}
+        g, f, c, p, ep = (bufs[k].array for k in ("g", "f", "c", "p", "ep"))
+        pageable = np.zeros((n, 6))
+        assert lib.dxm_bind_isv_output(h, 1, pageable.ctypes.data_as(C.c_void_p)) < 0 and b"page-locked" in lib.dxm_last_error()
+        assert lib.dxm_bind_isv_output(h, 2, ep.ctypes.data_as(C.c_void_p)) < 0        # two fields: p, epsp
+        _lib.check(lib.dxm_bind_isv_output(h, 0, p.ctypes.data_as(C.c_void_p)), lib)
+        _lib.check(lib.dxm_bind_isv_output(h, 1, ep.ctypes.data_as(C.c_void_p)), lib)
+        st = _lib.Stats()
+        for k in range(3):
+            g[...] = hist[k]
+            p[...] = -1.0
+            ep[...] = -1.0
+            assert lib.dxm_integrate(h, g.ctypes.data_as(C.c_void_p), 0.0, f.ctypes.data_as(C.c_void_p), None, c.ctypes.data_as(C.c_void_p), C.byref(st)) == 0
+            want_p, want_ep = np.empty((n, 1)), np.empty((n, 6))
+            _lib.check(lib.dxm_get_state(h, _lib.S1, 0, want_p.ctypes.data_as(C.c_void_p)), lib)
+            _lib.check(lib.dxm_get_state(h, _lib.S1, 1, want_ep.ctypes.data_as(C.c_void_p)), lib)
+            assert np.array_equal(p, want_p) and np.array_equal(ep, want_ep) and (k == 0 or want_p.any())
+            _lib.check(lib.dxm_advance(h), lib)
+        _lib.check(lib.dxm_bind_isv_output(h, 0, None), lib)
+        p[...] = -1.0
+        g[...] = hist[3]
+        assert lib.dxm_integrate(h, g.ctypes.data_as(C.c_void_p), 0.0, f.ctypes.data_as(C.c_void_p), None, c.ctypes.data_as(C.c_void_p), C.byref(st)) == 0
+        assert (p == -1.0).all() and not (ep == -1.0).any()
+        lib.dxm_destroy(h)
+        for b in bufs.values():
+            b.release()

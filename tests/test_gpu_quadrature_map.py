@@ -310,3 +310,68 @@ def test_update_keeps_the_references_timer_rows_with_the_engine(monkeypatch):
                                                                     "jaxmat: jaxmat to dolfinx conversion"]
     q.close()
     m.close()
+
+
+@pytest.mark.parametrize("law,ncell,nqp", [("j2_linear", 5000, 8), ("j2_voce", 601, 4), ("fefp", 4600, 8)])
+def test_default_mode_writes_the_isv_functions_inside_the_update_itself(law, ncell, nqp):
+    """`isv_every_update = True` (the default: the reference writes the ISV Functions in every update, quadrature_map.py:332) with
+    the engine and a map over all cells: the fields of the final state travel inside `integrate`'s own transfer pipeline into the
+    Functions' page-locked memory (`dxm_bind_isv_output`) -- no second pass over the state (`read_final_state` is not called by
+    `update()`), a Function object taken out of the dict earlier is current when `update()` returns, and the values are the bits
+    the lazy mode downloads.  Switching the mode switches the delivery."""
+    n = ncell * nqp
+    if law == "fefp":
+        hist, gname, ng = fefp_path(n, nsteps=6, eps=3e-2)[::2], "F", 9
+    else:
+        hist, gname, ng = j2_history(n, seed=8, sig0=SIG0_V if law == "j2_voce" else SIG0_LIN), "strain", 6
+    now = {"g": hist[0]}
+    ev = lambda c: now["g"].reshape(ncell, nqp, ng)[c].reshape(-1, ng)   # noqa: E731
+    maps = {}
+    for mode in (True, "lazy"):
+        q = QuadratureFieldMap(ncell, nqp, JAXMaterial(_behavior(law)))
+        q.isv_every_update = mode
+        q.register_gradient(gname, ev)
+        maps[mode] = q
+    fast, lazy = maps[True], maps["lazy"]
+    assert QuadratureFieldMap.isv_every_update is True
+    if law == "fefp":
+        now["g"] = np.tile(np.array([1.0, 1, 1, 0, 0, 0, 0, 0, 0]), (n, 1))
+        for q in maps.values():
+            q.update()
+    reads = []
+    inner = fast.material.read_final_state
+    fast.material.read_final_state = lambda name, out: (reads.append(name), inner(name, out))[1]
+    held = dict(fast._isv_functions())                       # Function objects taken out before any update
+    names = set(fast.material.internal_state_variables)
+    for k, g in enumerate(hist):
+        now["g"] = g
+        fast.update()
+        assert fast.material.delivers_state_outputs == names and not reads and not fast.__dict__["_accel_isv_stale"]
+        lazy.update()
+        assert lazy.material.delivers_state_outputs == frozenset()
+        for name in names:
+            assert np.array_equal(held[name].x.array, lazy.internal_state_variables[name].x.array), (k, name)
+        assert held["p"].x.array.any() or k == 0
+        if k % 2:
+            for q in maps.values():
+                q.advance()
+            assert reads and set(reads) >= names             # advance() writes the final state as the reference does (:350-360)
+            del reads[:]
+            for name, f in _fields(fast).items():
+                assert np.array_equal(f, _fields(lazy)[name]), name
+    # opting in to "lazy" on the same map stops the deliveries; back to True resumes them
+    fast.isv_every_update = "lazy"
+    now["g"] = hist[-1] * 0.5 if law != "fefp" else hist[-2]
+    before = {name: held[name].x.array.copy() for name in names}
+    fast.update()
+    assert fast.material.delivers_state_outputs == frozenset() and fast.__dict__["_accel_isv_stale"]
+    assert all(np.array_equal(held[name].x.array, before[name]) for name in names)      # nobody has looked yet
+    lazy.update()
+    assert all(np.array_equal(fast.internal_state_variables[name].x.array, lazy.internal_state_variables[name].x.array) for name in names)
+    fast.isv_every_update = True
+    fast.update()
+    assert fast.material.delivers_state_outputs == names and not fast.__dict__["_accel_isv_stale"]
+    for q in maps.values():
+        q.close()
+        q.material.close()
+    assert fast.material.delivers_state_outputs == frozenset()

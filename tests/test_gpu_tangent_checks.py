@@ -113,6 +113,24 @@ def test_a_yield_stress_that_is_not_positive_is_reported_not_hidden():
     m.close()
 
 
+def test_linear_softening_driven_to_a_non_positive_yield_stress_is_reported_too():
+    """the built-in LINEAR law with H < 0 reaches R(p) <= 0 as well (R = sig0 + H p = 0 at p = -sig0 / H); same
+    report, and none for the same strains with H >= 0 (the guard costs launches with H >= 0 one scalar compare)."""
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    n = 256
+    eps = _strains(n, 30.0, 60.0, seed=5)
+    got = {}
+    for H in (-5e4, 5e3):
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(250.0, H)))
+        m.set_data_manager(n)
+        assert m.kernel_name.startswith("small_strain_kernel<1")
+        sig, isv, ct = m.integrate(eps)
+        got[H] = dict(m.last_stats)
+        assert np.isfinite(ct).all() and np.isfinite(sig).all() and m.last_stats["n_nan"] == 0 and m.last_stats["n_plastic"] == n
+        m.close()
+    assert got[-5e4]["n_not_converged"] > 0 and got[5e3]["n_not_converged"] == 0
+
+
 LINEAR_R = "sig0 + H * p"
 
 
