@@ -54,6 +54,12 @@ def close(a, b, scale):
                                                (6, 3000, "io", True), (7, 66_000, "io", True), (8, 130, "io", False),
                                                (9, 2500, "rows", True), (10, 70_003, "rows", True), (11, 1, "rows", True)])
 def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
+    run_operation_sequence(seed, n, bound, lazy)
+
+
+def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=64):
+    """The sequence itself (also run on the CPU against the test double of the library, tests/test_protocol_fuzz_cpu.py, where the
+    device-pointer launches become host-buffer ones)."""
     rng = np.random.default_rng(seed)
     beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
     m = JAXMaterial(beh, lazy_isv=lazy)
@@ -75,7 +81,7 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     eps = np.zeros((n, 6))
     held = None           # (isv object of an earlier integrate, what it must show when looked at)
     ops = rng.choice(["integrate", "integrate", "integrate", "update", "update", "revert", "get", "set", "look", "device", "device", "prop",
-                      "hold", "hold", "drop"], size=64)
+                      "hold", "hold", "drop"], size=nops)
     # state dictionaries taken at random steps and KEPT (in a list, in a dict under their id(), inside a closure): each must go on
     # showing the state it was taken from whatever happens to the material afterwards (the reference's dictionaries are copies,
     # generic.py:265-277) -- hip_material.LazyInitialRows views, copies of the alternating flux buffers
@@ -97,13 +103,16 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
             for name, ref_rows in want.items():
                 assert np.array_equal(np.asarray(got[name]).reshape(ref_rows.shape), ref_rows), name
     known = {"initial": False, "final": False}   # whether the host-side stress mirror of s0 / s1 is meaningful
-    import torch
+    if device_ops:
+        import torch
 
-    dev = torch.device("cuda:0")
-    d_flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
-    d_ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
+        dev = torch.device("cuda:0")
+        d_flux = torch.empty((n, 6), dtype=torch.float64, device=dev)
+        d_ct = torch.empty((n, 36), dtype=torch.float64, device=dev)
     sig0_now = SIG0_V
     for op in ops:
+        if op == "device" and not device_ops:
+            op = "integrate"
         if op == "integrate":
             d = rng.standard_normal((n, 6))
             eps = 0.6 * eps + d * (rng.uniform(0, 3.0, n) * ey / np.linalg.norm(d, axis=1))[:, None]

@@ -1,0 +1,129 @@
+"""CPU: the Python layer above the C ABI -- ``hip_material.HIPMaterial`` (s0 / s1 mirrors, the views its state dictionaries hand
+out, bound arrays, rows mode, lazy ISVs) and ``quadrature_map.AcceleratedUpdate`` on top of it -- driven through the SAME random
+protocol sequences as ``tests/test_gpu_fuzz_protocol.py``, against ``tests/fake_dxmat.py``: a test double of libdxmat.so that restates
+the handle semantics of ``csrc/dxmat.hip`` (which device copies a handle holds, when it drops them) over numpy with the C oracle's
+arithmetic.  This is what found "revert(); set_initial_state_dict(isv); advance()" leaving a lazy mirror without its device copy
+only on the GPU box in round 5; now the host logic is exercised on every CPU run.  The product path is untouched: ``_lib.load`` is
+monkeypatched for the duration of a test."""
+import gc
+
+import numpy as np
+import pytest
+
+import dolfinx_materials_amd.materials as jm
+from dolfinx_materials_amd import _lib
+from dolfinx_materials_amd.jaxmat import JAXMaterial
+from fake_dxmat import FakeDxmat
+from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
+
+
+@pytest.fixture
+def fake(monkeypatch):
+    lib = FakeDxmat(_lib.load())
+    monkeypatch.setattr(_lib, "load", lambda *a, **k: lib)
+    yield lib
+    gc.collect()
+
+
+@pytest.mark.parametrize("seed,n,bound,lazy", [(0, 77, False, True), (1, 500, True, True), (2, 64, False, False), (3, 400, True, False),
+                                               (4, 1, False, True), (6, 300, "io", True), (7, 660, "io", True), (8, 130, "io", False),
+                                               (9, 250, "rows", True), (10, 703, "rows", True), (11, 1, "rows", True),
+                                               (21, 90, "io", True), (22, 90, "rows", True), (23, 90, True, True), (24, 90, False, True)])
+def test_random_operation_sequences_on_the_test_double(fake, seed, n, bound, lazy):
+    from test_gpu_fuzz_protocol import run_operation_sequence
+
+    run_operation_sequence(seed, n, bound, lazy, device_ops=False, nops=96 if seed > 20 else 64)
+
+
+def _j2():
+    return JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)))
+
+
+def test_views_are_counted_by_weak_references_not_reference_counts(fake):
+    """The CPU twin of tests/test_gpu_hostpath.py::test_views_of_the_initial_state_keep_their_content_however_they_are_held: one
+    download per field when a held view's state is replaced, none for dictionaries nobody kept."""
+    from dolfinx_materials_amd.hip_material import LazyInitialRows
+
+    n = 501
+    m = _j2()
+    m.set_data_manager(n)
+    flux_fn, jac_fn, grad_fn = np.zeros(n * 6), np.zeros(n * 36), np.zeros(n * 6)
+    m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+    m.bind_inputs(gradient=grad_fn)
+    rows = grad_fn.reshape(n, 6)
+    h = j2_history(n, seed=33)
+
+    def cycle(k):
+        rows[...] = h[k]
+        f = np.array(m.integrate(rows)[0])
+        m.data_manager.update()
+        return f
+
+    f0 = cycle(0)
+    local = m.get_initial_state_dict()["stress"]
+    bag = [m.get_initial_state_dict()["stress"]]
+    book = {}
+    v = m.get_initial_state_dict()["strain"]
+    book[id(v)] = v
+    del v
+    m.get_initial_state_dict()                       # nobody keeps this one
+    gc.collect()
+    assert all(isinstance(x, LazyInitialRows) and not x.fetched for x in (local, bag[0], *book.values())) and not fake.downloads
+    cycle(1)
+    assert sorted(fake.downloads) == [(0, 0), (0, 1)]
+    cycle(2)
+    assert len(fake.downloads) == 2
+    assert np.array_equal(np.asarray(local), f0) and np.array_equal(np.asarray(bag[0]), f0)
+    assert np.array_equal(np.asarray(next(iter(book.values()))), h[0])
+    del local, bag, book
+    gc.collect()
+    cycle(3)
+    assert len(fake.downloads) == 2                   # nothing held any more: nothing downloaded
+    # revert + an ISV set + advance: s1 gets its own storage back and the device drops the copies the mirror stood for
+    f3 = np.array(flux_fn.reshape(n, 6))
+    rows[...] = h[0]
+    m.integrate(rows)
+    m.data_manager.revert()
+    kept = m.get_final_state_dict()["stress"]
+    m.set_initial_state_dict({"p": np.full(n, 1e-3)})
+    m.data_manager.update()
+    rows[...] = h[1]
+    m.integrate(rows)
+    m.data_manager.update()
+    assert np.array_equal(np.asarray(kept), f3)
+    m.close()
+
+
+def test_accelerated_map_on_the_test_double_writes_isvs_inside_integrate(fake):
+    """``AcceleratedUpdate`` over ``HIPMaterial`` over the test double: default mode = ISV Functions written by the host-buffer call
+    itself (``dxm_bind_isv_output``), bit-identical fields to the reference cadence around a second material."""
+    from bench import as_reference_advance, as_reference_update
+    from dolfinx_materials_amd.field_map import FieldMapBase, QuadratureFieldMap
+
+    ncell, nqp = 60, 4
+    n = ncell * nqp
+    hist = j2_history(n, seed=5)
+    now = {"g": hist[0]}
+    ev = lambda c: now["g"].reshape(ncell, nqp, 6)[c].reshape(-1, 6)   # noqa: E731
+    fast, slow = QuadratureFieldMap(ncell, nqp, _j2()), FieldMapBase(ncell, nqp, _j2())
+    for q in (fast, slow):
+        q.register_gradient("strain", ev)
+    held = dict(fast._isv_functions())
+    reads = []
+    inner = fast.material.read_final_state
+    fast.material.read_final_state = lambda name, out: (reads.append(name), inner(name, out))[1]
+    for k, g in enumerate(hist):
+        now["g"] = g
+        fast.update()
+        as_reference_update(slow)
+        assert fast.material.delivers_state_outputs == {"p", "epsp"} and not reads
+        for name in ("p", "epsp"):
+            assert np.array_equal(held[name].x.array, slow.internal_state_variables[name].x.array), (k, name)
+        assert np.array_equal(fast.fluxes["stress"].x.array, slow.fluxes["stress"].x.array)
+        assert np.array_equal(fast.jacobian_flatten.x.array, slow.jacobian_flatten.x.array)
+        fast.advance()
+        as_reference_advance(slow)
+        del reads[:]
+    fast.close()
+    for q in (fast, slow):
+        q.material.close()

@@ -134,7 +134,8 @@ def main():
             f.write(f"\nTimed region = the last {timed['dispatches']} of the {timed['of']} dispatches of this kernel in the trace (the earlier ones "
                     f"are set-up, settling and warm-up launches of the same kernel): average "
                     f"**{timed['avg_ns']/1e3:.1f} us** (min {timed['min_ns']/1e3:.1f}, max {timed['max_ns']/1e3:.1f}) = **{alg/timed['avg_ns']:.0f} GB/s** = "
-                    f"{alg/timed['avg_ns']/8000:.3f} of peak; this is the figure `roofline.achieved` of the bench line corresponds to.\n")
+                    f"{alg/timed['avg_ns']/8000:.3f} of peak; " + ("this is the figure `roofline.achieved` of the bench line corresponds to.\n" if a.law == "j2_linear"
+                                                                     else "the steady-state figure of this kernel (`other_laws` of the bench line times 30 launches after 10 untimed ones).\n"))
         f.write("\n## PMC (mean per launch)\n\n| counter | value |\n|---|---|\n")
         for k in sorted(pmc):
             f.write(f"| {k} | {pmc[k]:.6g} |\n")
