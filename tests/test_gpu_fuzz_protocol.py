@@ -84,7 +84,7 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
                       "hold", "hold", "drop"], size=nops)
     # state dictionaries taken at random steps and KEPT (in a list, in a dict under their id(), inside a closure): each must go on
     # showing the state it was taken from whatever happens to the material afterwards (the reference's dictionaries are copies,
-    # generic.py:265-277) -- hip_material.LazyInitialRows views, copies of the alternating flux buffers
+    # generic.py:265-277) -- lazy_rows.LazyInitialRows views, copies of the alternating flux buffers
     handouts, by_id, closures = [], {}, []
 
     def keep(got, want, how):
@@ -196,7 +196,7 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
             if by_id and rng.random() < 0.5:
                 by_id.pop(next(iter(by_id)))
         elif op == "look" and held is not None and lazy:
-            # a lazy ISV array is a VIEW of s1 as it is NOW (hip_material.LazyISV); the eager one is a snapshot
+            # a lazy ISV array is a VIEW of s1 as it is NOW (lazy_rows.LazyISV); the eager one is a snapshot
             a = np.asarray(held)
             assert a.shape == (n, 7)
             assert close(a[:, 0], model.s1["p"], max(model.s1["p"].max(), 1e-300) + 1e-30)

@@ -3,7 +3,7 @@ page-locked range table, the bit-exact tangent rebuilds, threaded row moves, upl
 and AddressSanitizer + UBSan, on the CPU box: ``tests/host_side_harness.cpp`` is compiled twice with clang++ and run on
 seeded inputs; its rebuilt tangent blocks are compared with ``oracle/host_rebuild_np.py`` (0 ulp against the fused-multiply-add
 emulation on a sample, 2 ulp-of-the-block against plain numpy on everything).  Also: the Python array reaper of
-``hip_material.py`` under ``faulthandler`` with 10^4 drops."""
+``lazy_rows.py`` under ``faulthandler`` with 10^4 drops."""
 import os
 import shutil
 import subprocess
@@ -123,7 +123,7 @@ def test_product_library_exports_the_same_host_code():
 
 
 def test_reaper_survives_ten_thousand_drops():
-    """``hip_material._Reaper``: 10^4 large arrays handed to the helper thread under ``faulthandler`` in a child interpreter; the
+    """``lazy_rows._Reaper``: 10^4 large arrays handed to the helper thread under ``faulthandler`` in a child interpreter; the
     queue drains, nothing crashes, and small arrays are left to the caller."""
     code = r"""
 import faulthandler, sys, time, threading
@@ -131,7 +131,7 @@ faulthandler.enable()
 faulthandler.dump_traceback_later(120, exit=True)
 import numpy as np
 sys.path.insert(0, %r)
-from dolfinx_materials_amd.hip_material import _Reaper
+from dolfinx_materials_amd.lazy_rows import _Reaper
 r = _Reaper()
 small = np.empty(10)
 r.drop(small); r.drop(None)
