@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # traced / custom hardening laws compile into private copies of the library: keep those of the test runs inside the tree
+    # (git- and gpurun-ignored `_jit/`), not under the user's ~/.cache (the product's default, _lib.jit_cache_dir)
+    os.environ.setdefault("DXM_JIT_CACHE", os.path.join(ROOT, "_jit"))
 
 
 def pytest_sessionstart(session):
