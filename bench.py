@@ -826,8 +826,13 @@ def check_hbm_budget(torch, dev, rank, world, blocks):
     """`blocks`: name -> hbm_plan(...) of the workloads this rank will run one after the other (each releases its arrays on return).
     One line per rank on stderr; SystemExit with a message when the largest exceeds 0.9 x the free HBM of this rank's GPU -- the
     first lease of a multi-GPU node should not be spent on an allocation failure 40 s into the run."""
-    free_b, total_b = torch.cuda.mem_get_info(dev)
     need = max(p["total"] for p in blocks.values())
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+    except Exception as exc:   # the check itself must never cost the run
+        print("[bench.py hbm budget] " + json.dumps({"rank": rank, "world": world, "largest_block_GB": round(need / 1e9, 2), "error": repr(exc)}),
+              file=sys.stderr, flush=True)
+        return None
     line = {"rank": rank, "world": world, "device": str(dev), "hbm_free_GB": round(free_b / 1e9, 2), "hbm_total_GB": round(total_b / 1e9, 2),
             "largest_block_GB": round(need / 1e9, 2), "blocks_GB": {k: {kk: round(vv / 1e9, 3) for kk, vv in p.items()} for k, p in blocks.items()}}
     print("[bench.py hbm budget] " + json.dumps(line), file=sys.stderr, flush=True)
