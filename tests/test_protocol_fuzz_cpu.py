@@ -127,3 +127,13 @@ def test_accelerated_map_on_the_test_double_writes_isvs_inside_integrate(fake):
     fast.close()
     for q in (fast, slow):
         q.material.close()
+
+
+@pytest.mark.parametrize("seed,subset", [(20, False), (21, True), (22, True), (23, False), (30, False), (31, True), (32, False), (33, True)])
+def test_field_map_sequences_on_the_test_double(fake, seed, subset):
+    """tests/test_gpu_fuzz_protocol.py's differential test one level up (the same random QuadratureFieldMap operations with
+    HIPMaterial behind one map and the oracle-backed material behind the other), with the test double under HIPMaterial: bound
+    Functions, ISV delivery inside `integrate` (the default mode), rows mode for maps over a subset of the cells."""
+    from test_gpu_fuzz_protocol import test_field_map_driven_by_the_engine_equals_field_map_driven_by_the_oracle as run
+
+    run(seed, subset)
