@@ -134,7 +134,10 @@ def test_cfg5_host_assembly_loop_at_64_cubed():
 
     out = run(n=64, steps=8, law="j2_linear", verbose=False, solver="krylov", layout="coef", device_gradient=True)
     assert out["points"] == 64 ** 3 * 8
-    _check_host_loop(out)
+    # (the multigrid-CG of examples/hex_fem.py stops at its own relative tolerance: at 8.2e5 dofs the first, elastic step is an
+    # inexact Newton with a linear tail -- 5 iterations measured -- while the plastic steps keep their 2)
+    _check_host_loop(out, max_iters=6)
+    assert all(step["iters"] <= 3 for step in out["history"][1:])
 
 
 def test_cfg5_device_resident_loop_at_its_stated_size_200_cubed():
