@@ -305,3 +305,45 @@ def test_elastic_known_answer_nu_zero():
     sig, _, Ct = mat.integrate(eps)
     assert np.allclose(sig[:, :3], 210e3 * np.array([1e-3, 0, 0]), rtol=1e-14, atol=1e-12)
     assert np.allclose(Ct[0], 210e3 * np.eye(6), rtol=1e-14)
+
+
+@pytest.mark.parametrize("kind", ["voce", "linear"])
+def test_hip_uniaxial_stress_paths_follow_the_closed_form_of_the_hardening_law(kind):
+    """The KERNELS against a known answer that does not go through the oracle: 257 points, each on its own uniaxial-stress path
+    (axial strain ramped to 0.3 ... 3 %), lateral strain found per point by Newton on sigma_yy = 0 with the kernel's own consistent
+    tangent (several `integrate` calls from one s0, then `advance`: the cadence of a global Newton loop).  Constant flow direction =>
+    the radial return is exact for any step:  sigma_xx = R(p),  eps_xx = sigma_xx / E + p,  eps_yy = -nu sigma_xx / E - p / 2,
+    with R the law of tests/test_FeFp_jax.py:14-15 / the linear law of the MFront spec."""
+    from scipy.optimize import brentq
+
+    el = jm.LinearElasticIsotropic(E=E, nu=NU)
+    if kind == "voce":
+        s0, hard = SIG0_V, jm.VoceHardening(SIG0_V, SIGU_V, B_V)
+        R = lambda q: SIG0_V + (SIGU_V - SIG0_V) * (1.0 - np.exp(-B_V * q))   # noqa: E731
+    else:
+        s0, hard = SIG0_LIN, jm.LinearHardening(SIG0_LIN, H_LIN)
+        R = lambda q: SIG0_LIN + H_LIN * q   # noqa: E731
+    n = 257
+    m = JAXMaterial(jm.vonMisesIsotropicHardening(el, hard))
+    m.set_data_manager(n)
+    emax = np.linspace(3e-3, 3e-2, n)
+    et = np.zeros(n)
+    for t in np.linspace(0.0, 1.0, 9)[1:]:
+        exx = t * emax
+        for it in range(40):
+            eps = np.zeros((n, 6))
+            eps[:, 0], eps[:, 1], eps[:, 2] = exx, et, et
+            sig, isv, ct = m.integrate(eps)
+            syy = sig[:, 1].copy()
+            if np.abs(syy).max() < 1e-10 * s0:
+                break
+            et = et - syy / (ct[:, 1, 1] + ct[:, 1, 2])
+        assert np.abs(syy).max() < 1e-10 * s0 and it < 12, (t, it)
+        pc = np.array([0.0 if e <= s0 / E else brentq(lambda q, e=e: R(q) / E + q - e, 0.0, e, xtol=1e-16, rtol=1e-15) for e in exx])
+        sc = np.where(pc == 0.0, E * exx, R(pc))
+        assert np.abs(sig[:, 0] - sc).max() < 1e-9 * s0 and np.abs(sig[:, 1:]).max() < 1e-9 * s0
+        assert np.abs(np.asarray(isv)[:, 0] - pc).max() < 1e-12 and np.abs(et - (-NU * sc / E - pc / 2)).max() < 1e-12
+        assert m.last_stats["n_not_converged"] == 0 and m.last_stats["n_nan"] == 0
+        m.data_manager.update()
+    assert (pc > 0).sum() > 200 and pc.max() > 1e-2
+    m.close()

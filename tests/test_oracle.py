@@ -196,6 +196,38 @@ def test_uniaxial_known_answer():
     assert np.allclose(r["sig"][0, :3], g["expected"], rtol=1e-2, atol=1e-8)
 
 
+@pytest.mark.parametrize("kind", ["voce", "linear"])
+def test_uniaxial_stress_path_follows_the_closed_form_of_the_hardening_law(kind):
+    """Known answer anchored on the reference's own law formula (`sig0 + (sigu - sig0) (1 - exp(-b p))`, tests/test_FeFp_jax.py:14-15,
+    plane_elastoplasticity.py:60-71): under uniaxial stress the flow direction is constant, so the backward-Euler radial return is
+    exact for any step size and  sigma_xx = R(p),  eps_xx = sigma_xx / E + p,  eps_yy = eps_zz = -nu sigma_xx / E - p / 2.
+    The lateral strain is found by Newton on sigma_yy = 0 with the oracle's own consistent tangent (which is thereby exercised);
+    numpy and C oracle."""
+    from scipy.optimize import brentq
+
+    hard, (k, s0, h1, h2) = HARDS[kind]
+    R = (lambda q: s0 + (h1 - s0) * (1.0 - np.exp(-h2 * q))) if kind == "voce" else (lambda q: s0 + h1 * q)
+    epsp, p = np.zeros((1, 6)), np.zeros(1)
+    et = 0.0
+    for exx in np.linspace(0.0, 3e-2, 13)[1:]:
+        for _ in range(30):     # lateral strain: sigma_yy(e_t) = 0, d sigma_yy / d e_t = Ct[1,1] + Ct[1,2]
+            eps = np.array([[exx, et, et, 0.0, 0.0, 0.0]])
+            r = onp.j2_update(eps, epsp, p, E, NU, hard)
+            syy = r["sig"][0, 1]
+            if abs(syy) < 1e-11 * s0:
+                break
+            et -= syy / (r["Ct"][0, 1, 1] + r["Ct"][0, 1, 2])
+        assert abs(syy) < 1e-11 * s0
+        pc = 0.0 if exx <= s0 / E else brentq(lambda q: R(q) / E + q - exx, 0.0, exx, xtol=1e-16, rtol=1e-15)
+        sc = E * exx if pc == 0.0 else R(pc)
+        assert abs(r["sig"][0, 0] - sc) < 1e-10 * sc and np.abs(r["sig"][0, 1:]).max() < 1e-10 * s0
+        assert abs(r["p"][0] - pc) < 1e-13 + 1e-10 * pc and abs(et - (-NU * sc / E - pc / 2)) < 1e-13
+        rc = oracle_c.j2(eps, epsp, p, E, NU, k, s0, h1, h2)
+        assert np.allclose(rc["sig"], r["sig"], rtol=0, atol=1e-10 * s0) and np.allclose(rc["p"], r["p"], rtol=0, atol=1e-14)
+        epsp, p = r["epsp"], r["p"]
+    assert pc > 1e-2      # well into the saturating part of the Voce curve
+
+
 # ---------------------------------------------------------------------------------------------
 # FeFp (parity unpinned; the oracle is pinned by construction checks only)
 # ---------------------------------------------------------------------------------------------
