@@ -187,6 +187,7 @@ struct dxm_material {
   int opt_keep_initial_io = 0;
   double* d_isv = nullptr;
   double* isv_out[DXM_MAX_STATE_FIELDS] = {};   // dxm_bind_isv_output: host rows the host-buffer forms deliver each field of s1 into
+  double* d_isv_fields = nullptr;   // field-major scratch of those deliveries in a call that ALSO fills isv_aos (d_isv holds the AoS rows then)
   double* d_ct = nullptr;
   double* d_field = nullptr;  // (n, <= 6) AoS scratch for set/get_state of one field
   // host-buffer form, strain in ordinary memory: page-locked ring the kernels read the chunks from (zero-copy)
@@ -463,6 +464,7 @@ int dxm_destroy(dxm_material* m) {
   if (m->d_grad0) (void)hipFree(m->d_grad0);
   if (m->d_flux0) (void)hipFree(m->d_flux0);
   if (m->d_isv) (void)hipFree(m->d_isv);
+  if (m->d_isv_fields) (void)hipFree(m->d_isv_fields);
   if (m->d_ct) (void)hipFree(m->d_ct);
   if (m->d_field) (void)hipFree(m->d_field);
   if (m->h_grad_ring) (void)hipHostFree(m->h_grad_ring);
@@ -1019,6 +1021,15 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     }
     for (hipEvent_t& e : m->ring_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  double* field_scratch = m->d_isv;
+  if (isv_aos && total > 0) {
+    bool delivering = false;
+    for (int f = 0; f < d.n_isv_fields; ++f) delivering = delivering || m->isv_out[f] != nullptr;
+    if (delivering) {
+      if (!m->d_isv_fields) HIP_TRY(hipMalloc(&m->d_isv_fields, sizeof(double) * n * total));
+      field_scratch = m->d_isv_fields;
+    }
+  }
   const bool any = m->opt_pageable_dma;
   const bool flux_locked = rowmode || any || page_locked(flux_aos, sizeof(double) * n * d.n_flux);   // rowmode: into h_flux
   const bool isv_locked = any || page_locked(isv_aos, sizeof(double) * n * total);
@@ -1114,11 +1125,13 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
         HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
                                hipMemcpyDeviceToHost, st));
     }
-    // fields of the final state bound to host rows (dxm_bind_isv_output: the x.array of the ISV Functions): the (N, total)
-    // device scratch holds them field after field, [n * sum of the dims before f] + off * dim_f
+    // fields of the final state bound to host rows (dxm_bind_isv_output: the x.array of the ISV Functions): an (N, total)
+    // device scratch holds them field after field, [n * sum of the dims before f] + off * dim_f -- d_isv itself when the call
+    // has no isv_aos, its own scratch when d_isv carries the interleaved rows of isv_aos (two layouts cannot share one area:
+    // the chunks alternate on two streams and a pageable isv_aos is downloaded from d_isv after the loop)
     for (int f = 0, before = 0; f < d.n_isv_fields; before += d.isv_dim[f], ++f) {
       if (!m->isv_out[f]) continue;
-      double* dev = m->d_isv + n * before + off * d.isv_dim[f];
+      double* dev = field_scratch + n * before + off * d.isv_dim[f];
       if (int rc = pack_isv_field_range(m, f, off, cnt, dev, st)) return rc;
       HIP_TRY(hipMemcpyAsync(m->isv_out[f] + off * d.isv_dim[f], dev, sizeof(double) * cnt * d.isv_dim[f], hipMemcpyDeviceToHost, st));
     }

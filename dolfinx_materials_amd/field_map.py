@@ -20,7 +20,62 @@ from __future__ import annotations
 
 import numpy as np
 
-from .quadrature_map import AcceleratedUpdate
+from .quadrature_map import AcceleratedUpdate, tangent_entries
+
+
+class Column:
+    """Stands for a scalar UFL expression over the quadrature points: component ``i`` of a :class:`Field` and what ``+ - * /``
+    make of such components and numbers.  ``evaluate()`` returns the ``(points,)`` values from the fields' CURRENT content --
+    like a UFL expression, it is built once (at map construction) and read at assembly time."""
+
+    ufl_shape = ()
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def evaluate(self):
+        return self._fn()
+
+    @staticmethod
+    def _value(x):
+        return x.evaluate() if isinstance(x, Column) else x
+
+    def __add__(self, other):
+        return Column(lambda: self.evaluate() + Column._value(other))
+
+    def __radd__(self, other):
+        return Column(lambda: Column._value(other) + self.evaluate())
+
+    def __sub__(self, other):
+        return Column(lambda: self.evaluate() - Column._value(other))
+
+    def __rsub__(self, other):
+        return Column(lambda: Column._value(other) - self.evaluate())
+
+    def __mul__(self, other):
+        return Column(lambda: self.evaluate() * Column._value(other))
+
+    def __rmul__(self, other):
+        return Column(lambda: Column._value(other) * self.evaluate())
+
+    def __truediv__(self, other):
+        return Column(lambda: self.evaluate() / Column._value(other))
+
+    def __neg__(self):
+        return Column(lambda: -self.evaluate())
+
+
+def evaluate_block(entries, rows=None):
+    """``(points, n, n)`` values of a nested list of :class:`Column` expressions (``QuadratureFieldMap.jacobians[block]``): what
+    a form compiler does with the UFL matrix at every quadrature point.  ``rows``: only these points."""
+    n, m = len(entries), len(entries[0])
+    first = np.asarray(Column._value(entries[0][0]))
+    out = np.empty(((len(first) if rows is None else len(rows)), n, m))
+    for i in range(n):
+        for j in range(m):
+            v = np.asarray(Column._value(entries[i][j]))
+            out[:, i, j] = v if rows is None else v[rows]
+    return out
 
 
 class _Flat:
@@ -40,6 +95,12 @@ class Field:
     @property
     def values(self):
         return self.x.array.reshape(-1, self.dim)
+
+    def __getitem__(self, i):
+        """Component ``i`` as an expression (a UFL ``Indexed`` of the Function this stands for)."""
+        if not 0 <= int(i) < self.dim:
+            raise IndexError(i)
+        return Column(lambda: self.values[:, int(i)])
 
 
 class _Evaluator:
@@ -85,6 +146,20 @@ class FieldMapBase:
         self.jacobian_width = getattr(material, "tangent_size", None) or sum(int(np.prod(s)) for s in material.tangent_blocks.values())
         self.jacobian_flatten = Field("jacobian", self.jacobian_width, total)
         self.fluxes = {name: Field(name, dim, total) for name, dim in material.fluxes.items()}
+        # quadrature_map.py:88-105: the block derivative() contracts, written in the entries of jacobian_flatten (and of the
+        # stress for the "pack4" layout) -- the same expression the dolfinx class gets (AcceleratedUpdate._accel_packed_jacobians)
+        layout = getattr(material, "tangent_layout", "full")
+        self.jacobians, col = {}, 0
+        for block, shape in material.tangent_blocks.items():
+            if layout == "full":
+                if self.jacobian_width != sum(int(np.prod(sh)) for sh in material.tangent_blocks.values()):
+                    break   # a material that sizes its tangent its own way without naming a layout: no block expression
+                jf = self.jacobian_flatten
+                self.jacobians[block] = [[jf[col + shape[1] * i + j] for j in range(shape[1])] for i in range(shape[0])]
+                col += int(np.prod(shape))
+            else:
+                self.jacobians[block] = tangent_entries(layout, self.jacobian_flatten, self.fluxes[block[0]], shape[0])
+        self._accel_jacobian_layout = layout
         self.internal_state_variables = {name: Field(name, dim, total) for name, dim in material.internal_state_variables.items()}
         self.gradients, self.external_state_variables = {}, {}
         self.rotation_func = None
@@ -126,6 +201,13 @@ class QuadratureFieldMap(AcceleratedUpdate, FieldMapBase):
 
     def _jacobian_width(self):
         return self.jacobian_width
+
+    def tangent_block_values(self, block=None, rows=None):
+        """``jacobians[block]`` evaluated at the quadrature points, ``(points, nf, ng)``: the full block whatever the layout of
+        ``jacobian_flatten`` (what an assembly over this map consumes)."""
+        if block is None:
+            (block,) = self.jacobians
+        return evaluate_block(self.jacobians[block], rows)
 
     # names used by the examples and tests
     @property

@@ -31,7 +31,13 @@ same job with what the engine offers:
   between, which is why it is not the default; ``False`` writes them at ``advance()`` only;
 * the four phases carry the reference's timer names (``"dx_mat: ..."``, ``quadrature_map.py:302-331``), so ``list_timings`` keeps
   its rows;
-* optionally the gradient is evaluated on the GPU from the displacement vector (``register_device_gradient``).
+* optionally the gradient is evaluated on the GPU from the displacement vector (``register_device_gradient``);
+* a material created with a packed ``tangent_layout`` (``"sym"`` 21, ``"coef"`` 9, ``"pack4"`` 4 doubles per point instead of
+  36) gets a ``jacobian_flatten`` of exactly that width and ``jacobians[block]`` -- the UFL matrix ``derivative()`` contracts
+  (``quadrature_map.py:83-105, :132-158``) -- written in terms of it: an index-only change for ``"sym"``;
+  ``c1 1x1 + c2 I + c3 n x n`` for ``"coef"``; the same with ``n = dev(stress) w`` taken from the flux Function the map already
+  owns for ``"pack4"`` (the assembly-side consumer).  The host then receives 48 + 32 B/point of
+  stress + tangent and rebuilds nothing; ``derivative()`` itself is inherited unchanged.
 
 With a material that offers none of this (any duck-typed ``Material``: the oracle-backed one of the tests, a
 ``generic.Material`` subclass) the same methods fall back to plain row copies and host-side NaN checks; results are
@@ -71,6 +77,56 @@ def _slow_path_warning(what, exc):
 
 def _same_memory(a, b):
     return a.size == b.size and a.ctypes.data == b.ctypes.data
+
+
+def sym_position(i, j, n=6):
+    """Where entry ``(i, j)`` of a symmetric ``n x n`` block sits among its ``n (n + 1) / 2`` upper-triangle entries stored row by
+    row (``conventions.SYM_IDX``; the kernels' ``TL_SYM`` order)."""
+    i, j = (i, j) if i <= j else (j, i)
+    return i * n - i * (i - 1) // 2 + (j - i)
+
+
+def tangent_entries(layout, jf, flux=None, n=6):
+    """The ``n x n`` tangent block of one point as a nested list of scalar expressions in the entries of ``jf`` (the tangent
+    quadrature Function of the layout's width) and, for ``"pack4"``, of ``flux`` (the stress Function of the same update).
+    Only indexing and ``+ - * /`` are used, so ``jf`` / ``flux`` may be UFL Functions (then ``to_mat`` of the result is what
+    ``quadrature_map.py:92-104`` builds by indexing a 36-wide Function), :class:`field_map.Field` objects (numpy columns: the
+    stand-in assembly evaluates the same expression) or plain arrays.
+
+    * ``"full"``: ``jf[n i + j]`` (``quadrature_map.py:97``);
+    * ``"sym"``: ``jf[sym_position(i, j)]`` -- 21 entries for a 6 x 6 block;
+    * ``"coef"``: ``jf = (c1, c2, c3, n[0..5])``, ``Ct = c1 1x1 + c2 I + c3 n x n`` in the Mandel basis, ``1 = (1,1,1,0,0,0)``
+      (``tests/mfront/IsotropicLinearHardeningPlasticity.mfront:66-69`` with ``M`` expanded, ``include/dxmat.h`` DXM_TANGENT_COEF);
+    * ``"pack4"``: ``jf = (c1, c2, c3, w)`` and ``n = dev(flux) w`` -- the kernels build their own block from ``n`` in exactly
+      this form (``csrc/small_strain.hpp`` step 5), so nothing is lost; elastic points carry ``c3 = 0, w = 0``."""
+    if layout == "full":
+        return [[jf[n * i + j] for j in range(n)] for i in range(n)]
+    if layout == "sym":
+        return [[jf[sym_position(i, j, n)] for j in range(n)] for i in range(n)]
+    if layout not in ("coef", "pack4") or n != 6:
+        raise ValueError(f"no tangent expression for layout {layout!r} and a {n} x {n} block")
+    c1, c2, c3 = jf[0], jf[1], jf[2]
+    if layout == "coef":
+        nn = [jf[3 + k] for k in range(6)]
+    else:
+        if flux is None:
+            raise ValueError("the 'pack4' layout rebuilds the flow direction from the stress: pass the flux Function")
+        w = jf[3]
+        third = (flux[0] + flux[1] + flux[2]) / 3
+        nn = [(flux[k] - third) * w for k in range(3)] + [flux[k] * w for k in range(3, 6)]
+    rows = []
+    for i in range(6):
+        row = []
+        for j in range(6):
+            # the kernels' association (small_strain.hpp tangent_pair): (c1 + c2) + c3 (n_i n_j), symmetric in (i, j) as written
+            entry = c3 * (nn[i] * nn[j])
+            if i < 3 and j < 3:
+                entry = ((c1 + c2) if i == j else c1) + entry
+            elif i == j:
+                entry = c2 + entry
+            row.append(entry)
+        rows.append(row)
+    return rows
 
 
 class _LazyFields(dict):
@@ -136,6 +192,50 @@ class AcceleratedUpdate:
     #: ``False``: at ``advance()`` only
     isv_every_update = True
 
+    # ---- construction: the tangent Function and the matrix derivative() contracts -------------------------------
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        layout = getattr(self.material, "tangent_layout", "full")
+        if layout != "full" and self.__dict__.get("_accel_jacobian_layout", "full") != layout:
+            self._accel_packed_jacobians(layout)
+
+    def _accel_packed_jacobians(self, layout):
+        """``WJ`` / ``jacobian_flatten`` / ``jacobians`` of ``quadrature_map.py:83-105`` for a material that returns its tangent
+        packed (``material.tangent_layout``: ``"sym"`` / ``"coef"`` / ``"pack4"``, ``material.tangent_size`` doubles per point):
+        the Function gets the packed width and ``jacobians[block]`` is :func:`tangent_entries` of it -- what ``derivative()``
+        (``:147, :156``) contracts with the variation of the gradient.  The reference constructor has built the 36-wide
+        Function by then; it is dropped here (a transient allocation at construction, never one per update).
+
+        ``"pack4"`` reads the stress Function of the map, which every ``update()`` writes together with the four coefficients,
+        so the pair is consistent whenever a form is assembled; the tangent of a point is a function of its own stress, which
+        ``derivative()`` treats as data (it differentiates F, not the block)."""
+        m = self.material
+        if len(m.tangent_blocks) != 1:
+            raise ValueError("packed tangent layouts are defined for materials with one (flux, gradient) block")
+        ((block, shape),) = m.tangent_blocks.items()
+        if getattr(m, "rotation_matrix", None) is not None:
+            raise ValueError("a packed tangent cannot be rotated block by block (quadrature_map.py:326-330): use tangent_layout='full'")
+        if shape[0] != shape[1] or (layout in ("coef", "pack4") and shape[0] != 6):
+            raise ValueError(f"tangent layout {layout!r} is not defined for a {shape} block")
+        width = int(m.tangent_size)
+        ns = self._accel_reference_namespace()
+        self.WJ = ns["create_quadrature_functionspace"](self.mesh, self.degree, width)
+        self.jacobian_flatten = ns["fem"].Function(self.WJ)
+        flux = self.fluxes[block[0]] if layout == "pack4" else None
+        self.jacobians = {block: ns["to_mat"](tangent_entries(layout, self.jacobian_flatten, flux, shape[0]))}
+        self.__dict__["_accel_jacobian_layout"] = layout
+        self.__dict__["_accel_jacobian_width"] = width
+
+    def _accel_reference_namespace(self):
+        """The module namespace of the reference class under this mixin (``fem``, ``create_quadrature_functionspace``,
+        ``to_mat``: ``quadrature_map.py:4-11``) -- the names its own constructor built ``jacobian_flatten`` with."""
+        for klass in type(self).__mro__:
+            init = klass.__dict__.get("__init__")
+            ns = getattr(init, "__globals__", None)
+            if ns is not None and "create_quadrature_functionspace" in ns and "to_mat" in ns and "fem" in ns:
+                return ns
+        raise TypeError("a packed tangent layout needs the reference's QuadratureMap (or field_map.FieldMapBase) under AcceleratedUpdate")
+
     # ---- set-up, once ------------------------------------------------------------------------------------------
     def _accel_plan(self):
         plan = self.__dict__.get("_accel")
@@ -160,8 +260,8 @@ class AcceleratedUpdate:
         plan.grad_buffers, plan.state_buffers = {}, {}
         width = getattr(m, "tangent_size", None)
         if width is not None and int(width) != self._jacobian_width():
-            raise ValueError(f"the material returns {width} tangent entries per point (a packed tangent_layout) but jacobian_flatten "
-                             f"holds {self._jacobian_width()} (quadrature_map.py:83-105): create the material with tangent_layout='full'")
+            raise ValueError(f"the material returns {width} tangent entries per point but jacobian_flatten holds {self._jacobian_width()} "
+                             "(quadrature_map.py:83-105): the map was not constructed through AcceleratedUpdate.__init__ with this material")
         # results straight into the Functions: one flux, full-width tangent, and a material that can take caller arrays
         if plan.identity and plan.npoints > 0 and len(self.fluxes) == 1 and hasattr(m, "bind_outputs"):
             (flux_fun,) = self.fluxes.values()
@@ -213,7 +313,9 @@ class AcceleratedUpdate:
         return d.raw() if isinstance(d, _LazyFields) else d
 
     def _jacobian_width(self):
-        return int(sum(int(np.prod(shape)) for shape in self.material.tangent_blocks.values())) or 1
+        """Doubles per point of ``jacobian_flatten``: the packed width when the constructor built it for a packed layout."""
+        packed = self.__dict__.get("_accel_jacobian_width")
+        return int(packed) if packed else (int(sum(int(np.prod(shape)) for shape in self.material.tangent_blocks.values())) or 1)
 
     def register_device_gradient(self, mesh, displacement):
         """Evaluate the gradient on the GPU from the nodal vector ``displacement()`` returns (``gradient.Hex8Mesh`` /

@@ -141,7 +141,12 @@ enum { DXM_TANGENT_FULL = 0, DXM_TANGENT_SYM = 1, DXM_TANGENT_COEF = 2, DXM_TANG
 int dxm_set_tangent_layout(dxm_material* m, int layout);
 /* doubles per point of the tangent array integrate writes (36 / 21 / 9 / 81). */
 int dxm_tangent_size(const dxm_material* m);
-/* Local Newton controls: stop when |r| <= rtol * sig0, at most maxit iterations. */
+/* Local Newton controls (Voce / traced hardening, FeFp): at most maxit iterations, stop when
+ *   |r| <= max(tol, rtol * sigma_eq_trial),   tol = rtol * max(|sig0|, 2e-8 mu)
+ * (an absolute floor from the initial yield stress -- or from the shear modulus when sig0 is 0 -- and a relative term that
+ * follows the trial von Mises stress of the point: csrc/small_strain.hpp, csrc/dxm_common.hpp J2Params.tol / .rtol).
+ * FeFp solves two equations: the same bound on the yield residual (as a Kirchhoff stress) AND |det(be_bar) - 1| <= 1e-14.
+ * Points that stop at maxit are counted in dxm_stats.n_not_converged (and are the positive return value of the integrate calls). */
 int dxm_set_newton(dxm_material* m, int maxit, double rtol);
 
 /* ---- state: set_initial_state_dict / get_initial_state_dict / get_final_state_dict

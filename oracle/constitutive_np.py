@@ -162,7 +162,9 @@ def _solve_dp(seq, p_n, mu, hard, maxit=NEWTON_MAXIT, rtol=NEWTON_RTOL):
 # ----------------------------------------------------------------------------------------
 def j2_update(eps, epsp_n, p_n, E, nu, hard):
     """Returns dict(sig (N,6), epsp (N,6), p (N,), Ct (N,6,6), plastic (N,) bool,
-    iters (N,) int, f_trial (N,))."""
+    iters (N,) int, f_trial (N,)) and what ``Ct = c1 1x1 + c2 I + c3 n x n`` is made of: coef (N,3) = (c1, c2, c3), n (N,6) the
+    flow direction (zero at elastic points) and w (N,) with n = dev(sig) w (the return is radial: dev(sig) = (1 - 3 mu dp / seq)
+    s_trial, hence w = 3/2 / (seq - 3 mu dp); zero at elastic points)."""
     eps = np.asarray(eps, dtype=np.float64)
     epsp_n = np.asarray(epsp_n, dtype=np.float64)
     p_n = np.asarray(p_n, dtype=np.float64).reshape(-1)
@@ -207,7 +209,10 @@ def j2_update(eps, epsp_n, p_n, E, nu, hard):
         + c2[:, None, None] * np.eye(6)[None]
         + c3[:, None, None] * n[:, :, None] * n[:, None, :]
     )
-    return dict(sig=sig, epsp=epsp, p=p, Ct=Ct, plastic=plastic, iters=iters, f_trial=f_trial)
+    w = np.zeros(N)
+    if plastic.any():
+        w[idx] = 1.5 / (seq[idx] - 3 * mu * dp[idx])
+    return dict(sig=sig, epsp=epsp, p=p, Ct=Ct, plastic=plastic, iters=iters, f_trial=f_trial, coef=np.stack([c1, c2, c3], axis=1), n=n, w=w)
 
 
 def j2_update_mfront_form(deto, eel_n, p_n, E, nu, H, s0):

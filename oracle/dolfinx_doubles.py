@@ -14,7 +14,11 @@ replaced, by the data model those calls rely on:
   component fastest (what ``_cell_to_dofs`` and ``_update_vals`` assume, ``quadrature_map.py:255-260``, ``utils.py:136-143``);
 * ``fem.Expression(expr, points).eval(mesh, cells[, values])`` returns / fills ``(len(cells), nqp * dim)``; the "UFL
   expression" handed to ``register_gradient`` is an :class:`PointwiseExpression` around a callable ``cells -> rows``;
-* UFL algebra (``as_matrix``, indexing a Function) only builds inert placeholders: forms are not on the update path.
+* UFL algebra is a scalar expression tree that can be EVALUATED per quadrature point: indexing a Function gives a
+  :class:`Scalar` that reads the Function's current ``x.array`` column, ``+ - * /`` combine them, ``ufl.as_matrix`` /
+  ``ufl.as_vector`` keep their entries (:class:`_Tensor`, ``.evaluate() -> (points, ...)``).  That is what lets a test read
+  ``QuadratureMap.jacobians[block]`` (``quadrature_map.py:88-105``) numerically, the way a compiled form would at assembly.
+  Forms themselves (``ufl.derivative``, measures) stay out: they are not on the update path.
 
 Used by ``tests/test_reference_quadrature_map.py`` (the accelerated mixin over the real class against the real class) and by
 ``tests/golden/make_quadrature_map_golden.py`` (fields the reference's ``update()`` / ``advance()`` leave, as fixtures).
@@ -102,8 +106,44 @@ class _X:
         self.array = np.zeros(n)
 
 
-class _Indexed:
+class Scalar:
+    """A scalar UFL expression over the quadrature points, evaluated lazily from the Functions' current content."""
+
     ufl_shape = ()
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def evaluate(self):
+        return self._fn()
+
+    @staticmethod
+    def value(x):
+        return x.evaluate() if isinstance(x, Scalar) else x
+
+    def __add__(self, o):
+        return Scalar(lambda: self.evaluate() + Scalar.value(o))
+
+    def __radd__(self, o):
+        return Scalar(lambda: Scalar.value(o) + self.evaluate())
+
+    def __sub__(self, o):
+        return Scalar(lambda: self.evaluate() - Scalar.value(o))
+
+    def __rsub__(self, o):
+        return Scalar(lambda: Scalar.value(o) - self.evaluate())
+
+    def __mul__(self, o):
+        return Scalar(lambda: self.evaluate() * Scalar.value(o))
+
+    def __rmul__(self, o):
+        return Scalar(lambda: Scalar.value(o) * self.evaluate())
+
+    def __truediv__(self, o):
+        return Scalar(lambda: self.evaluate() / Scalar.value(o))
+
+    def __neg__(self):
+        return Scalar(lambda: -self.evaluate())
 
 
 class Function:
@@ -118,7 +158,10 @@ class Function:
         return self.ufl_shape[0]
 
     def __getitem__(self, i):
-        return _Indexed()
+        dim = int(np.prod(self.ufl_shape)) if self.ufl_shape else 1
+        if not 0 <= int(i) < dim:
+            raise IndexError(i)
+        return Scalar(lambda: self.x.array.reshape(-1, dim)[:, int(i)])
 
 
 class Expression:
@@ -134,8 +177,24 @@ class Expression:
 
 
 class _Tensor:
-    def __init__(self, shape):
-        self.ufl_shape = shape
+    """``ufl.as_matrix`` / ``ufl.as_vector`` of scalar expressions: keeps the entries."""
+
+    def __init__(self, shape, entries=None):
+        self.ufl_shape, self.entries = shape, entries
+
+    def __getitem__(self, idx):
+        e = self.entries
+        for k in (idx if isinstance(idx, tuple) else (idx,)):
+            e = e[k]
+        return e
+
+    def evaluate(self):
+        """``(points,) + ufl_shape`` values."""
+        flat = [e for row in self.entries for e in row] if len(self.ufl_shape) == 2 else list(self.entries)
+        cols = [np.asarray(Scalar.value(e), dtype=np.float64) for e in flat]
+        npts = max((c.shape[0] for c in cols if c.ndim), default=1)
+        out = np.stack([np.broadcast_to(c, (npts,)) for c in cols], axis=1)
+        return out.reshape((npts,) + tuple(self.ufl_shape))
 
 
 class Timer:
@@ -164,10 +223,10 @@ def _modules():
     ufl.shape = lambda f: f.ufl_shape
 
     def as_matrix(rows):
-        return _Tensor((len(rows), len(rows[0])))
+        return _Tensor((len(rows), len(rows[0])), [list(r) for r in rows])
 
     ufl.as_matrix = as_matrix
-    ufl.as_vector = lambda comps: _Tensor((len(comps),))
+    ufl.as_vector = lambda comps: _Tensor((len(comps),), list(comps))
     ufl.log = m["ufl.log"]
     ufl.log.UFLValueError = ValueError
     basix = m["basix"]

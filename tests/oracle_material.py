@@ -59,3 +59,24 @@ class OracleJ2Material:
         self.s1 = dict(strain=np.array(g), stress=r["sig"], p=r["p"][:, None], epsp=r["epsp"])
         self.last_stats = dict(n_nan=int(np.isnan(r["sig"]).any()), n_plastic=int(r["plastic"].sum()))
         return r["sig"], np.hstack([r["p"][:, None], r["epsp"]]), r["Ct"]
+
+
+class PackedOracleJ2Material(OracleJ2Material):
+    """The same law handing its tangent out packed, like ``HIPMaterial(tangent_layout=...)``: ``"sym"`` the 21 upper-triangle
+    entries, ``"coef"`` (c1, c2, c3, n[6]), ``"pack4"`` (c1, c2, c3, w) with n = dev(stress) w."""
+
+    def __init__(self, E, nu, hard, tangent_layout):
+        super().__init__(E, nu, hard)
+        self.tangent_layout = tangent_layout
+        self.tangent_size = {"full": 36, "sym": 21, "coef": 9, "pack4": 4}[tangent_layout]
+
+    def integrate(self, g, dt=0):
+        from dolfinx_materials_amd.conventions import pack_sym_tangent
+
+        r = onp.j2_update(g, self.s0["epsp"], self.s0["p"][:, 0], self.E, self.nu, self.hard)
+        self.s1 = dict(strain=np.array(g), stress=r["sig"], p=r["p"][:, None], epsp=r["epsp"])
+        self.last_stats = dict(n_nan=int(np.isnan(r["sig"]).any()), n_plastic=int(r["plastic"].sum()))
+        ct = {"full": lambda: r["Ct"], "sym": lambda: pack_sym_tangent(r["Ct"]), "coef": lambda: np.hstack([r["coef"], r["n"]]),
+              "pack4": lambda: np.hstack([r["coef"], r["w"][:, None]])}[self.tangent_layout]()
+        self.full_tangent = r["Ct"]
+        return r["sig"], np.hstack([r["p"][:, None], r["epsp"]]), ct

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 E, NU, SIG0, H = 70e3, 0.3, 250.0, 5e3
 
 
-def _setup(n=3, deg_quad=2, accelerated=False):
+def _setup(n=3, deg_quad=2, accelerated=False, tangent_layout="full"):
     import ufl
     from dolfinx import fem, mesh
     if accelerated:   # the third import swap of INTEGRATION.md section 1
@@ -34,7 +34,8 @@ def _setup(n=3, deg_quad=2, accelerated=False):
     domain = mesh.create_unit_cube(MPI.COMM_WORLD, n, n, n, mesh.CellType.hexahedron)
     V = fem.functionspace(domain, ("P", 1, (3,)))
     u = fem.Function(V, name="Displacement")
-    material = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)))
+    material = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)),
+                           tangent_layout=tangent_layout)
     qmap = QuadratureMap(domain, deg_quad, material)
     strain = lambda w: symmetric_tensor_to_vector(ufl.sym(ufl.grad(w)))   # noqa: E731  (Mandel: utils.py:146-165)
     qmap.register_gradient(material.gradient_names[0], strain(u))
@@ -134,6 +135,87 @@ def test_snes_solve_reaches_the_closed_form_uniaxial_answer(accelerated):
     expect = (SIG0 + H * exx) / (1 + H / E)
     sxx = qmap.fluxes["stress"].x.array.reshape(-1, 6)[:, 0]
     assert np.allclose(sxx, expect, rtol=1e-7)
+
+
+@pytest.mark.parametrize("layout", ["sym", "coef", "pack4"])
+def test_tangent_form_over_a_packed_jacobian_function_assembles_the_same_matrix(layout):
+    """SURVEY 8(f) row 4, the UFL side: the accelerated map of a packed-tangent material has a ``jacobian_flatten`` of 21 / 9 / 4
+    components and ``jacobians[block]`` written in terms of it (and of the stress Function for ``"pack4"``);
+    ``qmap.derivative(Res, u, du)`` -- the reference's method, unchanged -- assembled over it gives the matrix of the full
+    36-component map at the same plastic state."""
+    import ufl
+    from dolfinx import fem
+    from dolfinx.fem.petsc import assemble_matrix
+
+    full = _setup(accelerated=True)
+    packed = _setup(accelerated=True, tangent_layout=layout)
+    width = {"sym": 21, "coef": 9, "pack4": 4}[layout]
+    npts = len(packed[4].dofs)
+    assert packed[4].jacobian_flatten.x.array.size == npts * width and full[4].jacobian_flatten.x.array.size == npts * 36
+    x = full[1].tabulate_dof_coordinates()
+    mats = []
+    for domain, V, u, material, qmap, strain in (full, packed):
+        du, v = ufl.TrialFunction(V), ufl.TestFunction(V)
+        Res = ufl.dot(qmap.fluxes["stress"], strain(v)) * qmap.dx
+        Jac = fem.form(qmap.derivative(Res, u, du))
+        u.x.array[:] = (x @ (5e-3 * np.random.default_rng(7).standard_normal((3, 3))).T).reshape(-1)
+        u.x.array[:] += 3e-4 * np.sin(7.0 * x).reshape(-1)      # a non-homogeneous state: every point its own direction
+        qmap.update()
+        assert material.last_stats["n_plastic"] > 0
+        A = assemble_matrix(Jac)
+        A.assemble()
+        mats.append(A)
+    assert np.array_equal(full[4].fluxes["stress"].x.array, packed[4].fluxes["stress"].x.array)
+    diff = mats[0].copy()
+    diff.axpy(-1.0, mats[1])
+    assert diff.norm() <= 1e-12 * mats[0].norm()
+    for _, _, _, _, qmap, _ in (full, packed):
+        qmap.close()
+
+
+@pytest.mark.parametrize("layout", ["sym", "pack4"])
+def test_snes_solve_with_a_packed_tangent_reaches_the_closed_form_answer_in_as_many_iterations(layout):
+    """The Newton loop of ``tests/uniaxial_tension.py`` in 3-D over a packed-tangent map: same closed-form stress, and the
+    iteration counts of the full-layout run (the tangent is the same operator)."""
+    its = {}
+    for lay in ("full", layout):
+        its[lay] = _uniaxial(_setup(n=3, accelerated=True, tangent_layout=lay))
+    assert its[layout] == its["full"]
+
+
+def _uniaxial(setup):
+    import ufl
+    from dolfinx import fem
+    from dolfinx_materials.solvers import NonlinearMaterialProblem
+
+    domain, V, u, material, qmap, strain = setup
+    du, v = ufl.TrialFunction(V), ufl.TestFunction(V)
+    Res = ufl.dot(qmap.fluxes["stress"], strain(v)) * qmap.dx
+    Jac = qmap.derivative(Res, u, du)
+    fdim = domain.topology.dim - 1
+    ux, bcs = None, []
+    for axis, value in ((0, 0.0), (1, 0.0), (2, 0.0), (0, 1.0)):
+        facets = dolfinx.mesh.locate_entities_boundary(domain, fdim, lambda x: np.isclose(x[axis], value))
+        Vs, _ = V.sub(axis).collapse()
+        dofs = fem.locate_dofs_topological((V.sub(axis), Vs), fdim, facets)
+        g = fem.Function(Vs)
+        if value == 1.0:
+            ux = g
+        bcs.append(fem.dirichletbc(g, dofs, V.sub(axis)))
+    opts = {"snes_type": "newtonls", "snes_linesearch_type": "none", "snes_atol": 1e-10, "snes_rtol": 1e-10,
+            "ksp_type": "preonly", "pc_type": "lu"}   # tests/uniaxial_tension.py:74-82
+    problem = NonlinearMaterialProblem(qmap, Res, u, bcs=bcs, J=Jac, petsc_options_prefix="amd_packed", petsc_options=opts)
+    qmap.update()
+    iterations = []
+    for k in range(1, 9):
+        exx = 2e-2 * k / 8
+        ux.x.array[:] = exx
+        problem.solve()
+        iterations.append(problem.solver.getIterationNumber())   # the SNES of solvers.py:182-196
+    expect = (SIG0 + H * exx) / (1 + H / E)
+    assert np.allclose(qmap.fluxes["stress"].x.array.reshape(-1, 6)[:, 0], expect, rtol=1e-7)
+    qmap.close()
+    return iterations
 
 
 def test_device_gradient_adapter_matches_the_ufl_expression():

@@ -407,6 +407,53 @@ def test_results_are_delivered_into_bound_caller_arrays():
     flux_fn[:] = 0.0   # unregistered again: ordinary memory
 
 
+@pytest.mark.parametrize("pinned_isv", [False, True])
+@pytest.mark.parametrize("kind,n", [("linear", 300_001), ("voce", 2_200_000)])
+def test_eager_isv_rows_and_bound_field_deliveries_in_one_call(kind, n, pinned_isv):
+    """``lazy_isv=False`` (isv_aos handed to ``dxm_integrate``: interleaved (N, 7) rows) together with
+    ``bind_state_outputs(deliver=True)`` (``dxm_bind_isv_output``: field-major rows into the ISV Functions) in a call of many
+    chunks on two streams: the two layouts have their own device scratch (``dxmat.hip``: ``d_isv`` / ``d_isv_fields``), both for a
+    pageable isv_aos (filled after the chunk loop) and a page-locked one (filled by DMA inside it)."""
+    import ctypes as C
+
+    ref_m, m = _j2(kind), _j2(kind, lazy_isv=False)
+    ref_m.set_data_manager(n)
+    m.set_data_manager(n)
+    fields = {name: np.full(n * dim, np.nan) for name, dim in m.internal_state_variables.items()}
+    m.bind_state_outputs(fields, deliver=True)
+    assert m.delivers_state_outputs == frozenset(fields)
+    total = sum(m.internal_state_variables.values())
+    lib, h = m._lib, m._handles()[0]
+    own = _lib.PinnedArray((n, total)) if pinned_isv else None
+    isv_rows = own.array if pinned_isv else np.empty((n, total))
+    flux, ct = np.empty((n, 6)), np.empty((n, 6, 6))
+    st = _lib.Stats()
+    for eps in j2_history(n, seed=17, sig0=SIG0_LIN if kind == "linear" else SIG0_V)[:3]:
+        f0, i0, c0 = ref_m.integrate(eps)
+        i0 = np.asarray(i0)
+        # through the protocol: eager rows returned AND the Functions' memory written by the same call
+        f1, i1, c1 = m.integrate(eps)
+        assert isinstance(i1, np.ndarray) and np.array_equal(i1, i0) and np.array_equal(f1, f0) and np.array_equal(c1, c0)
+        col = 0
+        for name, dim in m.internal_state_variables.items():
+            assert np.array_equal(fields[name].reshape(n, dim), i0[:, col:col + dim]), name
+            fields[name][:] = np.nan
+            col += dim
+        # straight through the C ABI with the caller's own isv_aos (pageable / page-locked)
+        isv_rows[...] = np.nan
+        rc = lib.dxm_integrate(h, eps.ctypes.data_as(C.c_void_p), 0.0, flux.ctypes.data_as(C.c_void_p), isv_rows.ctypes.data_as(C.c_void_p),
+                               ct.ctypes.data_as(C.c_void_p), C.byref(st))
+        assert rc == 0 and np.array_equal(isv_rows, i0) and np.array_equal(flux, f0) and np.array_equal(ct, c0)
+        col = 0
+        for name, dim in m.internal_state_variables.items():
+            assert np.array_equal(fields[name].reshape(n, dim), i0[:, col:col + dim]), name
+            col += dim
+        ref_m.data_manager.update()
+        m.data_manager.update()
+    m.close()
+    ref_m.close()
+
+
 def test_options_replace_environment_variables():
     m = _j2()
     m.set_data_manager(1000)

@@ -375,3 +375,58 @@ def test_default_mode_writes_the_isv_functions_inside_the_update_itself(law, nce
         q.close()
         q.material.close()
     assert fast.material.delivers_state_outputs == frozenset()
+
+
+@pytest.mark.parametrize("law,layout,ncell,nqp,subset", [
+    ("j2_linear", "sym", 37, 4, False), ("j2_voce", "sym", 5001, 8, True), ("elastic", "sym", 4200, 8, False),
+    ("j2_linear", "coef", 4200, 8, False), ("j2_voce", "coef", 37, 4, True),
+    ("j2_linear", "pack4", 37, 4, True), ("j2_voce", "pack4", 5001, 8, False), ("j2_linear", "pack4", 40_000, 8, False)])
+def test_jacobians_of_a_packed_map_evaluate_to_the_block_of_the_full_map(law, layout, ncell, nqp, subset):
+    """The assembly-side consumer: a map whose material hands the tangent out packed holds a ``jacobian_flatten``
+    of 21 / 9 / 4 doubles per point and ``jacobians[block]`` in terms of it (and of the stress field for ``"pack4"``) -- the
+    expression ``derivative()`` contracts.  Evaluated at the quadrature points it must be the 6x6 block of the full-layout map:
+    bit for bit for ``"sym"`` (same kernel arithmetic, 21 of the 36 entries stored) and for ``"coef"`` / ``"pack4"`` to the rounding of
+    the one fused multiply-add the kernel uses per entry (1e-15 of the block's scale); flux and state fields are identical bit
+    for bit.  320 000 points: many chunks on two streams with the 80 B/point download and no host rebuild."""
+    n = ncell * nqp
+    rng = np.random.default_rng(5)
+    cells = np.sort(rng.choice(ncell, size=(ncell * 9) // 10, replace=False)).astype(np.int32) if subset else None
+    sig0 = SIG0_V if law == "j2_voce" else SIG0_LIN
+    hist = j2_history(n, seed=3, sig0=sig0)
+    now = {"g": hist[0]}
+    ev = lambda c: now["g"].reshape(ncell, nqp, 6)[c].reshape(-1, 6)   # noqa: E731
+    behavior = (lambda: jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU))) if law == "elastic" else (lambda: _behavior(law))
+    full = QuadratureFieldMap(ncell, nqp, JAXMaterial(behavior()), cells=cells)
+    packed = QuadratureFieldMap(ncell, nqp, JAXMaterial(behavior(), tangent_layout=layout), cells=cells)
+    width = {"sym": 21, "coef": 9, "pack4": 4}[layout]
+    assert packed.jacobian_flatten.x.array.size == n * width and packed.material.tangent_size == width
+    for q in (full, packed):
+        q.register_gradient("strain", ev)
+    rows = full.dofs
+    plastic = 0
+    for k, g in enumerate(hist):
+        now["g"] = g
+        for q in (full, packed):
+            q.update()
+        for name in _fields(full):
+            if name != "jacobian":
+                assert np.array_equal(_fields(packed)[name], _fields(full)[name]), (k, name)
+        want = full.tangent_block_values(rows=rows)
+        assert np.array_equal(want, full.jacobian_flatten.x.array.reshape(-1, 6, 6)[rows])
+        got = packed.tangent_block_values(rows=rows)
+        if layout == "sym":
+            assert np.array_equal(got, want), k
+        else:
+            assert np.abs(got - want).max() <= 1e-15 * np.abs(want).max(), (k, np.abs(got - want).max())
+        plastic += full.material.last_stats["n_plastic"]
+        assert packed.material.last_stats == full.material.last_stats
+        for q in (full, packed):
+            q.advance()
+        for name in _fields(full):
+            if name != "jacobian":
+                assert np.array_equal(_fields(packed)[name], _fields(full)[name]), (k, "advance", name)
+    assert plastic > 0 or law == "elastic"
+    assert packed._bound == (not subset)     # the packed Function's memory IS the material's output array for a map over all cells
+    for q in (full, packed):
+        q.close()
+        q.material.close()

@@ -296,10 +296,12 @@ def test_the_mixin_only_uses_the_reference_classs_attribute_surface():
     own = {n for n in vars(AcceleratedUpdate)} | {"__dict__", "_last_isv"}
     reference_surface = {"material", "mesh", "cells", "dofs", "gradients", "fluxes", "internal_state_variables",
                          "external_state_variables", "jacobian_flatten", "rotation_func", "_initialized",
-                         "get_gradient_vals", "update_external_state_variables"}
+                         "get_gradient_vals", "update_external_state_variables",
+                         # written by the constructor hook for a packed tangent layout (quadrature_map.py:77, :86-88)
+                         "WJ", "degree", "jacobians"}
     assert used - own <= reference_surface, sorted(used - own - reference_surface)
     base = FieldMapBase(2, 1, OracleJ2Material(E, NU, _hard()))
-    for name in reference_surface - {"update_external_state_variables"}:
+    for name in reference_surface - {"update_external_state_variables", "WJ", "degree"}:   # (the stand-in builds its own tangent Field)
         assert hasattr(base, name), name
 
 
@@ -313,7 +315,7 @@ def test_quadrature_map_placeholder_says_what_is_missing():
         assert issubclass(QuadratureMap, AcceleratedUpdate) and issubclass(QuadratureMap, qmod._reference)
 
 
-def test_a_packed_tangent_layout_behind_the_reference_sized_jacobian_is_refused_with_a_reason():
+def test_a_tangent_function_of_another_width_than_the_materials_is_refused_with_a_reason():
     class Sym21(OracleJ2Material):
         tangent_size = 21
 
@@ -321,7 +323,7 @@ def test_a_packed_tangent_layout_behind_the_reference_sized_jacobian_is_refused_
     q.jacobian_width = 36      # what the reference's constructor sizes jacobian_flatten for (quadrature_map.py:83-87)
     q.jacobian_flatten = type(q.jacobian_flatten)("jacobian", 36, 12)
     q.register_gradient("strain", lambda c: np.zeros((len(c) * 4, 6)))
-    with pytest.raises(ValueError, match="tangent_layout='full'"):
+    with pytest.raises(ValueError, match="not constructed through AcceleratedUpdate.__init__"):
         q.update()
 
 
