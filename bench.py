@@ -233,7 +233,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
 
     uploads, spread = [], []
 
-    def update_cadence(accelerated, reps, nqp=8, isv_mode=None):
+    def update_cadence(accelerated, reps, nqp=8, isv_mode=None, layout="full"):
         """One ``QuadratureMap.update()`` at n points (n / 8 hexahedra with 8 Gauss points), numpy stand-ins for the
         quadrature Functions (field_map.py): the reference's cadence around ``integrate`` (as_reference_update above)
         against ``quadrature_map.AcceleratedUpdate``.  The gradient "expression" hands out the precomputed strain rows."""
@@ -241,7 +241,8 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
 
         ncell = n // nqp
         npts = ncell * nqp
-        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
+        m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index,
+                        tangent_layout=layout)
         q = (QuadratureFieldMap if accelerated else FieldMapBase)(ncell, nqp, m)
         if isv_mode is not None:
             q.isv_every_update = isv_mode
@@ -386,8 +387,38 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
                 "value": round(npts / out["rows_by_the_engine"] / 1e3, 2), "unit": "Mpoints/s",
                 "note": "HIPMaterial.integrate_rows (dxm_integrate_rows): the threads that rebuild the tangent blocks store stress and block in the point's row"}
 
+    def packed_legs(fast, f_fields, keep_f):
+        """the same accelerated update with a material that hands its tangent out packed -- jacobian_flatten is
+        21 / 4 doubles per point and `jacobians[block]` (what derivative() contracts, quadrature_map.py:132-158) is written in terms
+        of it (`quadrature_map.tangent_entries`).  Nothing is rebuilt on the host.  Flux / ISV Functions must be those of the full
+        map bit for bit; the 6x6 block evaluated from the packed Function on a sample of points must be the full map's."""
+        out = {}
+        sample = np.linspace(0, fast["points"] - 1, 4096).astype(np.int64)
+        want = keep_f[0].tangent_block_values(rows=sample)
+        for layout in ("pack4", "sym"):
+            rec, fields, keep = update_cadence(True, reps, layout=layout)
+            same = all(np.array_equal(fields[k], f_fields[k]) for k in ("stress", "p", "epsp"))
+            got = keep[0].tangent_block_values(rows=sample)
+            err = float(np.abs(got - want).max() / np.abs(want).max())
+            keep[0].close()
+            keep[1].close()
+            rec.update({"flux_and_isv_fields_bit_identical_to_full_layout": bool(same), "tangent_block_max_rel_diff_on_4096_points": err,
+                        "ms_over_full_layout": round(rec["ms_per_update"] / fast["ms_per_update"], 3),
+                        "pcie_bytes_per_point_d2h": {"pack4": 48 + 32 + 56, "sym": 48 + 168 + 56}[layout],
+                        "host_bytes_written_per_point": {"pack4": 136, "sym": 272}[layout]})
+            out[layout] = rec
+            del fields, keep, got
+        out["note"] = ("HIPMaterial(tangent_layout=...) behind the same AcceleratedUpdate: the tangent Function holds (c1, c2, c3, w) [pack4: the flow direction "
+                       "is dev(stress) w, read from the stress Function in the UFL expression] or the 21 upper-triangle entries [sym]; no host thread rebuilds "
+                       "288 B/point of blocks (the bound of `accelerated_update`), the form compiler evaluates the block at assembly")
+        return out
+
     def cadence_pair():
         fast, f_fields, keep_f = update_cadence(True, reps)                      # the default: ISV Functions written in every update, like the reference
+        try:
+            packed = packed_legs(fast, f_fields, keep_f)
+        except Exception as exc:  # context only
+            packed = {"error": repr(exc)}
         lazy, l_fields, keep_l = update_cadence(True, reps, isv_mode="lazy")     # opt-in: ISVs cross PCIe when somebody looks, and at advance()
         lazy_same = all(np.array_equal(f_fields[k], l_fields[k]) for k in f_fields)
         keep_l[0].close()
@@ -398,7 +429,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
         try:
             slow, s_fields, keep_s = update_cadence(False, 2)
         except MemoryError as exc:
-            return {"accelerated_update": fast, "as_reference_update": {"error": repr(exc)}}
+            return {"accelerated_update": fast, "accelerated_update_packed": packed, "as_reference_update": {"error": repr(exc)}}
         same = all(np.array_equal(f_fields[k], s_fields[k]) for k in f_fields)
         for q_, m_ in (keep_f, keep_s):
             if hasattr(q_, "close"):
@@ -411,7 +442,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
         slow["note"] = ("the reference's cadence around the same HIPMaterial.integrate: gradient scattered into its Function and gathered back, concatenate, three np.isnan "
                         "passes (the ISV one downloads 56 B/point), flux / ISVs / tangent scattered through a per-call np.add.outer index "
                         "(quadrature_map.py:304-334, utils.py:136-143)")
-        return {"accelerated_update": fast, "as_reference_update": slow, "fields_bit_identical": bool(same),
+        return {"accelerated_update": fast, "accelerated_update_packed": packed, "as_reference_update": slow, "fields_bit_identical": bool(same),
                 "accelerated_over_reference": round(slow["ms_per_update"] / fast["ms_per_update"], 2)}
 
     def page_lock_probe():

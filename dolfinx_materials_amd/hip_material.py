@@ -227,6 +227,7 @@ class HIPMaterial:
     def set_newton(self, maxit=25, rtol=1e-14):
         for h in self._handles():
             self._chk(self._lib.dxm_set_newton(h, int(maxit), float(rtol)))
+        self._newton = (int(maxit), float(rtol))
 
     # ---- protocol: life cycle ------------------------------------------------------------------
     def set_data_manager(self, ngauss):
@@ -295,6 +296,9 @@ class HIPMaterial:
         for h, *_ in getattr(self, "_parts", []):
             self._lib.dxm_destroy(h)
         self._parts = []
+        sc = self.__dict__.pop("_scratch_material", None)
+        if sc is not None:
+            sc.close()
         if getattr(self, "_pool", None) is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
@@ -562,6 +566,86 @@ class HIPMaterial:
                 _reaper.drop(old)
             del old
         return flux, isv, self._out_ct
+
+    # ---- protocol: the explicit-state callables (jaxmat.py:147-164, generic.py:115-117, docs/jax.md:46-50) ---------------
+    def natural_state(self, n=1):
+        """The state the law starts from, as a state dictionary of ``n`` points (``behavior.init_state(n)`` of ``jaxmat.py:35``):
+        zero strain / ``F = I``, zero flux, zero internal state variables, ``be_bar = I`` for the FeFp laws
+        (``finite_strain_elastoplasticity.py:181``)."""
+        n = int(n)
+        g = np.zeros((n, int(self._info.n_grad)))
+        if self._info.n_grad == 9:
+            g[:, :3] = 1.0
+        out = {self._gname: g, self._fname: np.zeros((n, int(self._info.n_flux)))}
+        for name, dim in self.internal_state_variables.items():
+            a = np.zeros((n, max(1, dim)))
+            if name == "be_bar":
+                a[:, :3] = 1.0
+            out[name] = a
+        return out
+
+    def _scratch(self, n):
+        """A second material of the same behaviour for ``n`` points (same device, same library, full tangent blocks, same Newton
+        controls): the explicit-state callables integrate on it, so the state of THIS material (s0 / s1, its mirrors, its bound
+        arrays) is never touched.  Kept for the next call of the same size."""
+        sc = self.__dict__.get("_scratch_material")
+        if sc is None or sc._n != n or not sc._parts:
+            if sc is not None:
+                sc.close()
+            sc = HIPMaterial(self.behavior, device=self.device, gradient_name=self._gname, flux_name=self._fname, lazy_isv=False)
+            sc.set_data_manager(n)
+            self._scratch_material = sc
+        prm = np.asarray(self.behavior.params(), dtype=np.float64)   # (update_material_property may have changed them since)
+        for h in sc._handles():
+            sc._chk(sc._lib.dxm_set_params(h, prm.ctypes.data_as(C.POINTER(C.c_double)), prm.size))
+        if self.__dict__.get("_newton") and sc.__dict__.get("_newton") != self._newton:
+            sc.set_newton(*self._newton)
+        return sc
+
+    def batched_constitutive_update(self, gradients, state, dt=0):
+        """``Ct, new_state = material.batched_constitutive_update(gradients, state, dt)`` with the state passed in and handed
+        back EXPLICITLY -- the attribute ``JAXMaterial.__init__`` builds as ``jit(vmap(jacfwd(constitutive_update, argnums=0,
+        has_aux=True), in_axes=(0, 0, None)))`` (``jaxmat.py:147-155``; ``generic.py:115-117`` for the Python materials) and
+        ``integrate`` calls (``jaxmat.py:219-221``).
+
+        ``gradients``: ``(N, ng)``.  ``state``: dict name -> ``(N, dim)`` as the state dictionaries of this class
+        (``get_initial_state_dict()``, :meth:`natural_state`): the internal state variables the update starts from; for the FeFp
+        laws also the previous ``F`` (the kernel's state is rebuilt from ``(F_n, be_bar_n)``); other keys (the previous strain and
+        stress of the small-strain laws) are not read by these laws, absent keys take the natural state.  Returns the consistent
+        tangent ``(N, nf, ng)`` -- ``d flux / d gradient`` of the algorithm, what ``jacfwd`` differentiates -- and the new state
+        (gradient, flux and every internal state variable, ``(N, dim)`` each, owned by the caller).  The material's own
+        ``s0`` / ``s1`` are not touched: the update runs on a scratch material of the same behaviour (one ``dxm_integrate``)."""
+        ng, nf = int(self._info.n_grad), int(self._info.n_flux)
+        g = _as_c(gradients)
+        if g.ndim != 2 or g.shape[1] != ng:
+            raise ValueError(f"gradients must have shape (N, {ng}), got {g.shape}")
+        n = g.shape[0]
+        unknown = [k for k in state if k not in self.variables]
+        assert len(unknown) == 0, "Material state contains unknown field to update with."
+        start = self.natural_state(n)
+        for key, value in state.items():
+            start[key] = _as_c(value, start[key].shape)
+        sc = self._scratch(n)
+        wanted = list(self.internal_state_variables) + ([self._gname] if ng == 9 else [])
+        sc.set_initial_state_dict({k: start[k] for k in wanted})
+        flux, isv, ct = sc.integrate(g, float(dt))
+        new_state = {self._gname: g.copy(), self._fname: np.array(flux)}
+        col = 0
+        isv = np.asarray(isv)
+        for name, dim in self.internal_state_variables.items():
+            w = max(1, dim)
+            new_state[name] = np.array(isv[:, col:col + w])
+            col += w
+        return np.array(ct).reshape(n, nf, ng), new_state
+
+    def constitutive_update(self, gradients, state, dt=0):
+        """``sig, new_state = material.constitutive_update(eps, state, dt)`` at ONE material point (``jaxmat.py:158-164``,
+        ``docs/jax.md:46-50``): ``gradients`` ``(ng,)``, ``state`` dict name -> ``(dim,)`` (absent keys: the natural state); returns
+        the flux ``(nf,)`` and the new state with ``(dim,)`` entries.  (The reference vmaps / differentiates this function; here
+        the batched form is the primitive and this is its one-point case.)"""
+        g = np.asarray(gradients, dtype=np.float64).reshape(1, -1)
+        _, new_state = self.batched_constitutive_update(g, {k: np.asarray(v, dtype=np.float64).reshape(1, -1) for k, v in state.items()}, dt)
+        return new_state[self._fname][0], {k: v[0] for k, v in new_state.items()}
 
     def _fetch_isv(self):
         """Download the ISVs of the current s1 (for :class:`LazyISV`)."""

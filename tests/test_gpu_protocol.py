@@ -53,3 +53,51 @@ def test_uniaxial_tension_known_answer():
         assert np.allclose(s[0], sig, rtol=1e-12, atol=1e-9)
         mat.data_manager.update()
     assert np.allclose(s[0, :3], g["expected"], rtol=1e-2, atol=1e-8)
+
+
+# ---- the explicit-state callables (jaxmat.py:147-164, generic.py:115-117, docs/jax.md:46-50) ---------------------------------
+def test_recorded_reference_calls_as_explicit_state_updates():
+    from test_explicit_state_cpu import check_recorded_calls_of_the_reference_protocol
+
+    check_recorded_calls_of_the_reference_protocol()
+
+
+@pytest.mark.parametrize("kind", ["linear", "voce"])
+def test_explicit_state_update_against_the_oracle(kind):
+    from test_explicit_state_cpu import check_explicit_state_update_against_the_oracle
+
+    check_explicit_state_update_against_the_oracle(kind, n=40_001)
+
+
+def test_explicit_state_update_of_the_fefp_law_against_the_oracle():
+    """``PK1, new_state = material.constitutive_update(F, state, dt)`` for the finite-strain law (``jaxmat.py:170-182``): the state
+    names the previous ``F`` and ``be_bar`` (the kernel's own state, the isochoric ``Cp^-1``, is rebuilt from the pair), started from
+    a state that a first plastic increment left; the material's own batch is elsewhere and stays there."""
+    from helpers import E, NU, SIG0_F, SIGU_F, B_F, fefp_path
+    from oracle import constitutive_np as onp
+
+    n = 3001
+    hard = onp.VoceHardening(SIG0_F, SIGU_F, B_F)
+    mat = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_F, SIGU_F, B_F)))
+    mat.set_data_manager(7)
+    own = {k: np.array(v) for k, v in mat.get_initial_state_dict().items()}
+    path = fefp_path(n, nsteps=6, eps=4e-2)
+    cp0, p0 = onp.fefp_initial_state(n)["cpinv"], np.zeros(n)
+    first = onp.fefp_update(path[2], cp0, p0, E, NU, hard)
+    assert first["plastic"].any()
+    # step 1 from the natural state (no keys at all)
+    Ct1, s1 = mat.batched_constitutive_update(path[2], {}, 0.0)
+    assert Ct1.shape == (n, 9, 9) and set(s1) == {"F", "PK1", "p", "be_bar"}
+    scale = np.abs(first["P"]).max()
+    assert np.abs(s1["PK1"] - first["P"]).max() <= 1e-11 * scale and np.abs(s1["be_bar"] - first["be_bar"]).max() <= 1e-12
+    assert np.abs(Ct1 - first["Ct"]).max() <= 1e-10 * np.abs(first["Ct"]).max()
+    # step 2 from the state step 1 handed back: what a caller who carries the state himself does
+    second = onp.fefp_update(path[4], first["cpinv"], first["p"], E, NU, hard)
+    Ct2, s2 = mat.batched_constitutive_update(path[4], s1, 0.0)
+    assert np.abs(s2["PK1"] - second["P"]).max() <= 1e-11 * scale and np.abs(s2["p"][:, 0] - second["p"]).max() <= 1e-13
+    assert np.abs(Ct2 - second["Ct"]).max() <= 1e-10 * np.abs(second["Ct"]).max()
+    P_i, st_i = mat.constitutive_update(path[4][11], {k: v[11] for k, v in s1.items()}, 0.0)
+    assert P_i.shape == (9,) and np.array_equal(P_i, s2["PK1"][11]) and np.array_equal(st_i["be_bar"], s2["be_bar"][11])
+    for k, v in mat.get_initial_state_dict().items():
+        assert np.array_equal(np.asarray(v), own[k]), k
+    mat.close()
