@@ -613,6 +613,10 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, blocks_per_cu=0):
             "kernel_ms_min_max": [round(min(ts), 4), round(max(ts), 4)], "launches": reps,
             "plastic_fraction": round(stats["n_plastic"] / n, 4), "not_converged": stats["n_not_converged"], "n_nan": stats["n_nan"],
         }
+        try:
+            out[name].update(law_stream_probe(torch, m, name, n, g1, flux, ct, st, ab))
+        except Exception as exc:   # context only
+            out[name]["stream_probe"] = {"error": repr(exc)}
         if name.startswith("fefp"):
             # SURVEY 8(d) counts an F_n read (976 B/point) that this kernel does not need: its state is the material
             # tensor Cp^-1, so 952 B/point actually cross the HBM interface
@@ -622,6 +626,59 @@ def other_laws(torch, jm, JAXMaterial, dev, n, reps=30, blocks_per_cu=0):
         del g0, g1, flux, ct
         torch.cuda.empty_cache()
     return out
+
+
+def law_stream_probe(torch, m, name, n, grad, flux, ct, st, alg_bytes, reps=15):
+    """`frac_of_stream_probe` of one of the other laws: its kernel interleaved, launch by launch (each waited for), with the
+    arithmetic-free kernel of tools/libstreammix.so that has THIS law's stream structure and runs on the SAME arrays -- the bench's
+    gradient / flux / tangent arrays and the handle's own resident state (`dxm_state_ptr`), so that placement is common to both.
+    elastic: strain in, stress + tangent out (384 B/point, no state); j2_voce: the 17-stream J2 shape (496 B/point);
+    fefp: F + 7 state slots in, PK1 + 13 state slots + the 81-entry tangent out (952 B/point cross HBM).  Medians over `reps` rounds
+    after 3 untimed ones.  > 1 would mean the kernel is faster than its arithmetic-free twin; measurement only, never on the product path."""
+    import ctypes as C
+
+    lib = C.CDLL(os.path.join(ROOT, "tools", "libstreammix.so"))
+    n64 = n // 64 * 64
+    nblk = 2048
+    h = m._handle
+    if name == "elastic":
+        lib.stream_mix_elastic_shape_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        probe = lambda: lib.stream_mix_elastic_shape_launch(grad.data_ptr(), flux.data_ptr(), ct.data_ptr(), n64, nblk, st or None)   # noqa: E731
+        moved = 384
+    else:
+        p0, p1 = m._lib.dxm_state_ptr(h, 0, 0, 0), m._lib.dxm_state_ptr(h, 1, 0, 0)
+        ld_b = (m._lib.dxm_state_ptr(h, 0, 1, 0) or 0) - (p0 or 0)
+        if not (p0 and p1 and p0 != p1 and ld_b > 0 and ld_b % 8 == 0 and ld_b // 8 >= n):
+            return {"stream_probe": {"error": "the handle's state addresses are not usable for the probe"}}
+        ld = ld_b // 8
+        if name.startswith("fefp"):
+            lib.stream_mix_fefp_shape_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            # no dynamic LDS, no spin, whole-tile tangent rounds (ppr = 64), no prefetch, SoA state: the plain shape
+            probe = lambda: lib.stream_mix_fefp_shape_launch(grad.data_ptr(), p0, p1, ld, flux.data_ptr(), ct.data_ptr(), n64, nblk, 0, 0, 0, 64, 0, 0, st or None)   # noqa: E731
+            moved = 952
+        else:
+            lib.stream_mix_j2_shape_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+            probe = lambda: lib.stream_mix_j2_shape_launch(grad.data_ptr(), p0, p1, ld, flux.data_ptr(), ct.data_ptr(), n64, nblk, st or None)   # noqa: E731
+            moved = 496
+    kernel = lambda: m.integrate_device(grad.data_ptr(), flux.data_ptr(), ct.data_ptr(), st)   # noqa: E731
+    times = {"kernel": [], "probe": []}
+    for r in range(reps + 3):
+        for key, fn in (("kernel", kernel), ("probe", probe)):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            if r >= 3:
+                times[key].append(a.elapsed_time(b))
+    kernel()   # flux / tangent / s1 hold the kernel's results again
+    torch.cuda.synchronize()
+    k_ms, p_ms = float(np.median(times["kernel"])), float(np.median(times["probe"]))
+    return {"frac_of_stream_probe": round(p_ms / k_ms, 4),
+            "stream_probe": {"kernel_ms_interleaved": round(k_ms, 4), "probe_ms": round(p_ms, 4), "probe_GBs": round(moved * n64 / p_ms / 1e6, 1),
+                             "probe_frac_of_peak": round(moved * n64 / p_ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_moved_per_point": moved, "rounds": reps,
+                             "on_the_kernels_own_arrays": True}}
 
 
 def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30, state=None):

@@ -58,8 +58,12 @@ class _Handle:
         self.keep_initial_io = 0
         self.isv_out = {}
         self.stats = dict(n_points=n, n_plastic=0, n_not_converged=0, n_nan=0, max_local_iters=0)
-        self.generation = 0
+        self.epoch, self.parity = 0, 0       # dxm_launch_generation = epoch << 1 | parity (csrc/dxmat.hip)
         self.launched = False
+
+    @property
+    def generation(self):
+        return (self.epoch << 1) | self.parity
 
     def state_of(self, which):
         return self.state[1 if (which == S1 and not self.s1_alias) else 0]
@@ -118,13 +122,18 @@ class FakeDxmat:
 
     def dxm_set_params(self, h, params, nparams):
         self._h(h).params = [params[i] for i in range(nparams)]
+        self._h(h).epoch += 1                # dxm_set_params: ++m->epoch
         return 0
 
     def dxm_set_newton(self, h, maxit, rtol):
+        self._h(h).epoch += 1
         return 0
 
     def dxm_set_tangent_layout(self, h, layout):
-        return 0 if layout == 0 else self._fail(-1, "fake library: full tangent layout only")
+        if layout != 0:
+            return self._fail(-1, "fake library: full tangent layout only")
+        self._h(h).epoch += 1
+        return 0
 
     def dxm_tangent_size(self, h):
         return 36
@@ -142,7 +151,7 @@ class FakeDxmat:
         m = self._h(h)
         if name == b"keep_initial_io":
             m.keep_initial_io = int(value != 0)
-        m.generation += 1
+        m.epoch += 1                         # dxm_set_option: ++m->epoch
         return 0
 
     # ---- page-locked memory: ordinary memory here ------------------------------------------------------------------------------
@@ -196,7 +205,7 @@ class FakeDxmat:
         if not m.s1_alias:
             m.state[0], m.state[1] = m.state[1], m.state[0]
             m.s1_alias = True
-            m.generation += 1
+            m.parity ^= 1                    # launches read / write the other buffer now
             if m.keep_initial_io and m.io_valid[1]:
                 for bit, key in ((1, "grad"), (2, "flux")):
                     if m.io_valid[1] & bit:

@@ -126,3 +126,57 @@ def to_host(t):
     pin.copy_(t)
     torch.cuda.synchronize()
     return pin.numpy().copy()
+
+
+def fefp_uniaxial_known_answer(step, advance, R, n=257, nsteps=8, stretch=(1.004, 1.08), sig0=SIG0_F):
+    """Material-point known answer for the finite-strain law that does not go through the oracle's formulas: ``n`` points, each on
+    its own UNIAXIAL KIRCHHOFF-STRESS path.  ``F = diag(lam, lt, lt)`` with ``lam`` ramped to ``stretch[0] ... stretch[1]`` in
+    ``nsteps`` increments; the lateral stretch ``lt`` is found per point by Newton on ``P_yy = 0`` with the update's own 9x9
+    tangent (``dP_yy / d lt = Ct[yy, yy] + Ct[yy, zz]``: several updates from one initial state, then ``advance`` -- the cadence of
+    a global Newton loop).  ``step(F9) -> (P (n,9), Ct (n,9,9), p (n,), be_bar (n,6))``.
+
+    What must hold after every increment, whatever the integration algorithm (model: ``tau = kappa/2 (J^2 - 1) 1 + mu dev(be_bar)``,
+    J2 yield on Kirchhoff stress with ``R(p)``, isochoric ``be_bar``; DESIGN.md "FeFp"):
+      * ``tau = P F^T`` is uniaxial; at a plastic point ``tau_xx = R(p)`` (tests/test_FeFp_jax.py:14-15 for Voce);
+      * ``det(be_bar) = 1`` and ``be_bar = diag(a, a^-1/2, a^-1/2)`` with ``mu (a - a^-1/2) = tau_xx``;
+      * the volumetric relation ``kappa/2 (J^2 - 1) = tau_xx / 3`` for ``J = lam lt^2``;
+      * an elastic point has ``a = J^(-2/3) lam^2`` (no plastic stretch yet).
+    Returns (number of plastic points at the end, largest p)."""
+    lmbda, mu = onp.lame(E, NU)
+    kappa = lmbda + 2.0 * mu / 3.0
+    lam_end = np.linspace(stretch[0], stretch[1], n)
+    lt = np.ones(n)
+    p_prev = np.zeros(n)
+    for t in np.linspace(0.0, 1.0, nsteps + 1)[1:]:
+        lam = 1.0 + t * (lam_end - 1.0)
+        for it in range(60):
+            F9 = np.zeros((n, 9))
+            F9[:, 0], F9[:, 1], F9[:, 2] = lam, lt, lt
+            P, Ct, p, be = step(F9)
+            pyy = P[:, 1].copy()
+            if np.abs(pyy).max() < 1e-11 * sig0:
+                break
+            lt = lt - pyy / (Ct[:, 1, 1] + Ct[:, 1, 2])
+        assert np.abs(pyy).max() < 1e-11 * sig0 and it < 15, (t, it, np.abs(pyy).max())
+        txx = P[:, 0] * lam                                      # tau = P F^T, F diagonal
+        assert np.abs(P[:, 2]).max() < 1e-10 * sig0 and np.abs(P[:, 3:]).max() < 1e-10 * sig0
+        plastic = p > p_prev + 1e-15
+        assert np.all(p >= p_prev - 1e-16)
+        # yield consistency at the plastic points, elastic closed form at the others
+        assert np.abs(txx[plastic] - R(p[plastic])).max(initial=0.0) < 1e-9 * sig0
+        assert np.all(txx[~plastic] <= R(p[~plastic]) + 1e-9 * sig0)
+        J = lam * lt * lt
+        # be_bar: isochoric, uniaxial, and carrying exactly the deviatoric stress
+        a = np.ones(n)
+        for _ in range(60):                                      # mu (a - a^-1/2) = tau_xx, Newton from a = 1 (monotone)
+            a = a - (mu * (a - a ** -0.5) - txx) / (mu * (1.0 + 0.5 * a ** -1.5))
+        assert np.abs(mu * (a - a ** -0.5) - txx).max() < 1e-12 * sig0
+        det_be = be[:, 0] * be[:, 1] * be[:, 2]                  # (the shear entries vanish on this path)
+        assert np.abs(be[:, 3:]).max() < 1e-13 and np.abs(det_be - 1.0).max() < 1e-12
+        assert np.abs(be[:, 0] - a).max() < 1e-9 and np.abs(be[:, 1] - a ** -0.5).max() < 1e-9 and np.abs(be[:, 2] - be[:, 1]).max() < 1e-13
+        assert np.abs(0.5 * kappa * (J * J - 1.0) - txx / 3.0).max() < 1e-9 * sig0
+        el = p == 0.0
+        assert np.abs(a[el] - J[el] ** (-2.0 / 3.0) * lam[el] ** 2).max(initial=0.0) < 1e-9
+        advance()
+        p_prev = p.copy()
+    return int((p_prev > 0).sum()), float(p_prev.max())

@@ -161,3 +161,31 @@ def test_inverted_points_are_reported_not_computed():
     st = onp.fefp_initial_state(n)
     ref = onp.fefp_update(F9[good], st["cpinv"][good], st["p"][good], E, NU, onp.VoceHardening(SIG0_F, SIGU_F, B_F))
     assert relerr(P[good], ref["P"]) < TIGHT
+
+
+@pytest.mark.parametrize("kind", ["voce", "linear"])
+def test_hip_uniaxial_kirchhoff_stress_paths_follow_the_model_known_answer(kind):
+    """The FeFp KERNEL against a material-point known answer that does not go through the oracle
+    (``helpers.fefp_uniaxial_known_answer``): 257 points on their own uniaxial Kirchhoff-stress paths, lateral stretch by Newton on
+    ``P_yy = 0`` with the kernel's own 9x9 tangent (several ``integrate`` calls from one s0, then ``advance``), 8 increments up to 8 %
+    stretch: ``tau_xx = R(p)`` at the plastic points, ``det(be_bar) = 1`` with ``be_bar`` carrying exactly the deviatoric stress,
+    ``kappa/2 (J^2 - 1) = tau_xx / 3`` -- at 1e-9, both hardening laws (Voce: tests/test_FeFp_jax.py:14-15)."""
+    from helpers import fefp_uniaxial_known_answer
+
+    n = 257
+    if kind == "voce":
+        hard, R = jm.VoceHardening(SIG0_F, SIGU_F, B_F), (lambda q: SIG0_F + (SIGU_F - SIG0_F) * (1.0 - np.exp(-B_F * q)))
+    else:
+        hard, R = jm.LinearHardening(SIG0_F, 2e3), (lambda q: SIG0_F + 2e3 * q)
+    m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), hard))
+    m.set_data_manager(n)
+
+    def step(F9):
+        P, isv, Ct = m.integrate(F9)
+        assert m.last_stats["n_not_converged"] == 0 and m.last_stats["n_nan"] == 0
+        isv = np.asarray(isv)
+        return np.array(P), np.array(Ct), isv[:, 0].copy(), isv[:, 1:7].copy()
+
+    nplastic, pmax = fefp_uniaxial_known_answer(step, m.data_manager.update, R, n=n)
+    assert nplastic > 200 and pmax > 1e-2
+    m.close()

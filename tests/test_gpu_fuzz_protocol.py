@@ -57,9 +57,12 @@ def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     run_operation_sequence(seed, n, bound, lazy)
 
 
-def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=64):
+def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=64, trace=None):
     """The sequence itself (also run on the CPU against the test double of the library, tests/test_protocol_fuzz_cpu.py, where the
-    device-pointer launches become host-buffer ones)."""
+    device-pointer launches become host-buffer ones).  ``trace``: a list that receives, after EVERY operation, what the library
+    says about its handle -- ``dxm_io_held`` of s0 and s1, ``dxm_launch_generation`` -- and every array the operation returned:
+    the same seed against the test double and against libdxmat.so must leave the same trace
+    (``test_the_test_double_and_the_library_leave_the_same_trace``)."""
     rng = np.random.default_rng(seed)
     beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
     m = JAXMaterial(beh, lazy_isv=lazy)
@@ -113,6 +116,7 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
     for op in ops:
         if op == "device" and not device_ops:
             op = "integrate"
+        returned = {}
         if op == "integrate":
             d = rng.standard_normal((n, 6))
             eps = 0.6 * eps + d * (rng.uniform(0, 3.0, n) * ey / np.linalg.norm(d, axis=1))[:, None]
@@ -133,6 +137,9 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
             assert m.last_stats["n_plastic"] == ref["n_plastic"] and m.last_stats["n_nan"] == 0
             held = isv
             known["final"] = True
+            returned = {"sig": np.array(sig), "ct": np.array(ct).reshape(n, 36), "n_plastic": np.array(m.last_stats["n_plastic"])}
+            if not lazy:
+                returned["isv"] = np.array(np.asarray(isv))
         elif op == "device":
             # device-pointer form: asynchronous launch on torch's stream
             d = rng.standard_normal((n, 6))
@@ -166,9 +173,11 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
                 assert close(got["p"], st["p"][:, None], max(st["p"].max(), 1e-300) + 1e-30), which
                 assert close(got["epsp"], st["epsp"], max(np.abs(st["epsp"]).max(), 1e-300) + 1e-30), which
                 assert np.asarray(got["stress"]).shape == (n, 6) and np.asarray(got["strain"]).shape == (n, 6)   # whatever they hold, they can be looked at
+                returned[which + "_p"], returned[which + "_epsp"] = np.array(np.asarray(got["p"])), np.array(np.asarray(got["epsp"]))
                 if known[which]:
                     assert close(got["stress"], st["stress"], max(np.abs(st["stress"]).max(), SIG0_V)), which
                     assert np.array_equal(np.asarray(got["strain"]), st["strain"]), which
+                    returned[which + "_stress"], returned[which + "_strain"] = np.array(np.asarray(got["stress"])), np.array(np.asarray(got["strain"]))
         elif op == "set":
             # a consistent plastic state: p >= 0 and a deviatoric plastic strain
             p = rng.uniform(0, 2e-3, n)
@@ -198,13 +207,53 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
         elif op == "look" and held is not None and lazy:
             # a lazy ISV array is a VIEW of s1 as it is NOW (lazy_rows.LazyISV); the eager one is a snapshot
             a = np.asarray(held)
+            returned["looked_isv"] = np.array(a)
             assert a.shape == (n, 7)
             assert close(a[:, 0], model.s1["p"], max(model.s1["p"].max(), 1e-300) + 1e-30)
             assert close(a[:, 1:], model.s1["epsp"], max(np.abs(model.s1["epsp"]).max(), 1e-300) + 1e-30)
         if op in ("update", "integrate", "set", "revert"):
             check_kept()
+        if trace is not None:
+            h = m._handles()[0]
+            trace.append({"op": str(op), "held": (int(m._lib.dxm_io_held(h, 0)), int(m._lib.dxm_io_held(h, 1))),
+                          "generation": int(m._lib.dxm_launch_generation(h)), "arrays": returned})
     check_kept()
     m.close()
+
+
+@pytest.mark.parametrize("seed,n,bound,lazy", [(0, 77, False, True), (1, 500, True, True), (2, 64, False, False), (3, 400, True, False),
+                                               (6, 300, "io", True), (7, 660, "io", True), (8, 130, "io", False), (9, 250, "rows", True),
+                                               (10, 703, "rows", True), (21, 90, "io", True), (22, 90, "rows", True), (23, 90, True, True)])
+def test_the_test_double_and_the_library_leave_the_same_trace(monkeypatch, seed, n, bound, lazy):
+    """``tests/fake_dxmat.py`` restates the handle semantics of ``csrc/dxmat.hip`` in Python so that the layer above the C ABI is
+    fuzzed on every CPU run (``tests/test_protocol_fuzz_cpu.py``, these very seeds).  Here the SAME seed runs against the double and
+    against libdxmat.so, and the two traces are compared operation by operation: which copies of gradient / flux each state holds
+    on the device (``dxm_io_held``), the launch generation, and every array an operation returned (to the 1e-11 at which the C
+    oracle behind the double and the kernels agree).  A drift between the double and the C code fails here."""
+    from dolfinx_materials_amd import _lib
+    from fake_dxmat import FakeDxmat
+
+    real_trace, fake_trace = [], []
+    run_operation_sequence(seed, n, bound, lazy, device_ops=False, nops=96 if seed > 20 else 64, trace=real_trace)
+    real_load = _lib.load
+    fake = FakeDxmat(real_load())
+    with monkeypatch.context() as mp:
+        mp.setattr(_lib, "load", lambda *a, **k: fake)
+        run_operation_sequence(seed, n, bound, lazy, device_ops=False, nops=96 if seed > 20 else 64, trace=fake_trace)
+    assert len(real_trace) == len(fake_trace) > 0
+    for k, (a, b) in enumerate(zip(real_trace, fake_trace)):
+        assert a["op"] == b["op"]
+        assert a["held"] == b["held"], (k, a["op"], a["held"], b["held"])
+        assert a["generation"] == b["generation"], (k, a["op"], a["generation"], b["generation"])
+        assert set(a["arrays"]) == set(b["arrays"]), (k, a["op"])
+        for name, x in a["arrays"].items():
+            y = b["arrays"][name]
+            assert x.shape == y.shape, (k, a["op"], name)
+            if name == "n_plastic" or name.endswith("_strain"):
+                assert np.array_equal(x, y), (k, a["op"], name)
+                continue
+            floor = SIG0_V if name == "sig" or name.endswith("_stress") else 1e-300      # (state variables: relative to their own size)
+            assert np.abs(x - y).max(initial=0.0) <= TOL * max(np.abs(y).max(initial=0.0), floor), (k, a["op"], name)
 
 
 @pytest.mark.parametrize("seed,n", [(10, 500), (11, 64), (12, 3001)])

@@ -401,3 +401,31 @@ def test_fefp_c_oracle_linear_hardening():
         for key in ("P", "Ct", "p"):
             assert np.abs(c[key][safe] - r[key][safe]).max() <= 1e-12 * max(np.abs(r[key]).max(), 1e-300), key
         cp, p = r["cpinv"], r["p"]
+
+
+@pytest.mark.parametrize("kind", ["voce", "linear"])
+def test_fefp_uniaxial_kirchhoff_stress_path_known_answer(kind):
+    """ORACLE, finite strain: 257 uniaxial Kirchhoff-stress paths (helpers.fefp_uniaxial_known_answer): tau_xx = R(p) at the plastic
+    points, det(be_bar) = 1 with be_bar carrying exactly the deviatoric stress, kappa/2 (J^2 - 1) = tau_xx / 3 -- statements about the
+    MODEL that hold for any integration algorithm, at 1e-9, for both hardening laws (tests/test_FeFp_jax.py:14-15 for Voce)."""
+    from helpers import B_F, SIG0_F, SIGU_F, fefp_uniaxial_known_answer
+
+    n = 257
+    if kind == "voce":
+        hard, R = onp.VoceHardening(SIG0_F, SIGU_F, B_F), (lambda q: SIG0_F + (SIGU_F - SIG0_F) * (1.0 - np.exp(-B_F * q)))
+    else:
+        hard, R = onp.LinearHardening(SIG0_F, 2e3), (lambda q: SIG0_F + 2e3 * q)
+    st = onp.fefp_initial_state(n)
+    state = {"cpinv": st["cpinv"], "p": st["p"], "next": None}
+
+    def step(F9):
+        r = onp.fefp_update(F9, state["cpinv"], state["p"], E, NU, hard)
+        assert not r["notconv"].any()
+        state["next"] = (r["cpinv"], r["p"])
+        return r["P"], r["Ct"], r["p"], r["be_bar"]
+
+    def advance():
+        state["cpinv"], state["p"] = state["next"]
+
+    nplastic, pmax = fefp_uniaxial_known_answer(step, advance, R, n=n)
+    assert nplastic > 200 and pmax > 1e-2

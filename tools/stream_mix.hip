@@ -93,6 +93,32 @@ extern "C" int stream_mix_j2_shape_launch(const void* eps, const void* s0, void*
   return (int)hipGetLastError();
 }
 
+// Elastic-shaped variant: the elastic kernel's three streams and nothing else -- strain 48 B in (AoS, 16 B per lane), stress 48 B
+// and tangent 288 B out with the non-temporal stores libdxmat ships for flux / tangent (DXM_NT bit 0); no state.  384 B/point.
+__global__ void __launch_bounds__(256) stream_mix_elastic_shape_kernel(const double* __restrict__ eps, double* __restrict__ sig,
+                                                                       double* __restrict__ ct, int64_t ntiles) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t base = t * 64;
+    const double2_t* e2 = reinterpret_cast<const double2_t*>(eps + base * 6);
+    const double2_t acc = e2[lane] + e2[64 + lane] + e2[128 + lane];
+    double2_t* g2 = reinterpret_cast<double2_t*>(sig + base * 6);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) __builtin_nontemporal_store(acc, g2 + k * 64 + lane);
+    double2_t* c2 = reinterpret_cast<double2_t*>(ct + base * 36);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) __builtin_nontemporal_store(acc, c2 + k * 64 + lane);
+  }
+}
+
+extern "C" int stream_mix_elastic_shape_launch(const void* eps, void* sig, void* ct, int64_t npoints, int blocks, void* stream) {
+  hipLaunchKernelGGL(stream_mix_elastic_shape_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)eps, (double*)sig,
+                     (double*)ct, npoints / 64);
+  return (int)hipGetLastError();
+}
+
 extern "C" int stream_mix_pipelined_launch(const void* rbuf, void* wbuf, int64_t npoints, int read_bytes_per_point,
                                            int write_bytes_per_point, int blocks, void* stream) {
   hipLaunchKernelGGL(stream_mix_pipelined_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
