@@ -1006,7 +1006,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     m->elastic_lm[0] = m->prm.lambda;
     m->elastic_lm[1] = m->prm.mu;
   }
-  const dxm_host::ChunkPlan plan = dxm_host::plan_chunks(n, packed, host_grad != nullptr, m->opt_max_chunks, m->opt_pipeline);
+  // short chunks (up to 64) whenever little crosses PCIe per point -- the packed forms of this call AND a handle whose own layout
+  // is packed (sym / coef / pack4: 168 / 72 / 32 B/point of tangent): with 8 long chunks the first result lands after 5 of the
+  // 28 ms of a 1e7-point pack4 call (profiles/r06_packed_update.md); the full 288 B/point block keeps its 8
+  const bool short_chunks = packed || (m->tangent_layout != DXM_TANGENT_FULL && ct_aos != nullptr);
+  const dxm_host::ChunkPlan plan = dxm_host::plan_chunks(n, short_chunks, host_grad != nullptr, m->opt_max_chunks, m->opt_pipeline);
   const int nchunks = plan.nchunks;
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));

@@ -22,7 +22,11 @@ same job with what the engine offers:
   engine stores every point's stress and tangent block straight into its row of the Functions
   (``HIPMaterial.integrate_rows``); rows of other arrays are moved on several threads (``scatter_rows``);
 * NaNs are taken from the kernel's status record (``material.last_stats["n_nan"]``: stress, state AND tangent, like the
-  three asserts of ``quadrature_map.py:322-324``) instead of three host passes;
+  three asserts of ``quadrature_map.py:322-324``) instead of three host passes.  One ordering difference: the reference asserts
+  BEFORE it writes the Functions (``:331-334``), while a bound map's ``integrate`` has delivered flux, tangent and (default mode)
+  the internal state variables into the Functions' memory by the time the assertion fires -- after a failed ``update()`` the
+  Functions hold the non-finite result, not the previous one.  The material's state is the same on both sides (s1 is the failed
+  update, s0 untouched), and the next successful ``update()`` rewrites every Function;
 * internal state variables: ``isv_every_update = True`` (default) writes their Functions in every ``update()`` exactly like the
   reference (``:332``; +56 B/point over PCIe per update for J2).  Callers that read them between ``update()`` and ``advance()``
   only through the map opt in to ``"lazy"``: the Functions are refreshed on the first access to
@@ -496,6 +500,8 @@ class AcceleratedUpdate:
                 self._put_columns(self.fluxes, m.fluxes, flux)
                 self._put(self.jacobian_flatten, self._jacobian_width(), tangent)
             self._last_isv = isv
+            # (advance() need not read again what this call wrote into the Functions, unless the final state changes in between)
+            self.__dict__["_accel_isv_delivered_at"] = getattr(m, "_serial", None) if delivered else None
             self.__dict__["_accel_isv_stale"] = bool(m.internal_state_variables) and not delivered
             if self.isv_every_update is True and not delivered:
                 self.refresh_internal_state_variables()
@@ -538,8 +544,12 @@ class AcceleratedUpdate:
         reader = getattr(m, "read_final_state", None)
         final = None
         self.__dict__["_accel_isv_stale"] = False   # written below
+        at = self.__dict__.get("_accel_isv_delivered_at")
+        in_place = at is not None and at == getattr(m, "_serial", None)   # the last update() delivered the state that was just accepted
         for funs, sizes in ((self.fluxes, m.fluxes), (self._isv_functions(), m.internal_state_variables)):
             for name, dim in sizes.items():
+                if in_place and funs is not self.fluxes:
+                    continue                                   # 56 B/point that crossed PCIe inside the update already
                 if plan.identity and reader is not None:
                     reader(name, rows_of(funs[name], dim))     # device -> the Function's memory, no intermediate array
                     continue

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Measurement (round 6): where the time of one accelerated ``update()`` goes once no tangent block is rebuilt on the host.
+
+  * QuadratureFieldMap at N points: layout in {full, pack4} x isv_every_update in {True, "lazy"}: ms per update;
+  * the raw device-to-host rate of this box for the bytes of one pack4 update (136 B/point) into (a) memory from
+    ``dxm_host_alloc`` (hipHostMalloc), (b) numpy memory page-locked in place (``dxm_host_register``: what a bound Function
+    is), as one transfer and as 64 x 4 chunked transfers on two streams, alone and with the 48 B/point upload running.
+Prints one JSON line per figure."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def update_legs(n, reps=7):
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.field_map import QuadratureFieldMap
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+    from helpers import E, NU, SIG0_LIN, H_LIN, j2_history
+
+    nqp = 8
+    ncell = n // nqp
+    npts = ncell * nqp
+    h = j2_history(npts)
+    for layout in ("full", "pack4"):
+        for mode in (True, "lazy"):
+            m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)), tangent_layout=layout)
+            q = QuadratureFieldMap(ncell, nqp, m)
+            q.isv_every_update = mode
+            now = {"k": 0}
+            q.register_gradient("strain", lambda c: h[now["k"]].reshape(ncell, nqp * 6)[c])
+            q.update()
+            q.advance()
+            now["k"] = 1
+            q.update()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                q.update()
+                ts.append(time.perf_counter() - t0)
+            # the same without the gradient evaluation (the stand-in's copy of 480 MB into the Function): integrate alone
+            g = q.gradients["strain"].function.x.array.reshape(npts, 6)
+            ti = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                m.integrate(g)
+                ti.append(time.perf_counter() - t0)
+            print(json.dumps({"leg": "update", "layout": layout, "isv_every_update": mode, "ms_per_update_min_med": [round(min(ts) * 1e3, 2), round(float(np.median(ts)) * 1e3, 2)],
+                              "ms_integrate_alone_min_med": [round(min(ti) * 1e3, 2), round(float(np.median(ti)) * 1e3, 2)], "points": npts}), flush=True)
+            if layout == "pack4" and mode is True:
+                m.set_option("verbose", 1)
+                m.integrate(g)
+                m.set_option("verbose", 0)
+            q.close()
+            m.close()
+
+
+def raw_rates(n):
+    import torch
+
+    from dolfinx_materials_amd import _lib
+
+    lib = _lib.load()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    D2H, H2D = 2, 1
+    dev = torch.device("cuda:0")
+    nbytes = 136 * n
+    up = 48 * n
+    d = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+    d_up = torch.empty(up // 8, dtype=torch.float64, device=dev)
+    s = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    own = _lib.PinnedArray((nbytes // 8,))
+    own_up = _lib.PinnedArray((up // 8,))
+    own_up.array[...] = 1.0
+    reg = np.zeros(nbytes // 8)
+    assert lib.dxm_host_register(reg.ctypes.data, reg.nbytes) == 0
+    for name, host in (("hipHostMalloc", own.array), ("registered_numpy", reg)):
+        for chunks in (1, 64):
+            for with_upload in (False, True):
+                ts = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    if with_upload:
+                        hip.hipMemcpyAsync(d_up.data_ptr(), own_up.array.ctypes.data, up, H2D, s[2].cuda_stream)
+                    step = (nbytes // chunks) // 8 * 8
+                    for c in range(chunks):
+                        off = c * step
+                        cnt = step if c < chunks - 1 else nbytes - off
+                        # four transfers per chunk like the pipeline (flux, two state fields, coefficients): 48 + 8 + 48 + 32 of 136
+                        o = off
+                        for part in (48, 8, 48, 32):
+                            sz = cnt * part // 136 // 8 * 8 if part != 32 else off + cnt - o
+                            hip.hipMemcpyAsync(host.ctypes.data + o, d.data_ptr() + o, sz, D2H, s[c & 1].cuda_stream)
+                            o += sz
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                print(json.dumps({"leg": "raw_d2h", "host_memory": name, "chunks": chunks, "upload_running": with_upload, "bytes": nbytes,
+                                  "ms_min_med": [round(min(ts) * 1e3, 2), round(float(np.median(ts)) * 1e3, 2)], "GBs_best": round(nbytes / min(ts) / 1e9, 1)}), flush=True)
+    lib.dxm_host_unregister(reg.ctypes.data)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+    raw_rates(n)
+    update_legs(n)
