@@ -157,6 +157,7 @@ struct dxm_material {
   int parity = 0;
   // options (dxm_set_option)
   bool opt_pipeline = true;               // chunk-pipelined host path
+  bool opt_split_streams = true;          // host path: uploads + kernels on one stream, every download on the other (else: whole chunks alternate)
   int opt_packed_transfer = 2;            // host path: 0 move the full tangent; 1 its 9 coefficients (J2) / 54 building blocks (FeFp), block rebuilt
                                           // on the host; 2 (small strain) only (c1, c2, c3, w), the direction rebuilt from the stress
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
@@ -173,6 +174,7 @@ struct dxm_material {
   double* h_flux = nullptr;               // page-locked (n, 6) landing area of the stress (dxm_integrate_rows)
   double elastic_lm[2] = {0.0, 0.0};      // lambda, mu handed to the constant-block fill
   hipEvent_t chunk_done[DXM_MAX_CHUNKS] = {};
+  hipEvent_t kernel_done[DXM_MAX_CHUNKS] = {};   // option split_streams: what the download stream waits for, per chunk
   int num_cu = 256;
   int blocks_per_cu = 5;
   int tangent_layout = 0;    // DXM_TANGENT_FULL (36 / 81) | DXM_TANGENT_SYM (21) | DXM_TANGENT_COEF (9)
@@ -455,6 +457,7 @@ int dxm_destroy(dxm_material* m) {
   if (m->h_coef) (void)hipHostFree(m->h_coef);
   if (m->h_flux) (void)hipHostFree(m->h_flux);
   for (hipEvent_t e : m->chunk_done) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : m->kernel_done) if (e) (void)hipEventDestroy(e);
   if (m->last_event) (void)hipEventDestroy(m->last_event);
   free_state(m);
   if (m->d_stats) (void)hipFree(m->d_stats);
@@ -1014,6 +1017,10 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const int nchunks = plan.nchunks;
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));
+  const bool split = m->opt_split_streams && nchunks > 1;
+  if (split)
+    for (int c = 0; c < nchunks; ++c)
+      if (!m->kernel_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->kernel_done[c], hipEventDisableTiming));
   const int64_t csize = plan.csize;
   if (host_grad) {
     const int64_t need = csize * d.n_grad;
@@ -1083,7 +1090,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     const int64_t off = (int64_t)c * csize;
     if (off >= n) break;
     const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-    hipStream_t st = streams[c & 1];
+    hipStream_t st = split ? m->own_stream : streams[c & 1];   // upload + kernels of this chunk
+    hipStream_t sd = split ? m->pipe_stream : st;               // its downloads
     if (int rc = upload(off, cnt, st)) return rc;
     const double* gptr = fused ? m->d_flux : m->d_grad + off * d.n_grad;
     if (host_grad) {
@@ -1115,9 +1123,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                               m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr, tl))
       return rc;
     stats_off += grid;
-    if (flux_aos && flux_locked)
-      HIP_TRY(hipMemcpyAsync((rowmode ? m->h_flux : flux_aos) + off * d.n_flux, m->d_flux + off * d.n_flux,
-                             sizeof(double) * cnt * d.n_flux, hipMemcpyDeviceToHost, st));
+    // device side of the chunk first (pack kernels of the internal state variables included), then its downloads.
+    // split: uploads and kernels run ahead on one stream, EVERY download queues on the other (after the chunk's kernel_done
+    // event), so the device-to-host direction -- 80 to 136 B/point against 48 up -- never waits for an upload that sits
+    // behind a download of its own stream (whole chunks alternating on two streams: 44 GB/s of the link's 54-57 at 1e7
+    // points, profiles/r06_packed_update.md)
     if (isv_aos && total > 0) {
       // the kernel wrote state[1]; s1_alias is cleared below, address it directly
       const bool alias = m->s1_alias;
@@ -1125,25 +1135,34 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       int rc = pack_isv_range(m, DXM_S1, off, cnt, m->d_isv + off * total, st);
       m->s1_alias = alias;
       if (rc) return rc;
-      if (isv_locked)
-        HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total,
-                               hipMemcpyDeviceToHost, st));
     }
     // fields of the final state bound to host rows (dxm_bind_isv_output: the x.array of the ISV Functions): an (N, total)
     // device scratch holds them field after field, [n * sum of the dims before f] + off * dim_f -- d_isv itself when the call
     // has no isv_aos, its own scratch when d_isv carries the interleaved rows of isv_aos (two layouts cannot share one area:
-    // the chunks alternate on two streams and a pageable isv_aos is downloaded from d_isv after the loop)
+    // the chunks overlap on two streams and a pageable isv_aos is downloaded from d_isv after the loop)
     for (int f = 0, before = 0; f < d.n_isv_fields; before += d.isv_dim[f], ++f) {
       if (!m->isv_out[f]) continue;
-      double* dev = field_scratch + n * before + off * d.isv_dim[f];
-      if (int rc = pack_isv_field_range(m, f, off, cnt, dev, st)) return rc;
-      HIP_TRY(hipMemcpyAsync(m->isv_out[f] + off * d.isv_dim[f], dev, sizeof(double) * cnt * d.isv_dim[f], hipMemcpyDeviceToHost, st));
+      if (int rc = pack_isv_field_range(m, f, off, cnt, field_scratch + n * before + off * d.isv_dim[f], st)) return rc;
     }
+    if (split) {
+      HIP_TRY(hipEventRecord(m->kernel_done[c], st));
+      HIP_TRY(hipStreamWaitEvent(sd, m->kernel_done[c], 0));
+    }
+    if (flux_aos && flux_locked)
+      HIP_TRY(hipMemcpyAsync((rowmode ? m->h_flux : flux_aos) + off * d.n_flux, m->d_flux + off * d.n_flux,
+                             sizeof(double) * cnt * d.n_flux, hipMemcpyDeviceToHost, sd));
     if (ct_aos && !constant && (packed || ct_locked)) {
       double* dst = packed ? m->h_coef + off * np : ct_aos + off * nt;
-      HIP_TRY(hipMemcpyAsync(dst, m->d_ct + off * nt, sizeof(double) * cnt * nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(dst, m->d_ct + off * nt, sizeof(double) * cnt * nt, hipMemcpyDeviceToHost, sd));
     }
-    HIP_TRY(hipEventRecord(m->chunk_done[c], st));
+    if (isv_aos && total > 0 && isv_locked)
+      HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total, hipMemcpyDeviceToHost, sd));
+    for (int f = 0, before = 0; f < d.n_isv_fields; before += d.isv_dim[f], ++f) {
+      if (!m->isv_out[f]) continue;
+      HIP_TRY(hipMemcpyAsync(m->isv_out[f] + off * d.isv_dim[f], field_scratch + n * before + off * d.isv_dim[f],
+                             sizeof(double) * cnt * d.isv_dim[f], hipMemcpyDeviceToHost, sd));
+    }
+    HIP_TRY(hipEventRecord(m->chunk_done[c], sd));
     issued = c + 1;
     // a pageable upload blocks this thread for its whole duration, so earlier chunks land while the later ones are
     // still being issued: hand them to the workers now, not after the loop
@@ -1646,6 +1665,7 @@ int dxm_set_option(dxm_material* m, const char* name, double value) {
   const std::string k(name);
   const bool on = value != 0.0;
   if (k == "pipeline") m->opt_pipeline = on;
+  else if (k == "split_streams") m->opt_split_streams = on;
   else if (k == "packed_transfer") {
     if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(-1, "packed_transfer must be 0, 1 or 2");
     m->opt_packed_transfer = (int)value;

@@ -848,7 +848,7 @@ class HIPMaterial:
         self._chk(self._lib.dxm_notify_replay(self._require()))
 
     def set_option(self, name, value):
-        """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"packed_transfer"``, ``"packed_min_points"``,
+        """Per-handle options of ``include/dxmat.h`` (``"pipeline"``, ``"split_streams"``, ``"packed_transfer"``, ``"packed_min_points"``,
         ``"register_input"``, ``"stage_ahead"``, ``"keep_initial_io"``, ``"pageable_dma"``, ``"host_threads"``, ``"max_chunks"``,
         ``"fused_gradient"``, ``"blocks_per_cu"``, ``"verbose"``; process-wide:
         ``"query_foreign_pointers"``)."""

@@ -175,7 +175,12 @@ class LazyInitialRows(LazyISV):
         return self._m._serial0
 
     def _download(self):
-        return self._m._fetch_io_rows(self._which, self._kind)
+        # read-only: every view of this mirror shows THIS array (and advance() may install it as the next s0 mirror); the
+        # reference's dictionaries hold private copies (generic.py:265-277), so a caller who writes into one changes nothing but
+        # the copy -- here such a write is refused instead of silently changing what every other view shows
+        rows = self._m._fetch_io_rows(self._which, self._kind)
+        rows.setflags(write=False)
+        return rows
 
 
 class LazyFinalRows(LazyInitialRows):

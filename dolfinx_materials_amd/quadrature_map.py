@@ -500,8 +500,6 @@ class AcceleratedUpdate:
                 self._put_columns(self.fluxes, m.fluxes, flux)
                 self._put(self.jacobian_flatten, self._jacobian_width(), tangent)
             self._last_isv = isv
-            # (advance() need not read again what this call wrote into the Functions, unless the final state changes in between)
-            self.__dict__["_accel_isv_delivered_at"] = getattr(m, "_serial", None) if delivered else None
             self.__dict__["_accel_isv_stale"] = bool(m.internal_state_variables) and not delivered
             if self.isv_every_update is True and not delivered:
                 self.refresh_internal_state_variables()
@@ -544,12 +542,11 @@ class AcceleratedUpdate:
         reader = getattr(m, "read_final_state", None)
         final = None
         self.__dict__["_accel_isv_stale"] = False   # written below
-        at = self.__dict__.get("_accel_isv_delivered_at")
-        in_place = at is not None and at == getattr(m, "_serial", None)   # the last update() delivered the state that was just accepted
+        # (the fields a delivering update() wrote are read again here, 56 B/point per INCREMENT: between that update and this call
+        # the Functions may have been written by anybody -- the reference's own update_initial_state does, quadrature_map.py:262-279 --
+        # and the reference's advance() overwrites whatever they hold with the accepted state, :356-360)
         for funs, sizes in ((self.fluxes, m.fluxes), (self._isv_functions(), m.internal_state_variables)):
             for name, dim in sizes.items():
-                if in_place and funs is not self.fluxes:
-                    continue                                   # 56 B/point that crossed PCIe inside the update already
                 if plan.identity and reader is not None:
                     reader(name, rows_of(funs[name], dim))     # device -> the Function's memory, no intermediate array
                     continue

@@ -134,9 +134,17 @@ class HexMesh:
             self._pattern = (indptr, indices, slot.reshape(-1))
         return self._pattern
 
-    def element_matrices(self, tangent, B, layout="full"):
-        """``wdet * sum_q B_q^T Ct_q B_q`` per cell, (cells, 24, 24), from any tangent layout of the engine."""
+    def element_matrices(self, tangent, B, layout="full", flux=None):
+        """``wdet * sum_q B_q^T Ct_q B_q`` per cell, (cells, 24, 24), from any tangent layout of the engine (``"pack4"``: the four
+        coefficients plus the stress of the same update, from which the flow direction is ``n = dev(stress) w``)."""
         nc, w = self.num_cells, self.wdet
+        if layout == "pack4":   # -> the nine-coefficient form: n rebuilt with the kernel's own three operations
+            pk = np.asarray(tangent).reshape(-1, 4)
+            sg = np.asarray(flux).reshape(-1, 6)
+            third = (sg[:, 0] + sg[:, 1] + sg[:, 2]) * (1.0 / 3.0)
+            nn = sg * pk[:, 3:4]
+            nn[:, :3] = (sg[:, :3] - third[:, None]) * pk[:, 3:4]
+            tangent, layout = np.concatenate([pk[:, :3], nn], axis=1), "coef"
         if layout == "coef":   # Ct = c1 1x1 + c2 I + c3 n x n: rank structure, no 6x6 block is ever formed
             cf = np.asarray(tangent).reshape(nc, 8, 9)
             one = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
@@ -164,7 +172,7 @@ class HexMesh:
         re = self.wdet * np.einsum("qik,cqi->ck", B, f)
         r = np.bincount(self.cell_dofs.ravel(), weights=re.ravel(), minlength=self.ndof)
         indptr, indices, slot = self.pattern()
-        Ke = self.element_matrices(tangent, B, layout).reshape(self.num_cells, 8, 3, 8, 3)
+        Ke = self.element_matrices(tangent, B, layout, flux=flux).reshape(self.num_cells, 8, 3, 8, 3)
         data = np.empty((len(indices), 3, 3))
         for i in range(3):
             for j in range(3):
@@ -228,9 +236,12 @@ class Multigrid:
         return self._smooth(A, dinv, b, x)
 
 
-def solve_linear(mesh, K, rhs, free_mask, method="auto", rtol=1e-10, info=None, symmetric=True):
+def solve_linear(mesh, K, rhs, free_mask, method="auto", rtol=1e-10, info=None, symmetric=True, abs_tol=None):
     """Solve K dx = rhs on the free dofs (dx = 0 on the constrained ones): sparse LU on small meshes, otherwise
-    multigrid-preconditioned CG (symmetric tangents: the small-strain laws) or GMRES (dP/dF of the FeFp law)."""
+    multigrid-preconditioned CG (symmetric tangents: the small-strain laws) or GMRES (dP/dF of the FeFp law).
+    ``abs_tol``: the linear residual is also driven below this ABSOLUTE value (the Newton loop passes a fraction of its own
+    absolute tolerance): with a relative stop alone a large first residual leaves a linear residual above the Newton tolerance, and
+    a step that is linear takes several "Newton" iterations that are really restarts of the Krylov solver."""
     D = sp.diags(free_mask.astype(float))
     Kc = (D @ K.tocsr() @ D + sp.diags((~free_mask).astype(float))).tocsr()
     b = rhs * free_mask
@@ -242,6 +253,10 @@ def solve_linear(mesh, K, rhs, free_mask, method="auto", rtol=1e-10, info=None, 
     its = [0]
     M = spla.LinearOperator(Kc.shape, matvec=mg.vcycle)
     count = lambda _x: its.__setitem__(0, its[0] + 1)   # noqa: E731
+    if abs_tol is not None:
+        bn = float(np.linalg.norm(b))
+        if bn > 0.0:
+            rtol = max(min(rtol, abs_tol / bn), 1e-14)   # (never below what fp64 residuals can show)
     if symmetric:
         x, flag = spla.cg(Kc, b, rtol=rtol, atol=0.0, maxiter=400, M=M, callback=count)
     else:
@@ -284,7 +299,7 @@ def newton_solve(mesh, qmap, u, bc_dofs, bc_vals, B, flux_name, atol=1e-8, rtol=
         if rn < atol or (it > 0 and rn < rtol * norms[0]):
             break
         info = {}
-        du = solve_linear(mesh, K, -r, free, method=solver, info=info, symmetric=B.shape[1] == 6)
+        du = solve_linear(mesh, K, -r, free, method=solver, info=info, symmetric=B.shape[1] == 6, abs_tol=0.1 * atol)
         timers["solve"] = timers.get("solve", 0.0) + (time.perf_counter() - t2)
         for k, v in info.items():
             timers[k] = timers.get(k, 0) + v

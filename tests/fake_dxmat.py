@@ -52,7 +52,7 @@ class _Handle:
     def __init__(self, law, params, n):
         self.law, self.params, self.n = law, list(params), n
         self.state = [dict(p=np.zeros(n), epsp=np.zeros((n, 6))), dict(p=np.zeros(n), epsp=np.zeros((n, 6)))]   # [s0, s1]
-        self.s1_alias = True
+        self.s1_alias = False                # (a new handle's s1 has its own storage: csrc/dxmat.hip `bool s1_alias = false`)
         self.io = [dict(grad=None, flux=None), dict(grad=None, flux=None)]   # device copies of (gradient, flux) for s0 / s1
         self.io_valid = [0, 0]
         self.keep_initial_io = 0

@@ -46,7 +46,7 @@ def test_device_gradient_run_equals_host_gradient_run():
         assert abs(sa["sxx"] - sb["sxx"]) < 1e-9 * abs(sa["sxx"]) and abs(sa["p"] - sb["p"]) < 1e-12
 
 
-@pytest.mark.parametrize("layout", ["sym", "coef"])
+@pytest.mark.parametrize("layout", ["sym", "coef", "pack4"])
 def test_assembly_from_the_packed_tangent_layouts_gives_the_same_newton_history(layout):
     """the host assembly consumes the 21-entry upper triangle / the nine coefficients of the
     J2 tangent directly (examples/hex_fem.py); same iterates as with the full (N,6,6) block, multigrid-CG solves."""
@@ -134,10 +134,10 @@ def test_cfg5_host_assembly_loop_at_64_cubed():
 
     out = run(n=64, steps=8, law="j2_linear", verbose=False, solver="krylov", layout="coef", device_gradient=True)
     assert out["points"] == 64 ** 3 * 8
-    # (the multigrid-CG of examples/hex_fem.py stops at its own relative tolerance: at 8.2e5 dofs the first, elastic step is an
-    # inexact Newton with a linear tail -- 5 iterations measured -- while the plastic steps keep their 2)
-    _check_host_loop(out, max_iters=6)
-    assert all(step["iters"] <= 3 for step in out["history"][1:])
+    # (the multigrid-CG of examples/hex_fem.py drives the linear residual below a tenth of the Newton tolerance: the first, elastic
+    # step is linear and takes its one solve; with a relative stop alone it was an inexact Newton of 5 iterations at 8.2e5 dofs)
+    _check_host_loop(out, max_iters=3)
+    assert out["history"][0]["iters"] <= 2
 
 
 def test_cfg5_device_resident_loop_at_its_stated_size_200_cubed():
