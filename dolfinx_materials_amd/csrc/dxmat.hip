@@ -145,6 +145,7 @@ struct dxm_material {
   int stats_capacity = 0;
   int last_grid = 0;                      // stats records written by the last integrate
   hipStream_t pipe_stream = nullptr;      // second stream of the chunk-pipelined host path
+  hipStream_t down_stream2 = nullptr;     // option split_streams: the second of the two download streams (pipe_stream is the first)
   // completion of the last launch: an event owned by the handle, recorded on the caller's stream (the
   // stream itself may be gone by the time the handle is asked to wait: e.g. a torch side stream)
   hipEvent_t last_event = nullptr;
@@ -157,7 +158,7 @@ struct dxm_material {
   int parity = 0;
   // options (dxm_set_option)
   bool opt_pipeline = true;               // chunk-pipelined host path
-  bool opt_split_streams = true;          // host path: uploads + kernels on one stream, every download on the other (else: whole chunks alternate)
+  bool opt_split_streams = true;          // host path, page-locked gradient: uploads + kernels on one stream, downloads on two others (else: whole chunks alternate on two)
   int opt_packed_transfer = 2;            // host path: 0 move the full tangent; 1 its 9 coefficients (J2) / 54 building blocks (FeFp), block rebuilt
                                           // on the host; 2 (small strain) only (c1, c2, c3, w), the direction rebuilt from the stress
   bool opt_fused_gradient = true;         // displacement form: evaluate the gradient inside the update kernel
@@ -474,6 +475,7 @@ int dxm_destroy(dxm_material* m) {
   for (hipEvent_t e : m->ring_done) if (e) (void)hipEventDestroy(e);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->pipe_stream) (void)hipStreamDestroy(m->pipe_stream);
+  if (m->down_stream2) (void)hipStreamDestroy(m->down_stream2);
   delete m;
   return 0;
 }
@@ -999,6 +1001,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   const int nfull = d.n_flux * d.n_grad;
   const int nt = packed && !constant ? np : tangent_size(m);   // doubles per point in d_ct: the packed form of this call, else the handle's layout
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
+  if (m->opt_split_streams && !m->down_stream2) HIP_TRY(hipStreamCreateWithFlags(&m->down_stream2, hipStreamNonBlocking));
   if (packed || host_grad) {
     if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * (fefp ? FEFP_REC : 9), hipHostMallocDefault));
     if (rowmode && !m->h_flux) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_flux), sizeof(double) * n * d.n_flux, hipHostMallocDefault));
@@ -1013,11 +1016,21 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   // is packed (sym / coef / pack4: 168 / 72 / 32 B/point of tangent): with 8 long chunks the first result lands after 5 of the
   // 28 ms of a 1e7-point pack4 call (profiles/r06_packed_update.md); the full 288 B/point block keeps its 8
   const bool short_chunks = packed || (m->tangent_layout != DXM_TANGENT_FULL && ct_aos != nullptr);
-  const dxm_host::ChunkPlan plan = dxm_host::plan_chunks(n, short_chunks, host_grad != nullptr, m->opt_max_chunks, m->opt_pipeline);
+  // Three streams instead of two (option split_streams, default on) when every chunk starts with a DMA upload from page-locked
+  // memory: uploads + kernels of all chunks on one stream, the downloads of chunk c on one of two others behind the chunk's
+  // kernel_done event.  An upload queued on the stream that also carries a chunk's downloads costs the device-to-host
+  // direction -- 80 to 136 B/point against 48 up -- 4-8 ms per 1e7 points (raw HIP calls: 27-32 ms against 24-25); split,
+  // the 1.36 GB of a pack4 update with its state fields land in 25.4 ms (53 GB/s) instead of 27.4-30.6, the 0.8 GB of the lazy
+  // mode in 15.6 ms instead of 20-24, and the times stop moving from call to call.  At most 24 chunks then: from 32 chunks of
+  // four downloads (or 64 of two) on, the same scheme runs at a third of the link rate (profiles/r06_packed_update.md).
+  // Staged uploads (a pageable gradient array through the ring) and the fused displacement form (no per-chunk upload at
+  // all) keep the two alternating streams.
+  const bool split_ok = m->opt_split_streams && m->opt_pipeline && host_grad == nullptr && fused == nullptr;
+  const dxm_host::ChunkPlan plan = dxm_host::plan_chunks(n, short_chunks, host_grad != nullptr, split_ok && m->opt_max_chunks > 24 ? 24 : m->opt_max_chunks, m->opt_pipeline);
   const int nchunks = plan.nchunks;
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));
-  const bool split = m->opt_split_streams && nchunks > 1;
+  const bool split = split_ok && nchunks > 1;
   if (split)
     for (int c = 0; c < nchunks; ++c)
       if (!m->kernel_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->kernel_done[c], hipEventDisableTiming));
@@ -1057,6 +1070,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       if (completed) return;
       (void)hipStreamSynchronize(m->own_stream);
       if (m->pipe_stream) (void)hipStreamSynchronize(m->pipe_stream);
+      if (m->down_stream2) (void)hipStreamSynchronize(m->down_stream2);
       (void)hipGetLastError();
       m->launched = true;
       m->last_event_recorded = false;   // sync_last falls back to the whole device
@@ -1090,8 +1104,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     const int64_t off = (int64_t)c * csize;
     if (off >= n) break;
     const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-    hipStream_t st = split ? m->own_stream : streams[c & 1];   // upload + kernels of this chunk
-    hipStream_t sd = split ? m->pipe_stream : st;               // its downloads
+    hipStream_t st = split ? m->own_stream : streams[c & 1];                         // upload + kernels of this chunk
+    hipStream_t sd = split ? ((c & 1) ? m->down_stream2 : m->pipe_stream) : st;      // its downloads (split: two download streams take turns)
     if (int rc = upload(off, cnt, st)) return rc;
     const double* gptr = fused ? m->d_flux : m->d_grad + off * d.n_grad;
     if (host_grad) {
@@ -1123,11 +1137,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                               m->d_ct + off * nt, st, stats_off, &grid, fused ? &src : nullptr, tl))
       return rc;
     stats_off += grid;
-    // device side of the chunk first (pack kernels of the internal state variables included), then its downloads.
-    // split: uploads and kernels run ahead on one stream, EVERY download queues on the other (after the chunk's kernel_done
-    // event), so the device-to-host direction -- 80 to 136 B/point against 48 up -- never waits for an upload that sits
-    // behind a download of its own stream (whole chunks alternating on two streams: 44 GB/s of the link's 54-57 at 1e7
-    // points, profiles/r06_packed_update.md)
+    // device side of the chunk first (pack kernels of the internal state variables included), then its downloads (split: on
+    // one of the two download streams, behind the chunk's kernel_done event)
     if (isv_aos && total > 0) {
       // the kernel wrote state[1]; s1_alias is cleared below, address it directly
       const bool alias = m->s1_alias;

@@ -224,10 +224,11 @@ uint64_t dxm_launch_generation(const dxm_material* m);
 int dxm_notify_replay(dxm_material* m);
 /* Per-handle options (no environment variables are read by the library):
  *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on two streams (default 1)
- *   "split_streams"  1 | 0   how the chunks use the two streams.  1 (default): uploads and kernels of all chunks on one stream,
- *                            every download on the other (each waits for its chunk's kernel by an event): the device-to-host
- *                            direction, 80-136 B/point against 48 up, is never idle behind an upload.  0: whole chunks
- *                            alternate between the streams (rounds 1-5)
+ *   "split_streams"  1 | 0   how the chunks use the streams when the gradient array is page-locked (DMA uploads).  1 (default):
+ *                            uploads and kernels of all chunks on one stream, the downloads of chunk c on one of two others
+ *                            behind an event (at most 24 chunks): the device-to-host direction, 80-136 B/point against 48 up, does
+ *                            not wait behind uploads queued on its own stream.  0: whole chunks alternate between two streams
+ *                            (rounds 1-5; still what staged uploads and the displacement forms use)
  *   "max_chunks"     1..64   upper bound on the chunks of that pipeline (default 64)
  *   "packed_transfer" 2|1|0  host-buffer form, full tangent layout, >= packed_min_points.  1: move the 9 coefficients
  *                            of Ct = c1 1x1 + c2 I + c3 n x n (72 instead of 288 B/point; nothing for the elastic

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def update_legs(n, reps=9):
+def update_legs(n, reps=11):
     """``integrate`` on the bound Function memory of an accelerated map (what ``update()`` spends its time in), for layout x ISV mode x
     stream scheme; the two stream schemes alternate call by call on ONE handle."""
     import dolfinx_materials_amd.materials as jm
@@ -43,19 +43,22 @@ def update_legs(n, reps=9):
             now["k"] = 1
             q.update()
             g = q.gradients["strain"].function.x.array.reshape(npts, 6)
-            ts = {1: [], 0: []}
+            variants = [("alternating", {"split_streams": 0}), ("split", {"split_streams": 1}), ("split_16", {"split_streams": 1, "max_chunks": 16})]
+            base = {"max_chunks": 64, "split_streams": 1}
+            ts = {name: [] for name, _ in variants}
             for r in range(reps + 2):
-                for split in (1, 0):
-                    m.set_option("split_streams", split)
+                for name, opts in variants:
+                    for k, v in {**base, **opts}.items():
+                        m.set_option(k, v)
                     t0 = time.perf_counter()
                     m.integrate(g)
                     if r >= 2:
-                        ts[split].append(time.perf_counter() - t0)
+                        ts[name].append(time.perf_counter() - t0)
+            for k, v in base.items():
+                m.set_option(k, v)
             print(json.dumps({"leg": "integrate", "layout": layout, "isv_every_update": mode, "points": npts,
-                              "split_streams_ms_min_med": [round(min(ts[1]) * 1e3, 2), round(float(np.median(ts[1])) * 1e3, 2)],
-                              "alternating_chunks_ms_min_med": [round(min(ts[0]) * 1e3, 2), round(float(np.median(ts[0])) * 1e3, 2)]}), flush=True)
+                              "ms_min_med": {name: [round(min(v) * 1e3, 2), round(float(np.median(v)) * 1e3, 2)] for name, v in ts.items()}}), flush=True)
             if layout == "pack4" and mode is True:
-                m.set_option("split_streams", 1)
                 m.set_option("verbose", 1)
                 m.integrate(g)
                 m.set_option("verbose", 0)
@@ -107,10 +110,83 @@ def raw_rates(n):
                     ts.append(time.perf_counter() - t0)
                 print(json.dumps({"leg": "raw_d2h", "host_memory": name, "chunks": chunks, "upload_running": with_upload, "bytes": nbytes,
                                   "ms_min_med": [round(min(ts) * 1e3, 2), round(float(np.median(ts)) * 1e3, 2)], "GBs_best": round(nbytes / min(ts) / 1e9, 1)}), flush=True)
+    # the pipeline's own pattern, piece by piece, on raw HIP calls: two streams, 64 chunks; per chunk [H2D of its 48 B/point] ->
+    # [a small kernel: hipMemsetAsync] -> [its four downloads], all on the chunk's stream
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    scratch = torch.empty(1 << 20, dtype=torch.float64, device=dev)
+    host = reg
+    for pattern in ("d2h_only", "h2d_then_d2h", "h2d_kernel_d2h", "kernel_d2h"):
+        for chunks in (64, 32):
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step = (nbytes // chunks) // 8 * 8
+                ustep = (up // chunks) // 8 * 8
+                for c in range(chunks):
+                    st = s[c & 1].cuda_stream
+                    off = c * step
+                    cnt = step if c < chunks - 1 else nbytes - off
+                    if pattern.startswith("h2d"):
+                        hip.hipMemcpyAsync(d_up.data_ptr() + c * ustep, own_up.array.ctypes.data + c * ustep, ustep, H2D, st)
+                    if "kernel" in pattern:
+                        hip.hipMemsetAsync(scratch.data_ptr(), 0, 1 << 16, st)
+                    o = off
+                    for part in (48, 8, 48, 32):
+                        sz = cnt * part // 136 // 8 * 8 if part != 32 else off + cnt - o
+                        hip.hipMemcpyAsync(host.ctypes.data + o, d.data_ptr() + o, sz, D2H, st)
+                        o += sz
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            print(json.dumps({"leg": "raw_pattern", "pattern": pattern, "chunks": chunks, "bytes_down": nbytes, "ms_min_med": [round(min(ts) * 1e3, 2), round(float(np.median(ts)) * 1e3, 2)],
+                              "GBs_down_best": round(nbytes / min(ts) / 1e9, 1)}), flush=True)
+    # uploads (+ a small kernel + an event per chunk) on their own stream, the downloads of chunk c issued on two other streams
+    # (a) behind a device-side hipStreamWaitEvent, (b) by the host once hipEventSynchronize(event c) returns
+    hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipEventSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    events = []
+    for _ in range(64):
+        e = C.c_void_p()
+        assert hip.hipEventCreateWithFlags(C.byref(e), 2) == 0   # hipEventDisableTiming
+        events.append(e)
+    for gate in ("device_wait", "host_wait"):
+        for chunks in (64, 32):
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step = (nbytes // chunks) // 8 * 8
+                ustep = (up // chunks) // 8 * 8
+                su = s[2].cuda_stream
+                for c in range(chunks):
+                    hip.hipMemcpyAsync(d_up.data_ptr() + c * ustep, own_up.array.ctypes.data + c * ustep, ustep, H2D, su)
+                    hip.hipMemsetAsync(scratch.data_ptr(), 0, 1 << 16, su)
+                    hip.hipEventRecord(events[c], su)
+                for c in range(chunks):
+                    st = s[c & 1].cuda_stream
+                    if gate == "device_wait":
+                        hip.hipStreamWaitEvent(st, events[c], 0)
+                    else:
+                        hip.hipEventSynchronize(events[c])
+                    off = c * step
+                    cnt = step if c < chunks - 1 else nbytes - off
+                    o = off
+                    for part in (48, 8, 48, 32):
+                        sz = cnt * part // 136 // 8 * 8 if part != 32 else off + cnt - o
+                        hip.hipMemcpyAsync(host.ctypes.data + o, d.data_ptr() + o, sz, D2H, st)
+                        o += sz
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            print(json.dumps({"leg": "raw_pattern", "pattern": "uploads_on_their_own_stream_" + gate, "chunks": chunks, "bytes_down": nbytes,
+                              "ms_min_med": [round(min(ts) * 1e3, 2), round(float(np.median(ts)) * 1e3, 2)], "GBs_down_best": round(nbytes / min(ts) / 1e9, 1)}), flush=True)
     lib.dxm_host_unregister(reg.ctypes.data)
 
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-    raw_rates(n)
-    update_legs(n)
+    if "--no-raw" not in sys.argv:
+        raw_rates(n)
+    if "--raw-only" not in sys.argv:
+        update_legs(n)
