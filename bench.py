@@ -409,7 +409,7 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
             rec, same, err, keep = leg(layout)
             rec.update({"flux_and_isv_fields_bit_identical_to_full_layout": same, "tangent_block_max_rel_diff_on_4096_points": err,
                         "ms_over_full_layout": round(rec["ms_per_update"] / fast["ms_per_update"], 3),
-                        "pcie_bytes_per_point_d2h": {"pack4": 48 + 32 + 56, "sym": 48 + 168 + 56}[layout],
+                        "pcie_bytes_per_point_d2h": 48 + 32 + 56,   # (sym: the 21 entries are rebuilt on the host from the same four coefficients)
                         "host_bytes_written_per_point": {"pack4": 136, "sym": 272}[layout]})
             out[layout] = rec
             if layout == "pack4":
@@ -441,8 +441,8 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
             keep[1].close()
             del keep
         out["note"] = ("HIPMaterial(tangent_layout=...) behind the same AcceleratedUpdate: the tangent Function holds (c1, c2, c3, w) [pack4: the flow direction "
-                       "is dev(stress) w, read from the stress Function in the UFL expression] or the 21 upper-triangle entries [sym]; no host thread rebuilds "
-                       "288 B/point of blocks, the form compiler evaluates the block at assembly.  `interleaved_with_full_layout`: the pack4 map and the full map "
+                       "is dev(stress) w, read from the stress Function in the UFL expression] or the 21 upper-triangle entries [sym: rebuilt by the host threads from the same 32 B/point, 168 instead of 288 B/point of stores]; pack4: no host thread rebuilds "
+                       "anything, the form compiler evaluates the block at assembly.  `interleaved_with_full_layout`: the pack4 map and the full map "
                        "updated alternately in one loop -- the comparison that does not depend on what the host did between two legs")
         return out
 

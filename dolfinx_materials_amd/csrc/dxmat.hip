@@ -989,16 +989,23 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   // arrays, point i is their row rows[i].  Always the 32 B/point form; the stress lands in the library's own page-locked
   // area and the worker threads that rebuild the blocks put both where they belong -- the caller's arrays see CPU stores only.
   const bool rowmode = rows != nullptr;
-  const bool packed = rowmode || (m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && ct_aos != nullptr && n >= m->opt_packed_min_points);
-  const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
   const bool fefp = d.n_grad == 9;
+  // a J2 handle with the "sym" layout: (c1, c2, c3, w) cross PCIe like for the full layout (32 instead of 168 B/point) and the
+  // workers rebuild the 21 upper-triangle entries from them and the stress (expand_pack4_tangent_sym); needs the stress in
+  // page-locked memory like the pack4 form below, else the kernel's own 21 entries are downloaded
+  const bool sym_packed = !rowmode && m->opt_packed_transfer >= 2 && m->tangent_layout == DXM_TANGENT_SYM && m->law != DXM_LAW_ELASTIC_ISO && !fefp &&
+                          ct_aos != nullptr && flux_aos != nullptr && n >= m->opt_packed_min_points &&
+                          (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux));
+  const bool packed = rowmode || sym_packed || (m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && ct_aos != nullptr && n >= m->opt_packed_min_points);
+  const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
   // small strain: (c1, c2, c3, w) only -- the direction n is rebuilt from the stress, which the caller receives in
   // page-locked memory as part of the same chunk -- else the nine coefficients
   const bool pack4 = packed && !constant && !fefp && (rowmode || (m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
                      (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux))));
   const int tl = packed && !constant ? (pack4 ? TL_PACK4 : TL_COEF) : m->tangent_layout;   // layout of this call's launches
   const int np = fefp ? FEFP_REC : (pack4 ? 4 : 9);                     // doubles per point of the packed form
-  const int nfull = d.n_flux * d.n_grad;
+  const int nfull = sym_packed ? 21 : d.n_flux * d.n_grad;      // doubles per point of what the workers rebuild in the caller's array
+  const int job = sym_packed ? -4 : np;                         // HostPool job code of that rebuild
   const int nt = packed && !constant ? np : tangent_size(m);   // doubles per point in d_ct: the packed form of this call, else the handle's layout
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (m->opt_split_streams && !m->down_stream2) HIP_TRY(hipStreamCreateWithFlags(&m->down_stream2, hipStreamNonBlocking));
@@ -1181,7 +1188,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
         if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, constant ? 0 : np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
-        else m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, np, pack4 ? flux_aos + o * d.n_flux : nullptr);
+        else m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, job, pack4 ? flux_aos + o * d.n_flux : nullptr);
         ++submitted;
       }
   }
@@ -1199,7 +1206,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
       if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + off * np, ct_aos, cnt, constant ? 0 : np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
-      else m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, np, pack4 ? flux_aos + off * d.n_flux : nullptr);
+      else m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, job, pack4 ? flux_aos + off * d.n_flux : nullptr);
       submitted = c + 1;
     }
   }

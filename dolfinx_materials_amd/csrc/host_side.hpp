@@ -97,6 +97,30 @@ inline void expand_pack4_tangent(const double* __restrict__ sg, const double* __
   }
 }
 
+// The 21 upper-triangle entries (i <= j, row by row: the kernels' TL_SYM order) of the same block from the same 32 B/point: what a
+// handle with the "sym" tangent layout receives in its host-buffer calls instead of 168 B/point over PCIe.  Entry (i, j) is the
+// expression of expand_pack4_tangent, operation for operation, so the 21 numbers are those 21 of the full block, bit for bit.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("fma")))
+#endif
+inline void expand_pack4_tangent_sym(const double* __restrict__ sg, const double* __restrict__ cw, double* __restrict__ d, int64_t n) {
+#pragma clang fp contract(off)
+  for (int64_t p = 0; p < n; ++p, sg += 6, cw += 4, d += 21) {
+    const double k1 = cw[0], k2 = cw[1], k3 = cw[2], w = cw[3];
+    const double third = (sg[0] + sg[1] + sg[2]) * THIRD;
+    double nv[6];
+    nv[0] = (sg[0] - third) * w; nv[1] = (sg[1] - third) * w; nv[2] = (sg[2] - third) * w;
+    nv[3] = sg[3] * w; nv[4] = sg[4] * w; nv[5] = sg[5] * w;
+    int t = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) {
+        const double t0 = ((i < 3 && j < 3) ? k1 : 0.0) + ((i == j) ? k2 : 0.0);
+        const double nij = nv[i] * nv[j];
+        d[t++] = __builtin_fma(k3, nij, t0);
+      }
+  }
+}
+
 // FeFp: the 9x9 block from its 54 building blocks (fefp.hpp step 6):
 //   A[row=(i,J)][col=(k,L)] = Vc[col] Fi[J][i] + Wc[col] Sr[row] + U[i][L] Fi[J][k] + (i==k) g[L][J]
 // evaluated as the kernel evaluates it (one product, three fused multiply-adds, the Kronecker delta as a 0/1 factor).
@@ -146,8 +170,8 @@ inline void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, do
 // worker pool: a few persistent threads per handle (created on the first host-path call that needs them)
 // ------------------------------------------------------------------------------------------
 struct HostPool {
-  // stride 9: J2 coefficients -> 6x6, 4: (c1, c2, c3, w) + the stress rows `aux` -> 6x6, 54: FeFp building blocks -> 9x9,
-  // 0: constant block, -1: plain copy of n BYTES
+  // stride 9: J2 coefficients -> 6x6, 4: (c1, c2, c3, w) + the stress rows `aux` -> 6x6, -4: the same source -> the 21
+  // upper-triangle entries, 54: FeFp building blocks -> 9x9, 0: constant block, -1: plain copy of n BYTES
   struct Job { const double* src; double* dst; int64_t n; int stride; int tag; const double* aux; const int64_t* rows; double* dst2; };
   std::vector<std::thread> threads;
   std::mutex mu;
@@ -178,6 +202,7 @@ struct HostPool {
       }
       if (j.stride == 9) expand_coef_tangent(j.src, j.dst, j.n);
       else if (j.stride == 4) expand_pack4_tangent(j.aux, j.src, j.dst, j.n, j.rows, j.dst2);
+      else if (j.stride == -4) expand_pack4_tangent_sym(j.aux, j.src, j.dst, j.n);
       else if (j.stride == FEFP_RECORD) expand_fefp_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
       else if (j.stride == -1) memcpy(j.dst, j.src, (size_t)j.n);
       else fill_const_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
@@ -196,9 +221,11 @@ struct HostPool {
     const int64_t pieces = (int64_t)threads.size();
     const int64_t per = (n + pieces - 1) / pieces;
     const int nf = stride == FEFP_RECORD ? 9 : 6;
+    const int in_stride = stride == -4 ? 4 : stride;                                      // doubles per point of the source
+    const int out_stride = stride == FEFP_RECORD ? 81 : (stride == -4 ? 21 : 36);         // ... and of the destination
     std::lock_guard<std::mutex> lk(mu);
     for (int64_t o = 0; o < n; o += per) {
-      queue.push_back(Job{src + o * stride, rows ? dst : dst + o * (stride == FEFP_RECORD ? 81 : 36), std::min(per, n - o), stride, 0, aux ? aux + o * nf : nullptr,
+      queue.push_back(Job{src + o * in_stride, rows ? dst : dst + o * out_stride, std::min(per, n - o), stride, 0, aux ? aux + o * nf : nullptr,
                           rows ? rows + o : nullptr, dst2});
       ++pending;
     }

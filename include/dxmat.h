@@ -237,7 +237,9 @@ int dxm_notify_replay(dxm_material* m);
  *                            2 (default): the J2 laws move (c1, c2, c3, w) only, 32 B/point -- the kernels build
  *                            the tangent with n = dev(stress) w, so the host rebuilds n from the stress it receives
  *                            anyway (needs a flux destination in page-locked / registered memory, else as 1); FeFp
- *                            as 1.  0: the full block crosses PCIe.  All three deliver the same bits
+ *                            as 1.  0: the full block crosses PCIe.  All three deliver the same bits.  A J2 handle with the
+ *                            DXM_TANGENT_SYM layout: 2 moves (c1, c2, c3, w) as well and the workers rebuild its 21 entries
+ *                            (32 instead of 168 B/point over PCIe); 1 | 0 download the kernel's 21 entries
  *   "register_input" 2 | 1 | 0  host-buffer form, gradient array in ordinary (pageable) memory.  2: page-locked for the
  *                            duration of the call (hipHostRegister ... hipHostUnregister before the call returns) and
  *                            uploaded by DMA: ~1 ms per 480 MB on transparent huge pages (numpy's default).  Arrays on

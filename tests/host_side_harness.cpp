@@ -56,7 +56,7 @@ static bool same_bits(const std::vector<double>& a, const std::vector<double>& b
 // ---- A. the chunk pipeline of run_and_download (dxmat.hip) with the device played by memcpy ---------------------------------
 // Per chunk: stage it into its ring slot on the worker threads (`ahead` chunks ahead), wait for the copy, "upload" the slot,
 // hand the chunk's packed tangent to the workers.  Returns the rebuilt blocks; checks the staged gradient arrived intact.
-struct Rebuilt { std::vector<double> ct_coef, ct_pack4, ct_fefp, ct_const; };
+struct Rebuilt { std::vector<double> ct_coef, ct_pack4, ct_fefp, ct_const, ct_sym; };
 
 static Rebuilt run_pipeline(const Input& in, int threads, int max_chunks, int ahead, HostPool* shared = nullptr) {
   const int64_t n = in.n;
@@ -65,6 +65,7 @@ static Rebuilt run_pipeline(const Input& in, int threads, int max_chunks, int ah
   out.ct_pack4.assign(n * 36, -1.0);
   out.ct_fefp.assign(n * 81, -1.0);
   out.ct_const.assign(n * 36, -1.0);
+  out.ct_sym.assign(n * 21, -1.0);
   HostPool* own = shared ? nullptr : new HostPool(threads);
   HostPool& pool = shared ? *shared : *own;
   const ChunkPlan plan = plan_chunks(n, true, true, max_chunks, true);
@@ -90,6 +91,7 @@ static Rebuilt run_pipeline(const Input& in, int threads, int max_chunks, int ah
     slot_busy[ring_slot(c)] = false;                                                                                      // ring_done[slot]
     pool.submit(in.coef.data() + off * 9, out.ct_coef.data() + off * 36, cnt, 9);
     pool.submit(in.cw.data() + off * 4, out.ct_pack4.data() + off * 36, cnt, 4, in.sg.data() + off * 6);
+    pool.submit(in.cw.data() + off * 4, out.ct_sym.data() + off * 21, cnt, -4, in.sg.data() + off * 6);   // "sym" handles: 21 entries per point
     pool.submit(in.rec.data() + off * 54, out.ct_fefp.data() + off * 81, cnt, 54);
   }
   if (shared) {
@@ -111,13 +113,25 @@ static void test_pipeline(const Input& in, FILE* fout) {
   expand_pack4_tangent(in.sg.data(), in.cw.data(), ref.ct_pack4.data(), n);
   expand_fefp_tangent(in.rec.data(), ref.ct_fefp.data(), n);
   fill_const_tangent(in.lm.data(), ref.ct_const.data(), n);
+  // the 21-entry form is the upper triangle of the 36-entry one, bit for bit
+  ref.ct_sym.assign(n * 21, 0.0);
+  expand_pack4_tangent_sym(in.sg.data(), in.cw.data(), ref.ct_sym.data(), n);
+  for (int64_t p = 0; p < n; ++p) {
+    int t = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j, ++t)
+        CHECK(memcmp(&ref.ct_sym[p * 21 + t], &ref.ct_pack4[p * 36 + i * 6 + j], 8) == 0 && memcmp(&ref.ct_pack4[p * 36 + i * 6 + j], &ref.ct_pack4[p * 36 + j * 6 + i], 8) == 0,
+              "sym rebuild: entry (%d, %d) of point %" PRId64, i, j, p);
+    if (g_failures > 5) break;
+  }
   const int chunk_caps[] = {1, 2, 3, 7, 16, 17, 31, 33, 64};
   for (int cap : chunk_caps)
     for (int ahead : {1, 3, RING - 2})
       for (int threads : {1, 5, 16}) {
         if (threads == 16 && cap != 64 && cap != 17) continue;   // keep the sanitizer runs short
         Rebuilt got = run_pipeline(in, threads, cap, ahead);
-        CHECK(same_bits(got.ct_coef, ref.ct_coef) && same_bits(got.ct_pack4, ref.ct_pack4) && same_bits(got.ct_fefp, ref.ct_fefp) && same_bits(got.ct_const, ref.ct_const),
+        CHECK(same_bits(got.ct_coef, ref.ct_coef) && same_bits(got.ct_pack4, ref.ct_pack4) && same_bits(got.ct_fefp, ref.ct_fefp) && same_bits(got.ct_const, ref.ct_const) &&
+                  same_bits(got.ct_sym, ref.ct_sym),
               "pipeline result differs from the serial rebuild (max_chunks %d, ahead %d, %d threads)", cap, ahead, threads);
       }
   // rows mode (dxm_integrate_rows): blocks and stress delivered through the index into arrays of M rows

@@ -454,6 +454,77 @@ def test_eager_isv_rows_and_bound_field_deliveries_in_one_call(kind, n, pinned_i
     ref_m.close()
 
 
+@pytest.mark.parametrize("layout", ["full", "pack4", "sym"])
+@pytest.mark.parametrize("kind,n", [("linear", 300_001), ("voce", 2_200_000)])
+def test_the_three_stream_scheme_delivers_the_bits_of_the_alternating_chunks(kind, n, layout):
+    """Option ``split_streams`` (default 1 for page-locked inputs: uploads + kernels on one stream, the downloads of chunk c on one
+    of two others behind an event, at most 24 chunks) against 0 (whole chunks alternating on two streams, up to 64): same stress,
+    tangent, delivered state fields and status record, with bound (page-locked in place) input and output arrays as the accelerated
+    map sets them up; a pageable gradient array takes the staged route, which keeps the alternating streams either way."""
+    width = {"full": 36, "pack4": 4, "sym": 21}[layout]
+    mats, outs = [], []
+    h = j2_history(n, seed=23, sig0=SIG0_LIN if kind == "linear" else SIG0_V)
+    for split in (1, 0):
+        m = _j2(kind, tangent_layout=layout)
+        m.set_data_manager(n)
+        m.set_option("split_streams", split)
+        flux_fn, jac_fn, grad_fn = np.full(n * 6, np.nan), np.full(n * width, np.nan), np.zeros(n * 6)
+        fields = {name: np.full(n * dim, np.nan) for name, dim in m.internal_state_variables.items()}
+        m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+        m.bind_inputs(gradient=grad_fn)
+        m.bind_state_outputs(fields, deliver=True)
+        mats.append(m)
+        outs.append((flux_fn, jac_fn, grad_fn, fields))
+    for k in range(3):
+        stats = []
+        for m, (flux_fn, jac_fn, grad_fn, fields) in zip(mats, outs):
+            grad_fn[...] = h[k].ravel()
+            m.integrate(grad_fn.reshape(n, 6))
+            stats.append(dict(m.last_stats))
+            m.data_manager.update()
+        (fa, ja, _, sa), (fb, jb, _, sb) = outs
+        assert np.array_equal(fa, fb) and np.array_equal(ja, jb) and not np.isnan(ja).any(), k
+        assert all(np.array_equal(sa[name], sb[name]) for name in sa) and stats[0] == stats[1], k
+    # a pageable array (a new one per call, like the reference's update()): staged through the ring on both handles, same bits
+    res = [np.array(m.integrate(np.array(h[3]))[0]) for m in mats]
+    assert np.array_equal(res[0], res[1])
+    for m in mats:
+        m.close()
+
+
+@pytest.mark.parametrize("kind,n", [("linear", 40_001), ("voce", 300_001), ("linear", 2_200_000)])
+def test_sym_layout_host_calls_rebuild_the_21_entries_from_the_four_coefficients(kind, n):
+    """A handle with the ``"sym"`` tangent layout in the host-buffer form: with ``packed_transfer = 2`` (default) only (c1, c2, c3, w)
+    cross PCIe -- 32 instead of 168 B/point -- and the worker threads rebuild the 21 upper-triangle entries from them and the stress
+    (``host_side.hpp::expand_pack4_tangent_sym``); ``packed_transfer = 0`` downloads the kernel's own 21 entries.  Same bits, with the
+    material's own arrays and with bound ones; and they are the upper triangle of the full-layout handle's block."""
+    from dolfinx_materials_amd.conventions import pack_sym_tangent
+
+    hist = j2_history(n, seed=9, sig0=SIG0_V if kind == "voce" else SIG0_LIN)
+    mats = []
+    for level, bind in ((2, False), (2, True), (0, False)):
+        m = _j2(kind, tangent_layout="sym")
+        m.set_data_manager(n)
+        m.set_option("packed_transfer", level)
+        if bind:
+            keep = (np.zeros(n * 6), np.zeros(n * 21))
+            m.bind_outputs(flux=keep[0], tangent=keep[1])
+        mats.append(m)
+    full = _j2(kind)
+    full.set_data_manager(n)
+    for eps in hist[:3]:
+        out = [m.integrate(eps) for m in mats]
+        assert out[0][2].shape == (n, 21)
+        for f, i, c in out[1:]:
+            assert np.array_equal(f, out[0][0]) and np.array_equal(c, out[0][2]) and np.array_equal(np.asarray(i), np.asarray(out[0][1]))
+        ff, _, cf = full.integrate(eps)
+        assert np.array_equal(ff, out[0][0]) and np.array_equal(pack_sym_tangent(cf), out[0][2])
+        for m in mats + [full]:
+            m.data_manager.update()
+    for m in mats + [full]:
+        m.close()
+
+
 def test_options_replace_environment_variables():
     m = _j2()
     m.set_data_manager(1000)
