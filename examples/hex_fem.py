@@ -280,10 +280,22 @@ def newton_solve(mesh, qmap, u, bc_dofs, bc_vals, B, flux_name, atol=1e-8, rtol=
     # and the plastic branch for many iterations on fine meshes)
     old = u[bc_dofs]
     k = np.abs(old).argmax() if len(old) else 0
+    layout = getattr(qmap.material, "tangent_layout", "full")
     if len(old) and abs(old[k]) > 0.0 and np.isfinite(bc_vals[k] / old[k]):
         u *= bc_vals[k] / old[k]
+    elif len(old) and np.any(bc_vals != old):
+        # nothing to scale (the first increment): a LINEAR predictor with the tangent of the state the map was last updated at --
+        # the boundary increment dg is lifted through it, K_ff du_f = -(r + K dg)_f.  Evaluating the law at "u with only the
+        # boundary nodes moved" instead puts strains of exx * n into the first layer of cells (16 % at 64^3): that layer returns
+        # plastically in the first iterate and an ELASTIC step takes five Newton iterations to shake the layer off
+        t0 = time.perf_counter()
+        qmap.update()
+        r, K = mesh.assemble(qmap.fluxes[flux_name].values, qmap.jacobian_flatten.values, B, layout)
+        dg = np.zeros(mesh.ndof)
+        dg[bc_dofs] = bc_vals - old
+        u += solve_linear(mesh, K, -(r + K @ dg), free, method=solver, symmetric=B.shape[1] == 6, abs_tol=0.1 * atol) + dg
+        timers["predictor"] = timers.get("predictor", 0.0) + (time.perf_counter() - t0)
     u[bc_dofs] = bc_vals
-    layout = getattr(qmap.material, "tangent_layout", "full")
     norms = []
     for it in range(maxit):
         t0 = time.perf_counter()
