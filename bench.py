@@ -27,7 +27,12 @@ The JSON line also carries
   box           what the box looked like from its own side before, during and after the timed steps (tools/box_telemetry.py);
   cpu_baseline  the plain-C oracle ("port") timed on this box's host cores on a bounded sample;
   gather_inclusive  (N > 1) the same steps followed by an RCCL all-gather of stress and tangent;
-  other_laws    (N = 1) kernel rates of the elastic, J2-Voce and FeFp laws at the same batch size.
+  other_laws    (N = 1) kernel rates of the elastic, J2-Voce and FeFp laws at the same batch size, each with its own
+                `frac_of_stream_probe` (the arithmetic-free kernel with that law's streams on the same arrays);
+  host_path     (N = 1, context, never `value`) the PCIe-inclusive drop-in form: `integrate` on host arrays, one
+                `QuadratureMap.update()` of the accelerated map against the reference's cadence (`accelerated_update`,
+                `as_reference_update`), and the same map over a packed tangent Function (`accelerated_update_packed`: pack4 / sym,
+                also side by side with the full-layout map).
 """
 from __future__ import annotations
 

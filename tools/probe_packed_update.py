@@ -66,6 +66,39 @@ def update_legs(n, reps=11):
             m.close()
 
 
+def fefp_legs(n, reps=7):
+    """The finite-strain law in the host-buffer form with bound (page-locked) arrays: 72 B/point up, 72 + 432 down (PK1 + the 54
+    building blocks of the 9x9 tangent, rebuilt by the workers), split against alternating streams."""
+    import dolfinx_materials_amd.materials as jm
+    from dolfinx_materials_amd.jaxmat import JAXMaterial
+    from helpers import E, NU, SIG0_F, SIGU_F, B_F, fefp_path
+
+    path = fefp_path(n, nsteps=4, eps=3e-2)
+    m = JAXMaterial(jm.FeFpJ2Plasticity(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_F, SIGU_F, B_F)))
+    m.set_data_manager(n)
+    flux_fn, jac_fn, grad_fn = np.zeros(n * 9), np.zeros(n * 81), np.zeros(n * 9)
+    m.bind_outputs(flux=flux_fn, tangent=jac_fn)
+    m.bind_inputs(gradient=grad_fn)
+    g = grad_fn.reshape(n, 9)
+    g[...] = path[1]
+    m.integrate(g)
+    m.data_manager.update()
+    g[...] = path[2]
+    variants = [("alternating", {"split_streams": 0}), ("split", {"split_streams": 1}), ("split_16", {"split_streams": 1, "max_chunks": 16})]
+    base = {"max_chunks": 64, "split_streams": 1}
+    ts = {name: [] for name, _ in variants}
+    for r in range(reps + 2):
+        for name, opts in variants:
+            for k, v in {**base, **opts}.items():
+                m.set_option(k, v)
+            t0 = time.perf_counter()
+            m.integrate(g)
+            if r >= 2:
+                ts[name].append(time.perf_counter() - t0)
+    print(json.dumps({"leg": "integrate_fefp", "points": n, "ms_min_med": {name: [round(min(v) * 1e3, 2), round(float(np.median(v)) * 1e3, 2)] for name, v in ts.items()}}), flush=True)
+    m.close()
+
+
 def raw_rates(n):
     import torch
 
@@ -188,5 +221,7 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     if "--no-raw" not in sys.argv:
         raw_rates(n)
-    if "--raw-only" not in sys.argv:
+    if "--fefp" in sys.argv:
+        fefp_legs(n)
+    elif "--raw-only" not in sys.argv:
         update_legs(n)
