@@ -19,7 +19,8 @@ def test_uniaxial_tension_3d_j2_closed_form_and_quadratic_convergence():
     assert abs(h["sxx"] - expect) < 1e-8 * expect and h["sxx_spread"] < 1e-6
     assert abs(h["p"] - (h["exx"] - expect / out["E"])) < 1e-10
     for step in out["history"]:
-        assert step["iters"] <= 6 and step["norms"][-1] < 1e-6 * step["norms"][0]
+        # (an elastic first increment converges at the linear predictor: one residual evaluation, already below the tolerance)
+        assert step["iters"] <= 6 and (step["norms"][-1] < 1e-6 * step["norms"][0] or step["norms"][-1] < 1e-8)
 
 
 def test_uniaxial_tension_3d_fefp_runs_and_saturates():
