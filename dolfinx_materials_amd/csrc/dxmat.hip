@@ -173,6 +173,7 @@ struct dxm_material {
   HostPool* pool = nullptr;
   double* h_coef = nullptr;               // page-locked (n, 9) landing area of the tangent coefficients
   double* h_flux = nullptr;               // page-locked (n, 6) landing area of the stress (dxm_integrate_rows)
+  double* h_isv = nullptr;                // page-locked landing area of the bound state fields in the rows forms, field after field
   double elastic_lm[2] = {0.0, 0.0};      // lambda, mu handed to the constant-block fill
   hipEvent_t chunk_done[DXM_MAX_CHUNKS] = {};
   hipEvent_t kernel_done[DXM_MAX_CHUNKS] = {};   // option split_streams: what the download stream waits for, per chunk
@@ -457,6 +458,7 @@ int dxm_destroy(dxm_material* m) {
   delete m->pool;
   if (m->h_coef) (void)hipHostFree(m->h_coef);
   if (m->h_flux) (void)hipHostFree(m->h_flux);
+  if (m->h_isv) (void)hipHostFree(m->h_isv);
   for (hipEvent_t e : m->chunk_done) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : m->kernel_done) if (e) (void)hipEventDestroy(e);
   if (m->last_event) (void)hipEventDestroy(m->last_event);
@@ -989,6 +991,10 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   // arrays, point i is their row rows[i].  Always the 32 B/point form; the stress lands in the library's own page-locked
   // area and the worker threads that rebuild the blocks put both where they belong -- the caller's arrays see CPU stores only.
   const bool rowmode = rows != nullptr;
+  // ... and so are the bound state fields (dxm_bind_isv_output): in the rows forms the bound pointers are the BASES of the Functions
+  // over all cells; the fields land in the library's page-locked area and the worker threads put point i into row rows[i]
+  bool isv_rows = false;
+  if (rowmode) for (int f = 0; f < d.n_isv_fields; ++f) isv_rows = isv_rows || m->isv_out[f] != nullptr;
   const bool fefp = d.n_grad == 9;
   // a J2 handle with the "sym" layout: (c1, c2, c3, w) cross PCIe like for the full layout (32 instead of 168 B/point) and the
   // workers rebuild the 21 upper-triangle entries from them and the stress (expand_pack4_tangent_sym); needs the stress in
@@ -1012,6 +1018,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   if (packed || host_grad) {
     if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * (fefp ? FEFP_REC : 9), hipHostMallocDefault));
     if (rowmode && !m->h_flux) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_flux), sizeof(double) * n * d.n_flux, hipHostMallocDefault));
+    if (isv_rows && !m->h_isv) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_isv), sizeof(double) * n * total, hipHostMallocDefault));
     if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
       delete m->pool;
       m->pool = new HostPool(m->opt_host_threads);
@@ -1104,6 +1111,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                         sizeof(double) * ((n - o) < csize ? (n - o) : csize) * d.n_grad, p);
     return 0;
   };
+  // rows forms: the bound state fields of chunk [o, o + cnt) from the landing area to their rows, on the worker threads
+  auto scatter_fields = [&](int64_t o, int64_t cnt) {
+    for (int f = 0, before = 0; f < d.n_isv_fields; before += d.isv_dim[f], ++f)
+      if (m->isv_out[f]) m->pool->submit_scatter(m->h_isv + n * before + o * d.isv_dim[f], m->isv_out[f], rows + o, cnt, d.isv_dim[f]);
+  };
   double ms_wait_copy = 0.0, ms_first_copy = 0.0;   // option verbose: time the issue loop spent waiting for staging copies
   const int ahead = m->opt_stage_ahead;
   for (int p = 0; p < ahead; ++p) if (int rc = stage_chunk(p)) return rc;
@@ -1177,8 +1189,8 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       HIP_TRY(hipMemcpyAsync(isv_aos + off * total, m->d_isv + off * total, sizeof(double) * cnt * total, hipMemcpyDeviceToHost, sd));
     for (int f = 0, before = 0; f < d.n_isv_fields; before += d.isv_dim[f], ++f) {
       if (!m->isv_out[f]) continue;
-      HIP_TRY(hipMemcpyAsync(m->isv_out[f] + off * d.isv_dim[f], field_scratch + n * before + off * d.isv_dim[f],
-                             sizeof(double) * cnt * d.isv_dim[f], hipMemcpyDeviceToHost, sd));
+      double* land = isv_rows ? m->h_isv + n * before + off * d.isv_dim[f] : m->isv_out[f] + off * d.isv_dim[f];
+      HIP_TRY(hipMemcpyAsync(land, field_scratch + n * before + off * d.isv_dim[f], sizeof(double) * cnt * d.isv_dim[f], hipMemcpyDeviceToHost, sd));
     }
     HIP_TRY(hipEventRecord(m->chunk_done[c], sd));
     issued = c + 1;
@@ -1188,6 +1200,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
         if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, constant ? 0 : np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
+        if (isv_rows) scatter_fields(o, (n - o) < csize ? (n - o) : csize);
         else m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, job, pack4 ? flux_aos + o * d.n_flux : nullptr);
         ++submitted;
       }
@@ -1206,6 +1219,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
       if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + off * np, ct_aos, cnt, constant ? 0 : np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
+      if (isv_rows) scatter_fields(off, cnt);
       else m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, job, pack4 ? flux_aos + off * d.n_flux : nullptr);
       submitted = c + 1;
     }

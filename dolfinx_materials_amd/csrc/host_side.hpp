@@ -171,7 +171,8 @@ inline void fill_const_tangent(const double* __restrict__ s /* lambda, mu */, do
 // ------------------------------------------------------------------------------------------
 struct HostPool {
   // stride 9: J2 coefficients -> 6x6, 4: (c1, c2, c3, w) + the stress rows `aux` -> 6x6, -4: the same source -> the 21
-  // upper-triangle entries, 54: FeFp building blocks -> 9x9, 0: constant block, -1: plain copy of n BYTES
+  // upper-triangle entries, 54: FeFp building blocks -> 9x9, 0: constant block, -1: plain copy of n BYTES, -8: rows of `tag`
+  // doubles from a contiguous block to rows `rows` of `dst` (a state field into the Function of a map over a subset of the cells)
   struct Job { const double* src; double* dst; int64_t n; int stride; int tag; const double* aux; const int64_t* rows; double* dst2; };
   std::vector<std::thread> threads;
   std::mutex mu;
@@ -205,6 +206,11 @@ struct HostPool {
       else if (j.stride == -4) expand_pack4_tangent_sym(j.aux, j.src, j.dst, j.n);
       else if (j.stride == FEFP_RECORD) expand_fefp_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
       else if (j.stride == -1) memcpy(j.dst, j.src, (size_t)j.n);
+      else if (j.stride == -8) {
+        const int w = j.tag;
+        for (int64_t p = 0; p < j.n; ++p)
+          for (int k = 0; k < w; ++k) j.dst[j.rows[p] * w + k] = j.src[p * w + k];
+      }
       else fill_const_tangent(j.src, j.dst, j.n, j.rows, j.dst2, j.aux);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -227,6 +233,18 @@ struct HostPool {
     for (int64_t o = 0; o < n; o += per) {
       queue.push_back(Job{src + o * in_stride, rows ? dst : dst + o * out_stride, std::min(per, n - o), stride, 0, aux ? aux + o * nf : nullptr,
                           rows ? rows + o : nullptr, dst2});
+      ++pending;
+    }
+    cv.notify_all();
+  }
+  // point p of a contiguous (n, width) block -> row rows[p] of the caller's (M, width) array, cut over the threads
+  void submit_scatter(const double* src, double* dst_base, const int64_t* rows, int64_t n, int width) {
+    if (n <= 0) return;
+    const int64_t pieces = (int64_t)threads.size();
+    const int64_t per = (n + pieces - 1) / pieces;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int64_t o = 0; o < n; o += per) {
+      queue.push_back(Job{src + o * width, dst_base, std::min(per, n - o), -8, width, nullptr, rows + o, nullptr});
       ++pending;
     }
     cv.notify_all();

@@ -536,6 +536,7 @@ class HIPMaterial:
         the s1 gradient mirror.
         """
         self._handles()
+        self._refuse_with_row_deliveries("integrate")
         ng, nf = self._info.n_grad, self._info.n_flux
         # the reference's four timer names (jaxmat.py:209, :215, :218, :223), so that scripts reading
         # timing("jaxmat: ...") keep working when dolfinx is present
@@ -646,6 +647,11 @@ class HIPMaterial:
         g = np.asarray(gradients, dtype=np.float64).reshape(1, -1)
         _, new_state = self.batched_constitutive_update(g, {k: np.asarray(v, dtype=np.float64).reshape(1, -1) for k, v in state.items()}, dt)
         return new_state[self._fname][0], {k: v[0] for k, v in new_state.items()}
+
+    def _refuse_with_row_deliveries(self, what):
+        if self.__dict__.get("_delivers_rows"):
+            raise DxmError(f"{what}: internal state variables are bound for delivery into ROWS of larger arrays (bind_state_outputs(rows=True)): "
+                           "call integrate_rows / integrate_displacement_rows, or unbind first")
 
     def _fetch_isv(self):
         """Download the ISVs of the current s1 (for :class:`LazyISV`)."""
@@ -786,6 +792,7 @@ class HIPMaterial:
         only ``u`` crosses PCIe on the way in (the step before the path,
         ``quadrature_function.py:45-51``)."""
         self._require()   # the mesh lives on one GPU
+        self._refuse_with_row_deliveries("integrate_displacement")
         nf, ng = self._info.n_flux, self._info.n_grad
         u = _as_c(u).reshape(-1)
         if u.size != mesh.displacement_size:
@@ -896,20 +903,32 @@ class HIPMaterial:
         self._bound["gradient"] = gradient
         self.set_option("keep_initial_io", 1)
 
-    def bind_state_outputs(self, arrays, deliver=False):
+    #: :meth:`bind_state_outputs` takes ``rows=True`` (the ISV Functions of a map over a subset of the cells)
+    supports_row_state_outputs = True
+
+    def bind_state_outputs(self, arrays, deliver=False, rows=False):
         """Page-lock in place the caller-owned arrays that receive internal state variables -- the ``x.array`` of the ISV
         quadrature Functions (``read_final_state(name, out)`` into such memory is one DMA transfer instead of a staged copy).
         ``arrays``: name -> C-contiguous fp64 array of ``N * dim`` entries.  ``deliver=True``: every host-buffer ``integrate``
         writes these fields of the final state into the arrays inside its transfer pipeline (``dxm_bind_isv_output``) -- what
         ``QuadratureMap.update`` does after each ``integrate`` (``quadrature_map.py:332, :343-348``) without a second pass;
-        :attr:`delivers_state_outputs` then names the fields."""
+        :attr:`delivers_state_outputs` then names the fields.
+
+        ``rows=True`` (with ``deliver=True``): the arrays are the Functions over ALL cells of a map over a subset -- ``M * dim``
+        entries, ``M >= N`` -- and :meth:`integrate_rows` / :meth:`integrate_displacement_rows` put the fields of point ``i`` into their
+        row ``rows[i]``, like stress and tangent block (``_update_vals(isv, values, cells)``, ``utils.py:136-143``, done by the
+        threads that rebuild the blocks).  Such a binding serves the rows forms only: ``integrate`` refuses while it is in place."""
         self._handles()
+        if rows and not deliver:
+            raise ValueError("rows=True describes where deliveries go: pass deliver=True")
         for name, arr in arrays.items():
             if name not in self.internal_state_variables:
                 raise ValueError(f"unknown internal state variable {name!r}")
-            size = self._n * max(1, self.internal_state_variables[name])
-            if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size == size):
-                raise ValueError(f"{name} must be a C-contiguous float64 array with {size} entries")
+            dim = max(1, self.internal_state_variables[name])
+            size = self._n * dim
+            ok = isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous
+            if not (ok and (arr.size == size if not rows else (arr.size % dim == 0 and arr.size >= size))):
+                raise ValueError(f"{name} must be a C-contiguous float64 array with {size} entries" + (" or more (whole rows)" if rows else ""))
             key = "isv:" + name
             self._unbind(key)
             if arr.nbytes:
@@ -917,10 +936,14 @@ class HIPMaterial:
             self._bound[key] = arr
             if deliver:
                 f = self.internal_state_variable_names.index(name)
-                dim = max(1, self.internal_state_variables[name])
-                rows = arr.reshape(self._n, dim)
-                for h, lo, hi, ptrs in self._blocks(rows):
-                    self._chk(self._lib.dxm_bind_isv_output(h, f, ptrs[0] if hi > lo else None))
+                if rows:   # every block gets the BASE: its points find their rows through the index of the call
+                    for h, lo, hi, _dev in self._parts:
+                        self._chk(self._lib.dxm_bind_isv_output(h, f, _ptr(arr) if hi > lo else None))
+                    self._delivers_rows = True
+                else:
+                    block_rows = arr.reshape(self._n, dim)
+                    for h, lo, hi, ptrs in self._blocks(block_rows):
+                        self._chk(self._lib.dxm_bind_isv_output(h, f, ptrs[0] if hi > lo else None))
                 self._delivered.add(name)
 
     @property
@@ -985,6 +1008,8 @@ class HIPMaterial:
                 for h, *_ in getattr(self, "_parts", []):
                     self._lib.dxm_bind_isv_output(h, f, None)
                 self._delivered.discard(k[4:])
+                if not self._delivered:
+                    self._delivers_rows = False
             if arr.nbytes:
                 self._lib.dxm_host_unregister(_ptr(arr))
             # back to the material's own buffers (allocated when next needed)

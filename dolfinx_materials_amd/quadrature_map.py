@@ -95,7 +95,8 @@ def tangent_entries(layout, jf, flux=None, n=6):
     quadrature Function of the layout's width) and, for ``"pack4"``, of ``flux`` (the stress Function of the same update).
     Only indexing and ``+ - * /`` are used, so ``jf`` / ``flux`` may be UFL Functions (then ``to_mat`` of the result is what
     ``quadrature_map.py:92-104`` builds by indexing a 36-wide Function), :class:`field_map.Field` objects (numpy columns: the
-    stand-in assembly evaluates the same expression) or plain arrays.
+    stand-in assembly evaluates the same expression) or component-major arrays (``tangent.T`` of an ``(N, width)`` array, so
+    that ``jf[k]`` is component ``k`` of every point).
 
     * ``"full"``: ``jf[n i + j]`` (``quadrature_map.py:97``);
     * ``"sym"``: ``jf[sym_position(i, j)]`` -- 21 entries for a 6 x 6 block;
@@ -311,6 +312,34 @@ class AcceleratedUpdate:
             on = bool(want)
         return on
 
+    def _accel_row_deliveries(self, plan, want):
+        """The same for a map over a SUBSET of the cells whose results go into rows of the Functions (``integrate_rows``): the ISV
+        Functions over all cells are bound as row destinations (``bind_state_outputs(deliver=True, rows=True)``) and the threads that
+        put stress and tangent block of point i into row ``dofs[i]`` put its state fields there too.  Returns whether the call
+        writes the Functions."""
+        m = self.material
+        names = tuple(getattr(m, "internal_state_variables", {}))
+        if not names or not getattr(m, "supports_row_state_outputs", False):
+            return False
+        on = set(names) <= set(m.delivers_state_outputs)
+        if bool(want) == on:
+            return on
+        if want:
+            fields = self._isv_functions()
+            try:
+                m.bind_state_outputs({name: fields[name].x.array for name in names}, deliver=True, rows=True)
+                plan.bound_keys += tuple("isv:" + name for name in names if "isv:" + name not in plan.bound_keys)
+            except Exception as exc:   # page-locking refused: the second pass (refresh_internal_state_variables) keeps working
+                _slow_path_warning("the internal-state Functions", exc)
+                for name in names:
+                    m._unbind("isv:" + name)
+                return False
+            return True
+        for name in names:
+            m._unbind("isv:" + name)
+        plan.bound_keys = tuple(k for k in plan.bound_keys if not k.startswith("isv:"))
+        return False
+
     def _isv_functions(self):
         """name -> Function of the internal state variables, without triggering a lazy refresh."""
         d = self.internal_state_variables
@@ -467,7 +496,10 @@ class AcceleratedUpdate:
         if rotate and grad is not None:   # in place, on the rows (quadrature_map.py:315-318); a bound gradient Function is re-evaluated next call
             m.rotate_gradients(grad.ravel(), self.rotation_func.x.array)
         flux = tangent = None
-        delivered = plan.bound and self._accel_deliveries(plan, self.isv_every_update is True and not rows_mode)
+        if rows_mode:
+            delivered = self._accel_row_deliveries(plan, self.isv_every_update is True)
+        else:
+            delivered = plan.bound and self._accel_deliveries(plan, self.isv_every_update is True)
         with _Timer("dx_mat: Material integration"):
             if rows_mode:
                 # a map over a subset of the cells: the engine stores each point's stress and tangent block in its row of the
@@ -517,6 +549,18 @@ class AcceleratedUpdate:
         if plan.identity and reader is not None:   # device -> the Function's (page-locked) memory, one transfer per field
             for name, dim in sizes.items():
                 reader(name, rows_of(fields[name], dim))
+            return
+        if reader is not None and hasattr(self.material, "pinned_array"):
+            # a map over a subset of the cells: every field comes off the device as its own contiguous (points, dim) block into a
+            # persistent page-locked landing area (one DMA transfer) and goes to the map's rows on the library's threads -- slicing
+            # the interleaved (points, 7) array the material returns costs numpy two single-threaded strided copies per field
+            # (66 of the 77 ms of such an update at 5e6 points, profiles/r06_packed_update.md)
+            for name, dim in sizes.items():
+                buf = plan.state_buffers.get(name)
+                if buf is None:
+                    buf = plan.state_buffers[name] = self.material.pinned_array((plan.npoints, max(1, int(dim))))
+                reader(name, buf)
+                self._put(fields[name], dim, buf)
             return
         self._put_columns(fields, sizes, np.asarray(self._last_isv))
 

@@ -37,6 +37,17 @@ def main(Nbatch=10):
         P, isv, Ct = material.integrate(F, dt)
         material.data_manager.update()
         print(f"t={t:.3f}  P11={P[0, 0]:9.4f}  p={isv[0, 0]:.6f}  plastic points={material.last_stats['n_plastic']}")
+    # The same last increment with the state passed in and handed back EXPLICITLY -- ``sig, new_state = material.constitutive_update(
+    # eps, state, dt)`` of docs/jax.md:46-50 at one point, ``batched_constitutive_update`` (jaxmat.py:147-155) for a batch: the
+    # material's own s0 / s1 are not touched (here they already hold the accepted last increment).
+    state = material.natural_state(Nbatch)                     # F = I, be_bar = I, p = 0
+    for t in np.linspace(0, 1.0, Nsteps)[1:]:
+        F = np.zeros((Nbatch, 9))
+        F[:, 0] = 1 + eps * t
+        F[:, [1, 2]] = 1 - eps / 2 * t
+        Ct2, state = material.batched_constitutive_update(F, state, dt)
+    P0, state0 = material.constitutive_update(F[0], {k: v[0] for k, v in material.natural_state(1).items()}, dt)   # one virgin point, one step
+    print(f"explicit state: P11={state['PK1'][0, 0]:9.4f}  p={state['p'][0, 0]:.6f}  (max |P - P_explicit| = {np.abs(state['PK1'] - P).max():.2e})")
     # P and Ct own their (page-locked) memory and outlive the material; isv is a lazy view of its state: materialise it
     return P, np.array(isv), Ct
 

@@ -278,7 +278,10 @@ int dxm_isv_host(dxm_material* m, int which, double* isv_aos);
  * C-contiguous (npoints, dim) rows of field `field`, page-locked by dxm_host_alloc / dxm_host_register -- and the host-buffer
  * forms (dxm_integrate, dxm_integrate_displacement, ..._rows) deliver that field of the final state into it chunk by chunk inside
  * their transfer pipeline: the caller finds the Functions written when the call returns, without a second pass over the state.
- * NULL unbinds (do so before un-page-locking the array).  The device-pointer forms do not deliver. */
+ * NULL unbinds (do so before un-page-locking the array).  The device-pointer forms do not deliver.
+ * In the rows forms (dxm_integrate_rows, dxm_integrate_displacement_rows) the bound pointer is, like their flux / tangent arguments,
+ * the BASE of the Function over all cells: the field of point i goes to its row rows[i] (stored by the worker threads from the
+ * library's own page-locked landing area).  A handle serves either kind of call with a given binding, not both. */
 int dxm_bind_isv_output(dxm_material* m, int field, double* host_aos);
 
 /* ---- pinned host memory for the host-buffer form --------------------------------------------

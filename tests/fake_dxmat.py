@@ -13,7 +13,8 @@ test).  What it restates, with the lines it follows:
     dxm_revert                  s1_alias = true, io1_valid = 0
     dxm_set_state               materialize_s1 first (an aliased s1 gets its own storage and brings no copies along)
     dxm_get_io / dxm_io_held    io_mask: s1 shows the copies of s0 while it is served from it
-    dxm_bind_isv_output         fields of the final state into bound rows inside every host-buffer call
+    dxm_bind_isv_output         fields of the final state into bound rows inside every host-buffer call (the rows forms: into row rows[i]
+                                of the bound base)
 
 Entry points that are pure host code (law table, threaded copies, row scatter / gather, index range) go to the real library, which
 loads without a GPU.  Small-strain laws, full tangent layout, one device.
@@ -258,11 +259,14 @@ class FakeDxmat:
         m.stats = dict(n_points=m.n, n_plastic=int(r["n_plastic"]), n_not_converged=int(r["n_not_converged"]), n_nan=nan, max_local_iters=0)
         return r
 
-    def _finish(self, m, grad, r, stats):
+    def _finish(self, m, grad, r, stats, idx=None):
         for field, addr in m.isv_out.items():
             if addr:
                 name, dim = self.FIELDS[field]
-                _rows(addr, m.n, dim)[...] = m.state[1][name].reshape(m.n, dim)
+                if idx is None:
+                    _rows(addr, m.n, dim)[...] = m.state[1][name].reshape(m.n, dim)
+                else:   # the rows forms: the bound pointer is the base of the array over all rows (run_and_download: isv_rows)
+                    _rows(addr, int(idx.max()) + 1, dim)[idx] = m.state[1][name].reshape(m.n, dim)
         m.io[1] = dict(grad=np.array(grad), flux=r["sig"].copy())
         m.io_valid[1] = 3
         self._fill_stats(m, stats)
@@ -303,7 +307,7 @@ class FakeDxmat:
         top = int(idx.max()) + 1
         _rows(flux_base, top, 6)[idx] = r["sig"]
         _rows(ct_base, top, 36)[idx] = r["Ct"].reshape(m.n, 36)
-        return self._finish(m, g, r, stats)
+        return self._finish(m, g, r, stats, idx)
 
     def dxm_get_stats(self, h, stats):
         self._fill_stats(self._h(h), stats)

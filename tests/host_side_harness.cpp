@@ -136,7 +136,7 @@ static void test_pipeline(const Input& in, FILE* fout) {
       }
   // rows mode (dxm_integrate_rows): blocks and stress delivered through the index into arrays of M rows
   const int64_t M = in.M;
-  std::vector<double> ct_rows(M * 36, 7.0), fx_rows(M * 6, 7.0), ct9_rows(M * 81, 7.0), fx9_rows(M * 9, 7.0), ctc_rows(M * 36, 7.0), fxc_rows(M * 6, 7.0);
+  std::vector<double> ct_rows(M * 36, 7.0), fx_rows(M * 6, 7.0), ct9_rows(M * 81, 7.0), fx9_rows(M * 9, 7.0), ctc_rows(M * 36, 7.0), fxc_rows(M * 6, 7.0), fld6_rows(M * 6, 7.0), fld1_rows(M, 7.0);
   {
     HostPool pool(16);
     const ChunkPlan plan = plan_chunks(n, true, false, 64, true);
@@ -146,6 +146,8 @@ static void test_pipeline(const Input& in, FILE* fout) {
       pool.submit(in.cw.data() + off * 4, ct_rows.data(), cnt, 4, in.sg.data() + off * 6, in.rows.data() + off, fx_rows.data());
       pool.submit(in.rec.data() + off * 54, ct9_rows.data(), cnt, 54, in.pk.data() + off * 9, in.rows.data() + off, fx9_rows.data());
       pool.submit(in.lm.data(), ctc_rows.data(), cnt, 0, in.sg.data() + off * 6, in.rows.data() + off, fxc_rows.data());
+      pool.submit_scatter(in.sg.data() + off * 6, fld6_rows.data(), in.rows.data() + off, cnt, 6);      // a bound state field of 6 components
+      pool.submit_scatter(in.cw.data() + off, fld1_rows.data(), in.rows.data() + off, cnt, 1);          // ... and a scalar one (the first n doubles of cw as an (n, 1) field)
     }
     pool.wait();
   }
@@ -156,6 +158,7 @@ static void test_pipeline(const Input& in, FILE* fout) {
     CHECK(memcmp(ct_rows.data() + r * 36, ref.ct_pack4.data() + p * 36, 288) == 0 && memcmp(fx_rows.data() + r * 6, in.sg.data() + p * 6, 48) == 0, "rows mode (pack4): point %" PRId64, p);
     CHECK(memcmp(ct9_rows.data() + r * 81, ref.ct_fefp.data() + p * 81, 648) == 0 && memcmp(fx9_rows.data() + r * 9, in.pk.data() + p * 9, 72) == 0, "rows mode (fefp): point %" PRId64, p);
     CHECK(memcmp(ctc_rows.data() + r * 36, ref.ct_const.data() + p * 36, 288) == 0 && memcmp(fxc_rows.data() + r * 6, in.sg.data() + p * 6, 48) == 0, "rows mode (constant): point %" PRId64, p);
+    CHECK(memcmp(fld6_rows.data() + r * 6, in.sg.data() + p * 6, 48) == 0 && fld1_rows[r] == in.cw[p], "rows mode (state fields): point %" PRId64, p);
     if (g_failures > 5) break;
   }
   for (int64_t r = 0; r < M; ++r)

@@ -274,6 +274,40 @@ def test_views_of_the_initial_state_keep_their_content_however_they_are_held():
     m.close()
 
 
+@pytest.mark.parametrize("kind,n,total,devices", [("linear", 300_007, 700_000, None), ("voce", 2_200_000, 2_500_000, None), ("linear", 1, 5, None),
+                                                  ("linear", 150_003, 200_000, [0, 0, 0])])
+def test_integrate_rows_delivers_the_bound_state_fields_into_their_rows(kind, n, total, devices):
+    """``bind_state_outputs(deliver=True, rows=True)`` + ``integrate_rows``: the internal state variables of point i land in row
+    rows[i] of the ISV Functions over all cells inside the same call (the worker threads scatter them from the library's page-locked
+    landing area behind the transfers), rows of other maps untouched -- what ``_update_vals(isv, values, cells)`` does per update
+    (``quadrature_map.py:332, :343-348``); several chunks, one and three blocks."""
+    rng = np.random.default_rng(n + 1)
+    rows = np.ascontiguousarray(rng.permutation(total)[:n], dtype=np.int64)
+    others = np.setdiff1d(np.arange(total), rows)
+    ref_m, m = _j2(kind), _j2(kind, devices=devices)
+    ref_m.set_data_manager(n)
+    m.set_data_manager(n)
+    flux_fn, jac_fn = np.full(total * 6, -7.0), np.full((total, 36), -7.0)
+    fields = {"p": np.full(total, -7.0), "epsp": np.full(total * 6, -7.0)}
+    m.bind_state_outputs(fields, deliver=True, rows=True)
+    assert m.delivers_state_outputs == {"p", "epsp"}
+    h = j2_history(n, seed=14, sig0=SIG0_V if kind == "voce" else SIG0_LIN)
+    for k, eps in enumerate(h[:3]):
+        f0, i0, c0 = ref_m.integrate(eps)
+        i0 = np.asarray(i0)
+        isv = m.integrate_rows(eps, rows, flux_fn, jac_fn)
+        assert np.array_equal(flux_fn.reshape(total, 6)[rows], f0) and np.array_equal(jac_fn[rows], c0.reshape(n, 36)), k
+        assert np.array_equal(fields["p"][rows], i0[:, 0]) and np.array_equal(fields["epsp"].reshape(total, 6)[rows], i0[:, 1:]), k
+        assert (fields["p"][others] == -7.0).all() and (fields["epsp"].reshape(total, 6)[others] == -7.0).all()
+        assert np.array_equal(np.asarray(isv), i0) and m.last_stats == ref_m.last_stats
+        ref_m.data_manager.update()
+        m.data_manager.update()
+    with pytest.raises(_lib.DxmError, match="ROWS"):
+        m.integrate(h[3])
+    m.close()
+    ref_m.close()
+
+
 @pytest.mark.parametrize("kind,n,total,devices", [("linear", 300_007, 700_000, None), ("voce", 70_001, 70_001, None), ("linear", 1, 5, None),
                                                   ("linear", 150_003, 200_000, [0, 0, 0])])
 def test_integrate_rows_delivers_every_point_into_its_row(kind, n, total, devices):

@@ -67,7 +67,11 @@ def test_accelerated_map_is_bit_identical_to_the_reference_cadence(law, ncell, n
         for name in _fields(slow):
             assert np.array_equal(_fields(fast)[name], _fields(slow)[name]), (k, "advance", name)
     assert fast._bound == (not subset)
+    # default mode: the state fields were written by the engine inside every update -- into the bound Functions of a map over all
+    # cells, into the rows `dofs` of the Functions of a map over a subset (bind_state_outputs(rows=True)) -- never by a second pass
+    assert fast.material.delivers_state_outputs == frozenset(fast.material.internal_state_variables)
     fast.close()
+    assert fast.material.delivers_state_outputs == frozenset()
     fast.material.close()
     slow.material.close()
 

@@ -137,3 +137,37 @@ def test_field_map_sequences_on_the_test_double(fake, seed, subset):
     from test_gpu_fuzz_protocol import test_field_map_driven_by_the_engine_equals_field_map_driven_by_the_oracle as run
 
     run(seed, subset)
+
+
+def test_state_fields_bound_for_row_delivery_serve_the_rows_forms_only(fake):
+    """``bind_state_outputs(deliver=True, rows=True)``: the ISV Functions over ALL cells of a map over a subset; ``integrate_rows`` puts
+    the fields of point i into row rows[i] (here through the test double, on the GPU by the worker threads of ``dxm_integrate_rows``),
+    ``integrate`` refuses while the binding is in place, unbinding restores it."""
+    from dolfinx_materials_amd._lib import DxmError
+    from oracle import oracle_c
+
+    n, total = 300, 337
+    m = _j2()
+    m.set_data_manager(n)
+    rows = np.ascontiguousarray(np.random.default_rng(5).permutation(total)[:n], dtype=np.int64)
+    flux_all, jac_all = np.full((total, 6), 9.0), np.full((total, 36), 9.0)
+    fields = {"p": np.full(total, 9.0), "epsp": np.full(total * 6, 9.0)}
+    with pytest.raises(ValueError):
+        m.bind_state_outputs(fields, rows=True)                      # rows describes deliveries
+    with pytest.raises(ValueError):
+        m.bind_state_outputs({"p": np.zeros(n - 1)}, deliver=True, rows=True)
+    m.bind_state_outputs(fields, deliver=True, rows=True)
+    assert m.delivers_state_outputs == {"p", "epsp"}
+    eps = j2_history(n, seed=12)[2]
+    m.integrate_rows(eps, rows, flux_all, jac_all)
+    ref = oracle_c.j2(eps, np.zeros((n, 6)), np.zeros(n), E, NU, 0, SIG0_LIN, H_LIN)
+    others = np.setdiff1d(np.arange(total), rows)
+    assert np.array_equal(fields["p"][rows], ref["p"]) and np.array_equal(fields["epsp"].reshape(total, 6)[rows], ref["epsp"])
+    assert (fields["p"][others] == 9.0).all() and (fields["epsp"].reshape(total, 6)[others] == 9.0).all() and ref["n_plastic"] > 0
+    with pytest.raises(DxmError, match="ROWS"):
+        m.integrate(eps)
+    for name in fields:
+        m._unbind("isv:" + name)
+    assert m.delivers_state_outputs == frozenset()
+    m.integrate(eps)
+    m.close()
