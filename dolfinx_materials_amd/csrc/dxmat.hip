@@ -1199,8 +1199,10 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && (!constant || rowmode))
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
-        if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, constant ? 0 : np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
-        if (isv_rows) scatter_fields(o, (n - o) < csize ? (n - o) : csize);
+        if (rowmode) {
+          m->pool->submit(constant ? m->elastic_lm : m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, constant ? 0 : np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
+          if (isv_rows) scatter_fields(o, (n - o) < csize ? (n - o) : csize);
+        }
         else m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, job, pack4 ? flux_aos + o * d.n_flux : nullptr);
         ++submitted;
       }
@@ -1218,8 +1220,10 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
     if (packed && (!constant || rowmode) && c >= submitted) {
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
-      if (rowmode) m->pool->submit(constant ? m->elastic_lm : m->h_coef + off * np, ct_aos, cnt, constant ? 0 : np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
-      if (isv_rows) scatter_fields(off, cnt);
+      if (rowmode) {
+        m->pool->submit(constant ? m->elastic_lm : m->h_coef + off * np, ct_aos, cnt, constant ? 0 : np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
+        if (isv_rows) scatter_fields(off, cnt);
+      }
       else m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, job, pack4 ? flux_aos + off * d.n_flux : nullptr);
       submitted = c + 1;
     }
