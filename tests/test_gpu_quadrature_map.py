@@ -260,14 +260,14 @@ def test_close_gives_back_only_what_the_map_bound():
     n = ncell * nqp
     cells = np.arange(0, ncell, 2, dtype=np.int32)
     m = JAXMaterial(_behavior("j2_linear"))
-    q = QuadratureFieldMap(ncell, nqp, m, cells=cells)          # a subset map binds nothing itself
+    q = QuadratureFieldMap(ncell, nqp, m, cells=cells)          # a subset map binds its ISV Functions (row deliveries), nothing else
     npts = len(cells) * nqp
     mine = np.zeros(npts * 6)
     m.bind_inputs(gradient=mine)                                # the caller's own page-locked gradient buffer
     eps = j2_history(npts, seed=5)[2]
     q.register_gradient("strain", lambda c: eps.reshape(len(cells), nqp, 6))
     q.update()
-    assert set(m._bound) == {"gradient"}
+    assert set(m._bound) == {"gradient", "isv:p", "isv:epsp"} and m.delivers_state_outputs == {"p", "epsp"}
     q.close()
     assert set(m._bound) == {"gradient"} and m._bound["gradient"] is mine
     # ... and a map over everything gives back its five, not the sixth
