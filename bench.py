@@ -390,7 +390,8 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
                 "ms_per_update_integrate_then_threaded_scatter": out["rows_on_library_threads"],
                 "ms_per_update_integrate_then_numpy_assignment": out["rows_by_numpy"], "same_fields": bool(same),
                 "value": round(npts / out["rows_by_the_engine"] / 1e3, 2), "unit": "Mpoints/s",
-                "note": "HIPMaterial.integrate_rows (dxm_integrate_rows): the threads that rebuild the tangent blocks store stress and block in the point's row"}
+                "note": "HIPMaterial.integrate_rows (dxm_integrate_rows): the threads that rebuild the tangent blocks store stress, block and (default ISV mode, "
+                        "bind_state_outputs(rows=True)) the internal state variables in the point's row of the Functions over all cells"}
 
     def packed_legs(fast, f_fields, keep_f, lazy_full=None):
         """the same accelerated update with a material that hands its tangent out packed -- jacobian_flatten is
