@@ -171,7 +171,8 @@ struct dxm_material {
   int64_t opt_packed_min_points = 32768;   // below: waking the workers costs what the bytes save (r02_hostpath_v2.jsonl)
   int opt_max_chunks = DXM_MAX_CHUNKS;
   HostPool* pool = nullptr;
-  double* h_coef = nullptr;               // page-locked (n, 9) landing area of the tangent coefficients
+  double* h_coef = nullptr;               // page-locked landing area of the tangent coefficients, h_coef_per_point doubles per point
+  int h_coef_per_point = 0;
   double* h_flux = nullptr;               // page-locked (n, 6) landing area of the stress (dxm_integrate_rows)
   double* h_isv = nullptr;                // page-locked landing area of the bound state fields in the rows forms, field after field
   double elastic_lm[2] = {0.0, 0.0};      // lambda, mu handed to the constant-block fill
@@ -1003,20 +1004,30 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
                           ct_aos != nullptr && flux_aos != nullptr && n >= m->opt_packed_min_points &&
                           (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux));
   const bool packed = rowmode || sym_packed || (m->opt_packed_transfer && m->tangent_layout == DXM_TANGENT_FULL && ct_aos != nullptr && n >= m->opt_packed_min_points);
-  const bool constant = packed && m->law == DXM_LAW_ELASTIC_ISO;
+  // the rows forms of a handle whose OWN layout is packed (sym / coef / pack4): the kernel writes that layout, it lands in the
+  // library's page-locked area like the stress, and the worker threads MOVE point i to row rows[i] -- nothing is rebuilt
+  const bool rows_plain = rowmode && m->tangent_layout != DXM_TANGENT_FULL;
+  const bool constant = packed && !rows_plain && m->law == DXM_LAW_ELASTIC_ISO;
   // small strain: (c1, c2, c3, w) only -- the direction n is rebuilt from the stress, which the caller receives in
   // page-locked memory as part of the same chunk -- else the nine coefficients
-  const bool pack4 = packed && !constant && !fefp && (rowmode || (m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
+  const bool pack4 = packed && !constant && !fefp && !rows_plain && (rowmode || (m->opt_packed_transfer >= 2 && flux_aos != nullptr &&
                      (m->opt_pageable_dma || page_locked(flux_aos, sizeof(double) * n * d.n_flux))));
-  const int tl = packed && !constant ? (pack4 ? TL_PACK4 : TL_COEF) : m->tangent_layout;   // layout of this call's launches
-  const int np = fefp ? FEFP_REC : (pack4 ? 4 : 9);                     // doubles per point of the packed form
+  const int tl = rows_plain ? m->tangent_layout : (packed && !constant ? (pack4 ? TL_PACK4 : TL_COEF) : m->tangent_layout);   // layout of this call's launches
+  const int np = rows_plain ? tangent_size(m) : (fefp ? FEFP_REC : (pack4 ? 4 : 9));   // doubles per point of what lands in h_coef
   const int nfull = sym_packed ? 21 : d.n_flux * d.n_grad;      // doubles per point of what the workers rebuild in the caller's array
   const int job = sym_packed ? -4 : np;                         // HostPool job code of that rebuild
   const int nt = packed && !constant ? np : tangent_size(m);   // doubles per point in d_ct: the packed form of this call, else the handle's layout
   if (!m->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream, hipStreamNonBlocking));
   if (m->opt_split_streams && !m->down_stream2) HIP_TRY(hipStreamCreateWithFlags(&m->down_stream2, hipStreamNonBlocking));
   if (packed || host_grad) {
-    if (packed && !constant && !m->h_coef) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * (fefp ? FEFP_REC : 9), hipHostMallocDefault));
+    const int land = fefp ? FEFP_REC : (np > 9 ? np : 9);   // (9 covers both packed forms of the J2 laws; a "sym" handle in the rows forms lands 21)
+    if (packed && !constant && m->h_coef_per_point < land) {
+      if (m->h_coef) HIP_TRY(hipHostFree(m->h_coef));
+      m->h_coef = nullptr;
+      m->h_coef_per_point = 0;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_coef), sizeof(double) * n * land, hipHostMallocDefault));
+      m->h_coef_per_point = land;
+    }
     if (rowmode && !m->h_flux) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_flux), sizeof(double) * n * d.n_flux, hipHostMallocDefault));
     if (isv_rows && !m->h_isv) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_isv), sizeof(double) * n * total, hipHostMallocDefault));
     if (!m->pool || (int)m->pool->threads.size() != m->opt_host_threads) {
@@ -1200,8 +1211,13 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       while (submitted < issued && hipEventQuery(m->chunk_done[submitted]) == hipSuccess) {
         const int64_t o = (int64_t)submitted * csize;
         if (rowmode) {
-          m->pool->submit(constant ? m->elastic_lm : m->h_coef + o * np, ct_aos, (n - o) < csize ? (n - o) : csize, constant ? 0 : np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
-          if (isv_rows) scatter_fields(o, (n - o) < csize ? (n - o) : csize);
+          const int64_t cn = (n - o) < csize ? (n - o) : csize;
+          if (rows_plain) {
+            m->pool->submit_scatter(m->h_flux + o * d.n_flux, flux_aos, rows + o, cn, d.n_flux);
+            m->pool->submit_scatter(m->h_coef + o * np, ct_aos, rows + o, cn, np);
+          }
+          else m->pool->submit(constant ? m->elastic_lm : m->h_coef + o * np, ct_aos, cn, constant ? 0 : np, m->h_flux + o * d.n_flux, rows + o, flux_aos);
+          if (isv_rows) scatter_fields(o, cn);
         }
         else m->pool->submit(m->h_coef + o * np, ct_aos + o * nfull, (n - o) < csize ? (n - o) : csize, job, pack4 ? flux_aos + o * d.n_flux : nullptr);
         ++submitted;
@@ -1221,7 +1237,11 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
       const int64_t off = (int64_t)c * csize;
       const int64_t cnt = (n - off) < csize ? (n - off) : csize;
       if (rowmode) {
-        m->pool->submit(constant ? m->elastic_lm : m->h_coef + off * np, ct_aos, cnt, constant ? 0 : np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
+        if (rows_plain) {
+          m->pool->submit_scatter(m->h_flux + off * d.n_flux, flux_aos, rows + off, cnt, d.n_flux);
+          m->pool->submit_scatter(m->h_coef + off * np, ct_aos, rows + off, cnt, np);
+        }
+        else m->pool->submit(constant ? m->elastic_lm : m->h_coef + off * np, ct_aos, cnt, constant ? 0 : np, m->h_flux + off * d.n_flux, rows + off, flux_aos);
         if (isv_rows) scatter_fields(off, cnt);
       }
       else m->pool->submit(m->h_coef + off * np, ct_aos + off * nfull, cnt, job, pack4 ? flux_aos + off * d.n_flux : nullptr);
@@ -1357,8 +1377,6 @@ int dxm_integrate_rows(dxm_material* m, const double* grad_aos, double dt, doubl
   (void)dt;
   if (!m) return fail(-1, "null handle");
   if (m->n > 0 && (!flux_rows || !ct_rows || !rows)) return fail(-1, "dxm_integrate_rows needs the flux array, the tangent array and the row index");
-  if (m->tangent_layout != DXM_TANGENT_FULL)
-    return fail(-1, "dxm_integrate_rows: the full tangent layout only (packed layouts: dxm_integrate + dxm_host_scatter_rows)");
   return integrate_host(m, grad_aos, flux_rows, nullptr, ct_rows, stats, rows);
 }
 
@@ -1621,7 +1639,6 @@ int dxm_integrate_displacement_rows(dxm_material* m, dxm_mesh* mesh, const doubl
   (void)dt;
   if (!m) return fail(-1, "null argument");
   if (m->n > 0 && (!flux_rows || !ct_rows || !rows)) return fail(-1, "dxm_integrate_displacement_rows needs the flux array, the tangent array and the row index");
-  if (m->tangent_layout != DXM_TANGENT_FULL) return fail(-1, "dxm_integrate_displacement_rows: the full tangent layout only");
   return integrate_displacement_host(m, mesh, u_host, flux_rows, nullptr, ct_rows, stats, rows);
 }
 

@@ -714,19 +714,18 @@ class HIPMaterial:
 
     @property
     def supports_row_outputs(self):
-        """Whether :meth:`integrate_rows` exists for this material (full tangent blocks; every law)."""
-        return self.tangent_layout == "full"
+        """Whether :meth:`integrate_rows` exists for this material (every law, every tangent layout: a packed layout's rows are
+        ``tangent_size`` wide and are moved to their rows as they are, the full blocks are rebuilt there)."""
+        return True
 
     def _check_rows(self, rows, flux, tangent):
-        ng, nf = self._info.n_grad, self._info.n_flux
-        if not self.supports_row_outputs:
-            raise DxmError("integrate_rows: tangent_layout='full' only (integrate + scatter_rows otherwise)")
+        nf, nt = self._info.n_flux, self.tangent_size
         if not (isinstance(rows, np.ndarray) and rows.dtype == np.int64 and rows.flags.c_contiguous and rows.shape == (self._n,)):
             raise ValueError(f"rows must be a C-contiguous int64 array of {self._n} entries")
-        for name, arr, w in (("flux", flux, nf), ("tangent", tangent, nf * ng)):
+        for name, arr, w in (("flux", flux, nf), ("tangent", tangent, nt)):
             if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size % w == 0):
                 raise ValueError(f"{name} must be a C-contiguous float64 array of whole rows of {w}")
-        total = min(flux.size // nf, tangent.size // (nf * ng))
+        total = min(flux.size // nf, tangent.size // nt)
         # every call: dxm_integrate_rows does not range-check the index, and neither the address of the index array nor its
         # length says that its CONTENT is still the one checked last time (~1 ms per 1e7 entries on the library's threads)
         lo, hi = C.c_int64(0), C.c_int64(0)
@@ -747,7 +746,8 @@ class HIPMaterial:
     def integrate_rows(self, gradients, rows, flux, tangent, dt=0):
         """``integrate`` for a map over a SUBSET of the cells (``dxm_integrate_rows``): ``gradients`` are this material's
         ``(N, ng)`` points as usual, but ``flux`` / ``tangent`` are the arrays of the quadrature Functions over ALL cells
-        -- ``(M, nf)`` / ``(M, nf * ng)`` (or flat), ``M >= N`` -- and point ``i`` is delivered into their row ``rows[i]``: what
+        -- ``(M, nf)`` / ``(M, tangent_size)`` (or flat; 36 / 81 for the full layout, 21 / 9 / 4 for the packed ones), ``M >= N`` -- and
+        point ``i`` is delivered into their row ``rows[i]``: what
         ``_update_vals(field, values, cells)`` does with one fancy assignment per array per update
         (``utils.py:136-143``), done by the threads that rebuild the tangent blocks.  ``rows``: C-contiguous int64, each row
         once (``QuadratureMap.dofs``).  Returns the internal state variables (lazily, like ``integrate``); the flux of the

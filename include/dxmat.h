@@ -183,9 +183,11 @@ int dxm_integrate(dxm_material* m, const double* grad_aos, double dt, double* fl
  * (utils.py:136-143).  Of each point 80 B cross PCIe into the library's page-locked landing areas and the worker threads that
  * rebuild the (6, 6) blocks store them, and the stress, straight into their rows; the caller's arrays need not be page-locked.
  * (The elastic law's constant block is filled in by the same threads, the FeFp laws move their 54 building blocks + 9 stress
- * components per point.)  DXM_TANGENT_FULL only (packed layouts: dxm_integrate + dxm_host_scatter_rows); the index holds each
- * row once and is NOT range-checked here (dxm_host_index_range is the check; the Python layer runs it per call); internal
- * state variables: dxm_isv_host / dxm_get_state when needed. */
+ * components per point.)  A handle with a packed tangent layout (DXM_TANGENT_SYM / _COEF / _PACK4): ct_rows has dxm_tangent_size
+ * doubles per row, the kernel's own 21 / 9 / 4 numbers land and are moved to their rows as they are -- nothing is rebuilt.  The index
+ * holds each row once and is NOT range-checked here (dxm_host_index_range is the check; the Python layer runs it per call);
+ * internal state variables: bound with dxm_bind_isv_output they are delivered into their rows by the same call, else
+ * dxm_isv_host / dxm_get_state when needed. */
 int dxm_integrate_rows(dxm_material* m, const double* grad_aos, double dt, double* flux_rows, double* ct_rows,
                        const int64_t* rows, dxm_stats* stats);
 /* Device-pointer form: all three arrays are device memory on the handle's device (e.g. torch

@@ -399,20 +399,46 @@ def test_integrate_rows_for_the_elastic_and_the_finite_strain_law(law, n, total)
     ref_m.close()
 
 
-def test_integrate_rows_is_refused_for_packed_tangent_layouts():
-    from dolfinx_materials_amd._lib import DxmError
-
-    n = 1000
-    rows = np.arange(n, dtype=np.int64)
-    packed = _j2(tangent_layout="coef")
-    packed.set_data_manager(n)
-    assert not packed.supports_row_outputs
-    with pytest.raises(DxmError):
-        packed.integrate_rows(np.zeros((n, 6)), rows, np.zeros(n * 6), np.zeros(n * 36))
-    import ctypes as C
-    assert packed._lib.dxm_integrate_rows(packed._handles()[0], np.zeros((n, 6)).ctypes.data_as(C.c_void_p), 0.0, np.zeros(n * 6).ctypes.data_as(C.c_void_p),
-                                          np.zeros(n * 36).ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), None) < 0
-    packed.close()
+@pytest.mark.parametrize("law,layout,n,total", [("linear", "pack4", 300_007, 700_000), ("voce", "coef", 70_001, 70_001), ("linear", "sym", 150_003, 200_000),
+                                                ("elastic", "sym", 40_001, 50_000), ("linear", "pack4", 1, 3)])
+def test_integrate_rows_moves_the_rows_of_a_packed_tangent_layout(law, layout, n, total):
+    """The rows forms for a handle whose own tangent layout is packed (round 6): the kernel's 21 / 9 / 4 numbers per point land in the
+    library's page-locked area and are MOVED to row rows[i] of an ``(M, tangent_size)`` array -- nothing is rebuilt; stress and (bound)
+    state fields go with them; bit-identical to ``integrate`` of the same layout followed by a fancy assignment."""
+    rng = np.random.default_rng(n + 7)
+    rows = np.ascontiguousarray(rng.permutation(total)[:n], dtype=np.int64)
+    others = np.setdiff1d(np.arange(total), rows)
+    if law == "elastic":
+        make = lambda: JAXMaterial(jm.ElasticBehavior(jm.LinearElasticIsotropic(E=E, nu=NU)), tangent_layout=layout)   # noqa: E731
+    else:
+        make = lambda: _j2(law, tangent_layout=layout)   # noqa: E731
+    ref_m, m = make(), make()
+    ref_m.set_data_manager(n)
+    m.set_data_manager(n)
+    width = m.tangent_size
+    assert m.supports_row_outputs and width == {"pack4": 4, "coef": 9, "sym": 21}[layout]
+    flux_fn, jac_fn = np.full((total, 6), -7.0), np.full(total * width, -7.0)
+    fields = {name: np.full(total * max(1, dim), -7.0) for name, dim in m.internal_state_variables.items()}
+    if fields:
+        m.bind_state_outputs(fields, deliver=True, rows=True)
+    h = j2_history(n, seed=4, sig0=SIG0_V if law == "voce" else SIG0_LIN)
+    for k, eps in enumerate(h[:3]):
+        f0, i0, c0 = ref_m.integrate(eps)
+        i0 = np.asarray(i0)
+        m.integrate_rows(eps, rows, flux_fn, jac_fn)
+        assert np.array_equal(flux_fn[rows], f0) and np.array_equal(jac_fn.reshape(total, width)[rows], np.asarray(c0).reshape(n, width)), k
+        assert (flux_fn[others] == -7.0).all() and (jac_fn.reshape(total, width)[others] == -7.0).all()
+        col = 0
+        for name, dim in m.internal_state_variables.items():
+            assert np.array_equal(fields[name].reshape(total, dim)[rows], i0[:, col:col + dim]), (k, name)
+            col += dim
+        assert m.last_stats == ref_m.last_stats
+        ref_m.data_manager.update()
+        m.data_manager.update()
+    with pytest.raises(ValueError):
+        m.integrate_rows(h[3], rows, flux_fn, np.zeros(total * 36 + 1))        # whole rows of tangent_size doubles
+    m.close()
+    ref_m.close()
 
 
 def test_results_are_delivered_into_bound_caller_arrays():

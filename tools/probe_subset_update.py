@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(npts=5_000_000, mode_isv=True):
+def main(npts=5_000_000, mode_isv=True, layout="full"):
     import dolfinx_materials_amd.materials as jm
     from dolfinx_materials_amd.field_map import QuadratureFieldMap
     from dolfinx_materials_amd.jaxmat import JAXMaterial
@@ -24,7 +24,7 @@ def main(npts=5_000_000, mode_isv=True):
     h = j2_history(npts)
     ncell = npts // 8
     cells = np.arange(0, 2 * ncell, 2)
-    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)))
+    m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0_LIN, H_LIN)), tangent_layout=layout)
     q = QuadratureFieldMap(2 * ncell, 8, m, cells=cells)
     q.isv_every_update = mode_isv
     strain = h[0][:ncell * 8]
@@ -45,7 +45,7 @@ def main(npts=5_000_000, mode_isv=True):
         t0 = time.perf_counter()
         q.update()
         ts.append(time.perf_counter() - t0)
-    print(f"isv_every_update={mode_isv!r}: ms per update {[round(t * 1e3, 1) for t in ts]}", flush=True)
+    print(f"layout={layout} isv_every_update={mode_isv!r}: ms per update {[round(t * 1e3, 1) for t in ts]}", flush=True)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(3):
@@ -62,5 +62,6 @@ def main(npts=5_000_000, mode_isv=True):
 
 
 if __name__ == "__main__":
-    main(mode_isv=True)
-    main(mode_isv="lazy")
+    for layout in (sys.argv[1:] or ["full"]):
+        main(mode_isv=True, layout=layout)
+        main(mode_isv="lazy", layout=layout)
