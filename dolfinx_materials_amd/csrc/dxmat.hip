@@ -48,11 +48,16 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// A failing runtime call is reported through the library's own channel (return code + dxm_last_error) and CONSUMED here: the
+// runtime's per-thread "last error" is shared with the host application (torch checks it after its own launches), which must not
+// find an error of this library in it (tests/conftest.py checks the state after every GPU test).
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
     hipError_t _e = (expr);                                                                \
-    if (_e != hipSuccess)                                                                  \
+    if (_e != hipSuccess) {                                                                \
+      (void)hipGetLastError();                                                             \
       return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    }                                                                                      \
   } while (0)
 
 // Selects the handle's device for the duration of a call and restores the caller's current
@@ -1385,6 +1390,7 @@ void* dxm_host_alloc(uint64_t bytes) {
   if (bytes == 0) bytes = 8;
   hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     fail(-3, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
     return nullptr;
   }
@@ -1803,7 +1809,10 @@ int dxm_host_index_range(const int64_t* rows, int64_t n, int threads, int64_t* l
 int dxm_host_register(void* p, uint64_t bytes) {
   if (!p || bytes == 0) return fail(-1, "null / empty host range");
   hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
-  if (e != hipSuccess) return fail(-3, "hipHostRegister(%p, %llu) failed: %s", p, (unsigned long long)bytes, hipGetErrorString(e));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();   // (a range that is registered already, memory that cannot be pinned: the caller falls back)
+    return fail(-3, "hipHostRegister(%p, %llu) failed: %s", p, (unsigned long long)bytes, hipGetErrorString(e));
+  }
   note_locked(p, bytes);
   return 0;
 }
