@@ -354,10 +354,11 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
         from dolfinx_materials_amd.field_map import QuadratureFieldMap
 
         out = {}
-        for label, mode in (("rows_by_the_engine", "engine"), ("rows_on_library_threads", "threads"), ("rows_by_numpy", "numpy")):
+        for label, mode in (("rows_by_the_engine", "engine"), ("rows_on_library_threads", "threads"), ("rows_by_numpy", "numpy"), ("rows_by_the_engine_pack4", "engine")):
             ncell = npts // 8
             cells = np.arange(0, 2 * ncell, 2)
-            m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index)
+            m = JAXMaterial(jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.LinearHardening(SIG0, H)), device=dev_index,
+                            tangent_layout="pack4" if label.endswith("pack4") else "full")
             if mode == "numpy":
                 m.scatter_rows = m.gather_rows = None
             q = QuadratureFieldMap(2 * ncell, 8, m, cells=cells)
@@ -382,13 +383,20 @@ def host_path(jm, JAXMaterial, dev_index, n, seed, reps=9):
                 q.update()
                 ts.append(time.perf_counter() - t0)
             out[label] = round(float(np.median(ts)) * 1e3, 2)
-            out.setdefault("check", []).append(float(q.jacobian_flatten.x.array[::997].sum()))
+            if label.endswith("pack4"):   # (another tangent Function: compared through the stress and the state fields)
+                out["pack4_same_stress_and_state"] = bool(out["stress_check"] == float(q.fluxes["stress"].x.array[::997].sum())
+                                                          and out["p_check"] == float(q.internal_state_variables["p"].x.array[::997].sum()))
+            else:
+                out.setdefault("check", []).append(float(q.jacobian_flatten.x.array[::997].sum()))
+                out["stress_check"] = float(q.fluxes["stress"].x.array[::997].sum())
+                out["p_check"] = float(q.internal_state_variables["p"].x.array[::997].sum())
             q.close()
             m.close()
         same = out["check"][0] == out["check"][1] == out["check"][2]
         return {"points_in_map": npts, "points_in_fields": 2 * npts, "ms_per_update": out["rows_by_the_engine"],
                 "ms_per_update_integrate_then_threaded_scatter": out["rows_on_library_threads"],
                 "ms_per_update_integrate_then_numpy_assignment": out["rows_by_numpy"], "same_fields": bool(same),
+                "ms_per_update_pack4_layout": out["rows_by_the_engine_pack4"], "pack4_same_stress_and_state": out.get("pack4_same_stress_and_state"),
                 "value": round(npts / out["rows_by_the_engine"] / 1e3, 2), "unit": "Mpoints/s",
                 "note": "HIPMaterial.integrate_rows (dxm_integrate_rows): the threads that rebuild the tangent blocks store stress, block and (default ISV mode, "
                         "bind_state_outputs(rows=True)) the internal state variables in the point's row of the Functions over all cells"}
