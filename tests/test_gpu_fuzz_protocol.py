@@ -52,7 +52,8 @@ def close(a, b, scale):
 @pytest.mark.parametrize("seed,n,bound,lazy", [(0, 777, False, True), (1, 5000, True, True), (2, 64, False, False),
                                                (3, 40_000, True, False), (4, 1, False, True), (5, 70_001, False, True),
                                                (6, 3000, "io", True), (7, 66_000, "io", True), (8, 130, "io", False),
-                                               (9, 2500, "rows", True), (10, 70_003, "rows", True), (11, 1, "rows", True)])
+                                               (9, 2500, "rows", True), (10, 70_003, "rows", True), (11, 1, "rows", True),
+                                               (12, 3100, "rows_isv", True), (13, 70_009, "rows_isv", True)])
 def test_random_operation_sequences_match_the_state_model(seed, n, bound, lazy):
     run_operation_sequence(seed, n, bound, lazy)
 
@@ -67,11 +68,16 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
     beh = jm.vonMisesIsotropicHardening(jm.LinearElasticIsotropic(E=E, nu=NU), jm.VoceHardening(SIG0_V, SIGU_V, B_V))
     m = JAXMaterial(beh, lazy_isv=lazy)
     m.set_data_manager(n)
-    if bound == "rows":   # a map over a subset of the cells: results into rows `rows` of arrays over all cells (integrate_rows)
+    isv_rows = None
+    if bound in ("rows", "rows_isv"):   # a map over a subset of the cells: results into rows `rows` of arrays over all cells (integrate_rows)
         total = n + 37
         rows = np.ascontiguousarray(np.random.default_rng(seed + 100).permutation(total)[:n], dtype=np.int64)
         flux_all, jac_all = np.full((total, 6), 9.0), np.full((total, 36), 9.0)
         others = np.setdiff1d(np.arange(total), rows)
+        if bound == "rows_isv":   # ... and the ISV Functions over all cells as row destinations (what the accelerated map binds by default)
+            isv_rows = {"p": np.full(total, 9.0), "epsp": np.full(total * 6, 9.0)}
+            m.bind_state_outputs(isv_rows, deliver=True, rows=True)
+            bound = "rows"
     elif bound:
         flux_fn, jac_fn = np.zeros(n * 6), np.zeros(n * 36)
         m.bind_outputs(flux=flux_fn, tangent=jac_fn)
@@ -127,6 +133,11 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
                 isv = m.integrate_rows(eps, rows, flux_all, jac_all)
                 sig, ct = flux_all[rows], jac_all[rows]
                 assert (flux_all[others] == 9.0).all() and (jac_all[others] == 9.0).all()
+                if isv_rows is not None:   # the state fields of this very call, in their rows; nobody else's rows touched
+                    r_now = oracle_c.j2(eps, model.s0["epsp"], model.s0["p"], E, NU, 1, model.sig0, SIGU_V, B_V)
+                    assert close(isv_rows["p"][rows], r_now["p"], max(r_now["p"].max(), 1e-300) + 1e-30)
+                    assert close(isv_rows["epsp"].reshape(total, 6)[rows], r_now["epsp"], max(np.abs(r_now["epsp"]).max(), 1e-300) + 1e-30)
+                    assert (isv_rows["p"][others] == 9.0).all() and (isv_rows["epsp"].reshape(total, 6)[others] == 9.0).all()
             else:
                 sig, isv, ct = m.integrate(eps)
             ref = model.integrate(eps)
@@ -223,7 +234,8 @@ def run_operation_sequence(seed, n, bound, lazy, device_ops=True, tol=TOL, nops=
 
 @pytest.mark.parametrize("seed,n,bound,lazy", [(0, 77, False, True), (1, 500, True, True), (2, 64, False, False), (3, 400, True, False),
                                                (6, 300, "io", True), (7, 660, "io", True), (8, 130, "io", False), (9, 250, "rows", True),
-                                               (10, 703, "rows", True), (21, 90, "io", True), (22, 90, "rows", True), (23, 90, True, True)])
+                                               (10, 703, "rows", True), (21, 90, "io", True), (22, 90, "rows", True), (23, 90, True, True),
+                                               (12, 310, "rows_isv", True), (25, 90, "rows_isv", True)])
 def test_the_test_double_and_the_library_leave_the_same_trace(monkeypatch, seed, n, bound, lazy):
     """``tests/fake_dxmat.py`` restates the handle semantics of ``csrc/dxmat.hip`` in Python so that the layer above the C ABI is
     fuzzed on every CPU run (``tests/test_protocol_fuzz_cpu.py``, these very seeds).  Here the SAME seed runs against the double and

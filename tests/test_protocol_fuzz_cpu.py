@@ -28,7 +28,8 @@ def fake(monkeypatch):
 @pytest.mark.parametrize("seed,n,bound,lazy", [(0, 77, False, True), (1, 500, True, True), (2, 64, False, False), (3, 400, True, False),
                                                (4, 1, False, True), (6, 300, "io", True), (7, 660, "io", True), (8, 130, "io", False),
                                                (9, 250, "rows", True), (10, 703, "rows", True), (11, 1, "rows", True),
-                                               (21, 90, "io", True), (22, 90, "rows", True), (23, 90, True, True), (24, 90, False, True)])
+                                               (21, 90, "io", True), (22, 90, "rows", True), (23, 90, True, True), (24, 90, False, True),
+                                               (12, 310, "rows_isv", True), (25, 90, "rows_isv", True)])
 def test_random_operation_sequences_on_the_test_double(fake, seed, n, bound, lazy):
     from test_gpu_fuzz_protocol import run_operation_sequence
 
