@@ -316,14 +316,17 @@ def test_update_keeps_the_references_timer_rows_with_the_engine(monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("law,ncell,nqp", [("j2_linear", 5000, 8), ("j2_voce", 601, 4), ("fefp", 4600, 8)])
-def test_default_mode_writes_the_isv_functions_inside_the_update_itself(law, ncell, nqp):
+@pytest.mark.parametrize("law,ncell,nqp,subset", [("j2_linear", 5000, 8, False), ("j2_voce", 601, 4, False), ("fefp", 4600, 8, False),
+                                                  ("j2_linear", 9000, 8, True), ("fefp", 4600, 8, True)])
+def test_default_mode_writes_the_isv_functions_inside_the_update_itself(law, ncell, nqp, subset):
     """`isv_every_update = True` (the default: the reference writes the ISV Functions in every update, quadrature_map.py:332) with
     the engine and a map over all cells: the fields of the final state travel inside `integrate`'s own transfer pipeline into the
     Functions' page-locked memory (`dxm_bind_isv_output`) -- no second pass over the state (`read_final_state` is not called by
     `update()`), a Function object taken out of the dict earlier is current when `update()` returns, and the values are the bits
-    the lazy mode downloads.  Switching the mode switches the delivery."""
+    the lazy mode downloads.  Switching the mode switches the delivery.  ``subset``: a map over every other cell -- the Functions over
+    all cells are bound as ROW destinations and ``integrate_rows`` writes the fields of point i into row ``dofs[i]``."""
     n = ncell * nqp
+    cells = np.arange(0, ncell, 2, dtype=np.int32) if subset else None
     if law == "fefp":
         hist, gname, ng = fefp_path(n, nsteps=6, eps=3e-2)[::2], "F", 9
     else:
@@ -332,7 +335,7 @@ def test_default_mode_writes_the_isv_functions_inside_the_update_itself(law, nce
     ev = lambda c: now["g"].reshape(ncell, nqp, ng)[c].reshape(-1, ng)   # noqa: E731
     maps = {}
     for mode in (True, "lazy"):
-        q = QuadratureFieldMap(ncell, nqp, JAXMaterial(_behavior(law)))
+        q = QuadratureFieldMap(ncell, nqp, JAXMaterial(_behavior(law)), cells=cells)
         q.isv_every_update = mode
         q.register_gradient(gname, ev)
         maps[mode] = q
@@ -342,6 +345,7 @@ def test_default_mode_writes_the_isv_functions_inside_the_update_itself(law, nce
         now["g"] = np.tile(np.array([1.0, 1, 1, 0, 0, 0, 0, 0, 0]), (n, 1))
         for q in maps.values():
             q.update()
+    assert fast._accel_plan().identity == (not subset)
     reads = []
     inner = fast.material.read_final_state
     fast.material.read_final_state = lambda name, out: (reads.append(name), inner(name, out))[1]
