@@ -969,10 +969,11 @@ static int ensure_host_path_buffers(dxm_material* m, bool need_grad = true) {
 
 // Host-buffer form, shared by dxm_integrate and dxm_integrate_displacement.
 //   upload(off, cnt, stream) enqueues whatever produces m->d_grad[off .. off+cnt) on `stream`.
-// Large batches are cut into up to 64 chunks (multiples of 256 points) issued on two alternating
-// streams: the H2D and the kernel of chunk c+1 overlap the D2H of chunk c (PCIe is full duplex and the
-// bytes coming back dominate).  Each chunk is one launch over a point range; its block-stat records
-// are appended after the previous chunk's.
+// Large batches are cut into chunks (multiples of 256 points): the H2D and the kernel of chunk c+1 overlap the D2H of
+// chunk c (PCIe is full duplex and the bytes coming back dominate).  Page-locked gradient arrays: up to 24 chunks, uploads +
+// kernels on one stream, downloads on two others (option split_streams, see below); staged uploads and the displacement
+// forms: up to 64 whole chunks alternating on two streams.  Each chunk is one launch over a point range; its block-stat
+// records are appended after the previous chunk's.
 //
 // What crosses PCIe on the way back, per point: the flux (48 / 72 B), the tangent, and -- only when the
 // caller passes a destination -- the internal state variables (they are consumed at advance(), not per
@@ -1232,7 +1233,7 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   m->last_grid = stats_off;
   m->launched = true;
   m->s1_alias = false;  // every slot of s1 has been rewritten
-  // the chunks complete in issue order on their two streams; rebuild each block as soon as it has landed
+  // the chunks complete in issue order on their streams; rebuild each block as soon as it has landed
   const auto t_issued = std::chrono::steady_clock::now();
   auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   for (int c = 0; c < issued; ++c) {

@@ -281,7 +281,7 @@ struct HostPool {
 // ------------------------------------------------------------------------------------------
 // chunk planner of the host-buffer form, ring slots, status-record capacity
 // ------------------------------------------------------------------------------------------
-// Large batches are cut into up to MAX_CHUNKS chunks (multiples of 256 points) issued on two alternating streams.  The
+// Large batches are cut into up to MAX_CHUNKS chunks (multiples of 256 points; dxmat.hip caps the three-stream scheme at 24).  The
 // last chunk's host expansion is not hidden behind any transfer: many small chunks keep that tail short.
 struct ChunkPlan {
   int nchunks;

@@ -225,7 +225,7 @@ uint64_t dxm_launch_generation(const dxm_material* m);
  * the flux / tangent / stats.  Call after every replay, before dxm_advance / dxm_get_stats / dxm_get_state. */
 int dxm_notify_replay(dxm_material* m);
 /* Per-handle options (no environment variables are read by the library):
- *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on two streams (default 1)
+ *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on several streams (default 1)
  *   "split_streams"  1 | 0   how the chunks use the streams when the gradient array is page-locked (DMA uploads).  1 (default):
  *                            uploads and kernels of all chunks on one stream, the downloads of chunk c on one of two others
  *                            behind an event (at most 24 chunks): the device-to-host direction, 80-136 B/point against 48 up, does
