@@ -174,11 +174,13 @@ def test_device_gradient_through_the_map_equals_the_host_gradient_route():
         q.material.close()
 
 
-def test_two_materials_on_disjoint_cells_with_device_gradients_fill_the_same_functions():
+@pytest.mark.parametrize("layout", ["full", "pack4", "sym"])
+def test_two_materials_on_disjoint_cells_with_device_gradients_fill_the_same_functions(layout):
     """A multi-material problem (demos/multimaterials/multimaterials.py:253-257: one QuadratureMap per material, each over its
     cells): both maps evaluate their strain on the GPU from the one displacement vector (a mesh object per map, connectivity
     restricted to its cells) and the engine stores stress and tangent blocks in the rows of that map -- against the same two
-    maps with host-evaluated strains, and against their restated reference cadence."""
+    maps with host-evaluated strains, and against their restated reference cadence.  ``layout``: the rows forms move the rows of
+    a packed tangent layout as they are (``dxm_integrate_rows`` / ``dxm_integrate_displacement_rows`` with a 4- / 21-wide Function)."""
     from dolfinx_materials_amd.gradient import Hex8Mesh
 
     import os
@@ -197,8 +199,10 @@ def test_two_materials_on_disjoint_cells_with_device_gradients_fill_the_same_fun
         maps = []
         for law, cells in laws.values():
             cls = FieldMapBase if route == "cadence" else QuadratureFieldMap
-            q = cls(mesh.num_cells, mesh.nqp, JAXMaterial(_behavior(law)), cells=cells)
+            q = cls(mesh.num_cells, mesh.nqp, JAXMaterial(_behavior(law), tangent_layout=layout), cells=cells)
             q.register_gradient("strain", lambda c: mesh.strain(u["now"], c))
+            if route != "cadence":
+                assert q._accel_plan().row_outputs
             if route == "device":
                 q.register_device_gradient(Hex8Mesh(mesh.coords, mesh.conn[cells]), lambda: u["now"])
                 assert q._accel_plan().row_outputs and not q._accel_plan().identity
