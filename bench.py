@@ -791,16 +791,29 @@ def stream_probes(torch, dev, n, stream, kernel_launch, eps, flux, ct, reps=30, 
     return out
 
 
-def source_hash():
-    """Identity of the device code the numbers belong to: sha1 over the kernel sources and the ABI header (what
-    `make` compiles into libdxmat.so); stamped into profiles/pmc_traffic.json by tools/summarize_profile.py."""
+def _code_only(text):
+    """C / C++ source without comments and with runs of white space collapsed (string literals are kept as they are): what the
+    compiler sees.  A comment edit does not make a measurement belong to other code."""
+    import re
+
+    pattern = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'', re.S)
+    text = pattern.sub(lambda m: " " if m.group(0).startswith("/") else m.group(0), text)
+    return re.sub(r"\s+", " ", text).strip()
+
+
+def source_hash(root=None, read=None):
+    """Identity of the code the numbers belong to: sha1 over the kernel sources and the ABI header (what `make` compiles into
+    libdxmat.so) with comments and white space taken out (`_code_only`); stamped into profiles/pmc_traffic.json by
+    tools/summarize_profile.py.  `read(path) -> str` lets a caller hash another revision (`git show <rev>:<path>`)."""
     import hashlib
 
-    d = os.path.join(ROOT, "dolfinx_materials_amd", "csrc")
-    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".hpp"))) + [os.path.join(ROOT, "include", "dxmat.h")]
+    root = root or ROOT
+    d = os.path.join(root, "dolfinx_materials_amd", "csrc")
+    names = sorted(os.path.join("dolfinx_materials_amd", "csrc", f) for f in os.listdir(d) if f.endswith((".hip", ".hpp"))) + [os.path.join("include", "dxmat.h")]
+    read = read or (lambda rel: open(os.path.join(root, rel), encoding="utf-8").read())
     h = hashlib.sha1()
-    for f in files:
-        h.update(open(f, "rb").read())
+    for rel in names:
+        h.update(rel.encode() + b"\0" + _code_only(read(rel)).encode() + b"\0")
     return h.hexdigest()[:16]
 
 

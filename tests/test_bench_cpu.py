@@ -44,3 +44,19 @@ def test_self_launcher_propagates_a_failing_rank_without_hanging():
 
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "needs a GPU" in r.stderr
+
+
+def test_source_hash_ignores_comments_and_matches_the_stamped_traffic_file():
+    """`bench.source_hash`: the identity of the code a measurement belongs to -- comments and white space do not change it, code does --
+    and `profiles/pmc_traffic.json` carries the hash of the shipped sources."""
+    import json
+    import os
+
+    import bench
+
+    code = 'int a = 1; // one\n/* block\n comment */ const char* s = "// kept /* kept */";\n\n   double  b = a /2.0 ;'
+    same = 'int a = 1;\nconst char* s = "// kept /* kept */"; double b = a /2.0 ; // trailing'
+    assert bench._code_only(code) == bench._code_only(same)
+    assert bench._code_only(code) != bench._code_only(code.replace("2.0", "3.0"))
+    stamped = json.load(open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.json")))
+    assert stamped["source_hash"] == bench.source_hash()
