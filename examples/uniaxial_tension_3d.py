@@ -3,7 +3,7 @@
 driver ``tests/uniaxial_tension.py:11-118`` (BASELINE.json configs[4]) with the stand-in host FE
 loop of ``examples/hex_fem.py`` (dolfinx is not available) and the GPU constitutive update.
 
-    python examples/uniaxial_tension_3d.py [--n 16] [--steps 10] [--law j2_linear|fefp] [--layout full|sym|coef]
+    python examples/uniaxial_tension_3d.py [--n 16] [--steps 10] [--law j2_linear|fefp] [--layout full|sym|coef|pack4]
     python examples/uniaxial_tension_3d.py --n 64 --steps 8 --layout coef --device-gradient     # the config-5 stand-in (8 load steps: the
                                                                                                   # bare Newton of hex_fem.py has no line search for bigger jumps)
 
@@ -36,8 +36,8 @@ def run(n=8, steps=10, law="j2_linear", exx_max=2e-2, verbose=True, device_gradi
     mesh = HexMesh(n)
     u = np.zeros(mesh.ndof)
     if law == "j2_linear":
-        # layout: what the host assembly consumes -- the (N,6,6) block, its 21-entry upper triangle, or the nine
-        # coefficients of Ct = c1 1x1 + c2 I + c3 n x n (hex_fem.HexMesh.element_matrices)
+        # layout: what the host assembly consumes -- the (N,6,6) block, its 21-entry upper triangle, the nine coefficients of
+        # Ct = c1 1x1 + c2 I + c3 n x n, or (c1, c2, c3, w) with n = dev(stress) w (hex_fem.HexMesh.element_matrices)
         material = JAXMaterial(jm.vonMisesIsotropicHardening(el, jm.LinearHardening(sig0, H)), tangent_layout=layout)
         gname, fname, B = "strain", "stress", mesh.B_eps
         evaluator = lambda cells: mesh.strain(u, cells)  # noqa: E731
@@ -80,7 +80,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--law", default="j2_linear")
     ap.add_argument("--device-gradient", action="store_true")
-    ap.add_argument("--layout", default="full", choices=["full", "sym", "coef"])
+    ap.add_argument("--layout", default="full", choices=["full", "sym", "coef", "pack4"])
     ap.add_argument("--solver", default="auto", choices=["auto", "direct", "krylov"])
     ap.add_argument("--exx", type=float, default=2e-2)
     a = ap.parse_args()
