@@ -1052,12 +1052,19 @@ static int run_and_download(dxm_material* m, Upload upload, double* flux_aos, do
   // kernel_done event.  An upload queued on the stream that also carries a chunk's downloads costs the device-to-host
   // direction -- 80 to 136 B/point against 48 up -- 4-8 ms per 1e7 points (raw HIP calls: 27-32 ms against 24-25); split,
   // the 1.36 GB of a pack4 update with its state fields land in 25.4 ms (53 GB/s) instead of 27.4-30.6, the 0.8 GB of the lazy
-  // mode in 15.6 ms instead of 20-24, and the times stop moving from call to call.  At most 24 chunks then: from 32 chunks of
-  // four downloads (or 64 of two) on, the same scheme runs at a third of the link rate (profiles/r06_packed_update.md).
+  // mode in 15.6 ms instead of 20-24, and the times stop moving from call to call.  With too many chunks the same scheme runs at
+  // a third of the link rate (1e7 points: from 32 chunks of four downloads, or 64 of two, on; profiles/r06_packed_update.md):
+  // the number of chunks is capped below.
   // Staged uploads (a pageable gradient array through the ring) and the fused displacement form (no per-chunk upload at
   // all) keep the two alternating streams.
   const bool split_ok = m->opt_split_streams && m->opt_pipeline && host_grad == nullptr && fused == nullptr;
-  const dxm_host::ChunkPlan plan = dxm_host::plan_chunks(n, short_chunks, host_grad != nullptr, split_ok && m->opt_max_chunks > 24 ? 24 : m->opt_max_chunks, m->opt_pipeline);
+  // How many chunks the three-stream scheme takes before it turns slower than the two alternating streams grows with the batch
+  // (profiles/r06_hostpath_split_chunk_sweep.jsonl, 3e5 ... 1e7 points x 2 ... 24 chunks): 6 at 3e5 points, 8 at 1e6, 12 at
+  // 2-3e6, 16 at 5e6, 24 at 1e7 -- one chunk more and the call takes up to 1.7 x as long.  7 sqrt(n / 1e6) stays on the good
+  // side at every size measured (4, 7, 9-12, 15, 22), where the scheme beats alternating chunks by 8-25 %.
+  int split_cap = (int)(7.0 * std::sqrt((double)n / 1e6));
+  split_cap = split_cap < 1 ? 1 : (split_cap > 24 ? 24 : split_cap);
+  const dxm_host::ChunkPlan plan = dxm_host::plan_chunks(n, short_chunks, host_grad != nullptr, split_ok && m->opt_max_chunks > split_cap ? split_cap : m->opt_max_chunks, m->opt_pipeline);
   const int nchunks = plan.nchunks;
   for (int c = 0; c < nchunks; ++c)
     if (!m->chunk_done[c]) HIP_TRY(hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming));

@@ -228,7 +228,7 @@ int dxm_notify_replay(dxm_material* m);
  *   "pipeline"       1 | 0   host-buffer form: chunked upload / kernel / download on several streams (default 1)
  *   "split_streams"  1 | 0   how the chunks use the streams when the gradient array is page-locked (DMA uploads).  1 (default):
  *                            uploads and kernels of all chunks on one stream, the downloads of chunk c on one of two others
- *                            behind an event (at most 24 chunks): the device-to-host direction, 80-136 B/point against 48 up, does
+ *                            behind an event (7 sqrt(npoints / 1e6) chunks, at most 24): the device-to-host direction, 80-136 B/point against 48 up, does
  *                            not wait behind uploads queued on its own stream.  0: whole chunks alternate between two streams
  *                            (rounds 1-5; still what staged uploads and the displacement forms use)
  *   "max_chunks"     1..64   upper bound on the chunks of that pipeline (default 64)

@@ -19,6 +19,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+SPLIT_CHUNKS = (24, 16)
+
+
 def update_legs(n, reps=11):
     """``integrate`` on the bound Function memory of an accelerated map (what ``update()`` spends its time in), for layout x ISV mode x
     stream scheme; the two stream schemes alternate call by call on ONE handle."""
@@ -43,7 +46,7 @@ def update_legs(n, reps=11):
             now["k"] = 1
             q.update()
             g = q.gradients["strain"].function.x.array.reshape(npts, 6)
-            variants = [("alternating", {"split_streams": 0}), ("split", {"split_streams": 1}), ("split_16", {"split_streams": 1, "max_chunks": 16})]
+            variants = [("alternating", {"split_streams": 0})] + [(f"split_{k}", {"split_streams": 1, "max_chunks": k}) for k in SPLIT_CHUNKS]
             base = {"max_chunks": 64, "split_streams": 1}
             ts = {name: [] for name, _ in variants}
             for r in range(reps + 2):
@@ -221,6 +224,8 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     if "--no-raw" not in sys.argv:
         raw_rates(n)
+    if "--sweep" in sys.argv:
+        SPLIT_CHUNKS = (64, 4, 8, 12, 16, 24)   # 64: the library's own cap for the batch size decides
     if "--fefp" in sys.argv:
         fefp_legs(n)
     elif "--raw-only" not in sys.argv:
