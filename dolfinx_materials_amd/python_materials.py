@@ -18,6 +18,7 @@ class LinearElasticIsotropic(HIPMaterial):
         )
         self.E = E
         self.nu = nu
+        self.C = self.compute_C(E, nu)
 
     @property
     def name(self):
@@ -25,3 +26,23 @@ class LinearElasticIsotropic(HIPMaterial):
 
     def get_Lame_parameters(self, E, nu):
         return E * nu / (1 + nu) / (1 - 2 * nu), E / 2 / (1 + nu)
+
+    def compute_C(self, E, nu):
+        """``elasticity.py:15-19``: ``C = 2 mu I6; C[:3, :3] += lambda`` (Mandel basis)."""
+        import numpy as np
+
+        lmbda, mu = self.get_Lame_parameters(E, nu)
+        C = 2 * mu * np.eye(6)
+        C[:3, :3] += lmbda
+        return C
+
+    def constitutive_update(self, eps, state, dt=0):
+        """The per-point callable in the convention of ``generic.Material`` (``elasticity.py:21-24``): returns ``(C, state)`` -- the
+        TANGENT, not the stress -- with ``state["Stress"]`` set in the dictionary that was passed.  (``JAXMaterial.constitutive_update``
+        returns ``(stress, new_state)``, ``jaxmat.py:158-164``; ``batched_constitutive_update`` returns ``(Ct, new_state)`` in both.)"""
+        import numpy as np
+
+        known = {k: np.asarray(v, dtype=np.float64).reshape(1, -1) for k, v in state.items() if k in self.variables}
+        Ct, new = self.batched_constitutive_update(np.asarray(eps, dtype=np.float64).reshape(1, -1), known, dt)
+        state["Stress"] = new["Stress"][0]
+        return Ct[0], state

@@ -124,3 +124,21 @@ def test_natural_state_has_the_shapes_of_the_state_dictionaries(fake):
     st = mat.natural_state(4)
     assert {k: v.shape for k, v in st.items()} == {"strain": (4, 6), "stress": (4, 6), "p": (4, 1), "epsp": (4, 6)}
     assert all(not v.any() for v in st.values())
+
+
+def test_python_materials_callable_follows_the_generic_convention(fake):
+    """``python_materials.LinearElasticIsotropic.constitutive_update(eps, state, dt)`` returns ``(C, state)`` with ``state["Stress"]``
+    set, like the reference's (``python_materials/elasticity.py:21-24``; the JAX materials return ``(stress, new_state)``); the batched
+    form is the ``_vmap`` of it: ``(Ct (N,6,6), state of (N, dim) arrays)`` (``generic.py:115-117``)."""
+    from dolfinx_materials_amd.python_materials import LinearElasticIsotropic
+
+    mat = LinearElasticIsotropic(70e3, 0.3)
+    mat.set_data_manager(2)
+    eps = np.array([1e-3, -2e-4, 3e-4, 5e-4, 0.0, -1e-4])
+    state = {}
+    C, out = mat.constitutive_update(eps, state, 0)
+    assert out is state and C.shape == (6, 6) and np.allclose(C, onp.elastic_matrix(70e3, 0.3), rtol=1e-14) and np.array_equal(mat.C, onp.elastic_matrix(70e3, 0.3))
+    assert np.allclose(state["Stress"], onp.elastic_matrix(70e3, 0.3) @ eps, rtol=1e-13)
+    Ct, new = mat.batched_constitutive_update(np.tile(eps, (5, 1)), {}, 0)
+    assert Ct.shape == (5, 6, 6) and new["Stress"].shape == (5, 6) and np.allclose(new["Stress"][3], state["Stress"], rtol=1e-14)
+    mat.close()
