@@ -127,6 +127,10 @@ def test_natural_state_has_the_shapes_of_the_state_dictionaries(fake):
 
 
 def test_python_materials_callable_follows_the_generic_convention(fake):
+    check_python_materials_callable()
+
+
+def check_python_materials_callable():
     """``python_materials.LinearElasticIsotropic.constitutive_update(eps, state, dt)`` returns ``(C, state)`` with ``state["Stress"]``
     set, like the reference's (``python_materials/elasticity.py:21-24``; the JAX materials return ``(stress, new_state)``); the batched
     form is the ``_vmap`` of it: ``(Ct (N,6,6), state of (N, dim) arrays)`` (``generic.py:115-117``)."""

@@ -101,3 +101,9 @@ def test_explicit_state_update_of_the_fefp_law_against_the_oracle():
     for k, v in mat.get_initial_state_dict().items():
         assert np.array_equal(np.asarray(v), own[k]), k
     mat.close()
+
+
+def test_python_materials_callable_follows_the_generic_convention():
+    from test_explicit_state_cpu import check_python_materials_callable
+
+    check_python_materials_callable()
