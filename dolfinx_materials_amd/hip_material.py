@@ -224,6 +224,11 @@ class HIPMaterial:
             for h, *_ in self._parts:
                 self._chk(self._lib.dxm_set_params(h, prm.ctypes.data_as(C.POINTER(C.c_double)), prm.size))
 
+    def default_properties(self):
+        """``generic.py:122-123``: the base class's (empty) defaults -- the properties of a behaviour live in ``material_properties``
+        (``jaxmat.py:146``: the flattened behaviour)."""
+        return {}
+
     def set_newton(self, maxit=25, rtol=1e-14):
         for h in self._handles():
             self._chk(self._lib.dxm_set_newton(h, int(maxit), float(rtol)))
