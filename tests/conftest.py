@@ -57,11 +57,18 @@ def no_hip_error_left_behind(request):
     if _hip is None:
         import ctypes
 
-        try:
-            _hip = ctypes.CDLL("libamdhip64.so")
-            _hip.hipGetErrorName.restype = ctypes.c_char_p
-        except OSError:
-            _hip = False
+        # the runtime the process ALREADY uses (torch's, preloaded into the global symbol scope by _lib.load; else the one libdxmat.so
+        # linked): never a second copy by file name -- its "last error" would be another runtime's and always 0
+        _hip = False
+        for candidate in (None, "libamdhip64.so"):
+            try:
+                lib = ctypes.CDLL(candidate)
+                lib.hipGetLastError, lib.hipGetErrorName
+                lib.hipGetErrorName.restype = ctypes.c_char_p
+                _hip = lib
+                break
+            except (OSError, AttributeError):
+                continue
     if _hip:
         err = _hip.hipGetLastError()
         assert err == 0, f"the test left HIP error {err} ({_hip.hipGetErrorName(err).decode()}) in the runtime's last-error state"
