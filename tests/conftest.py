@@ -60,11 +60,17 @@ def no_hip_error_left_behind(request):
         # the runtime the process ALREADY uses (torch's, preloaded into the global symbol scope by _lib.load; else the one libdxmat.so
         # linked): never a second copy by file name -- its "last error" would be another runtime's and always 0
         _hip = False
-        for candidate in (None, "libamdhip64.so"):
+        mapped = []
+        try:   # the copy that is mapped into this process (the one libdxmat.so / torch resolved), by its path
+            with open("/proc/self/maps") as maps:
+                mapped = sorted({line.split()[-1] for line in maps if "libamdhip64.so" in line})
+        except OSError:
+            pass
+        for candidate in mapped + ["libamdhip64.so"]:
             try:
                 lib = ctypes.CDLL(candidate)
-                lib.hipGetLastError, lib.hipGetErrorName
                 lib.hipGetErrorName.restype = ctypes.c_char_p
+                lib.hipGetLastError
                 _hip = lib
                 break
             except (OSError, AttributeError):
